@@ -1,0 +1,216 @@
+"""Pins oracle/a3t_oracle.py against the golden vectors produced by the reference
+itself (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import a3t_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_param_inventory_matches_reference_count():
+    # 67 691 328 parameters for the reference yaml (probe)
+    shapes = O.param_shapes(O.A3TConfig())
+    n = sum(int(np.prod(s)) for k, s in shapes.items() if "running" not in k and "num_batches" not in k)
+    assert n == 67691328 == int(_load("e2e_refyaml.npz")["n_params"])
+    assert len(shapes) == 363  # == len(reference state_dict), asserted in make_golden.py
+
+
+def test_masks_bit_exact():
+    g = _load("masks.npz")
+    for i in range(7):
+        k = f"c{i}."
+        B, P, T = int(g[k + "B"]), int(g[k + "P"]), int(g[k + "T"])
+        smask = np.arange(T)[None] < g[k + "tl"][:, None]
+        np.random.seed(int(g[k + "seed"]))
+        mp = O.phones_masking(T, smask, g[k + "a_s"], g[k + "a_e"], g[k + "lens"], float(g[k + "prob"]),
+                              int(g[k + "span"]))
+        assert np.array_equal(mp, g[k + "masked"]), i
+        # numpy global RNG consumed identically
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g[k + "rng_after"]), i
+        sp, tp = O.get_segment_pos(T, P, g[k + "a_s"], g[k + "a_e"], g[k + "lens"], True)
+        assert np.array_equal(sp, g[k + "sp"]) and np.array_equal(tp, g[k + "tp"])
+    T = int(g["sb.T"])
+    smask = np.arange(T)[None] < g["sb.tl"][:, None]
+    mp = O.phones_masking(T, smask, np.zeros((2, 3), np.int32), np.zeros((2, 3), np.int32), [3, 3], 0.8, 8,
+                          span_boundary=g["sb.sb"])
+    assert np.array_equal(mp, g["sb.masked"])
+    np.random.seed(5)
+    assert np.array_equal(O.random_spans_noise_mask(37, 0.8, 8), g["rsnm.len37"])
+    assert np.array_equal(O.random_spans_noise_mask(2, 0.8, 8), g["rsnm.len2"])
+
+
+def test_align_frames_bit_exact():
+    g = _load("masks.npz")
+    fr = O.align_to_frames(torch.from_numpy(g["align.sec"]), 24000, 300).numpy()
+    assert np.array_equal(fr, g["align.frames"])
+
+
+def test_logmel():
+    g = _load("logmel.npz")
+    feats, flen = O.logmel_fbank(torch.from_numpy(g["wav"]), torch.from_numpy(g["lens"]), O.A3TConfig())
+    assert np.array_equal(flen.numpy(), g["feats_lengths"])
+    np.testing.assert_allclose(feats.numpy(), g["feats"], atol=1e-4, rtol=0)
+
+
+def test_collate_matches_reference_collate_fn():
+    g = _load("collate.npz")
+    data = []
+    for i in range(2):
+        data.append((f"utt{i}", {k: g[f"in{i}.{k}"] for k in ("speech", "text", "align_start", "align_end")}))
+    np.random.seed(77)
+    _, b = O.collate(data, O.tiny_config())
+    for k in ("text", "masked_position", "speech_mask", "text_mask", "speech_segment_pos", "text_segment_pos",
+              "speech_lengths", "text_lengths"):
+        assert np.array_equal(b[k].numpy(), g["out." + k]), k
+    np.testing.assert_allclose(b["speech"].numpy(), g["out.speech"], atol=1e-4)
+
+
+def test_relshift_bit_exact():
+    g = _load("block384.npz")
+    for T in (5, 37):
+        out = O.rel_shift_legacy(torch.from_numpy(g[f"relshift_in{T}"])).numpy()
+        assert np.array_equal(out, g[f"relshift_out{T}"])
+        # closed form used by the HIP kernels (SURVEY §7 hard parts)
+        bd = g[f"relshift_in{T}"][0, 0]
+        ref = g[f"relshift_out{T}"][0, 0]
+        for i in range(T):
+            for j in range(T):
+                if j <= i:
+                    v = bd[i, T - 1 - (i - j)]
+                elif j == i + 1:
+                    v = 0.0
+                else:
+                    v = bd[i + 1, j - i - 2]
+                assert v == ref[i, j]
+
+
+def test_attention_and_block_384():
+    g = _load("block384.npz")
+    c = O.A3TConfig(enc_blocks=1, dec_blocks=1, postnet_layers=2, postnet_chans=16)
+    p = O.to_torch_state(O.procedural_state(O.param_shapes(c), seed=2), requires_grad=True)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    mask = torch.from_numpy(g["mask"])
+    gy = torch.from_numpy(g["g"])
+    T = x.shape[1]
+    pos = O.legacy_pe(c, T)[None]
+    pre = "encoder.encoders.0.self_attn."
+    out, probs = O.attention(x, pos, mask, p, pre, c, return_probs=True)
+    np.testing.assert_allclose(out.detach().numpy(), g["attn_out"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(probs.detach().numpy(), g["attn_probs"], atol=1e-6)
+    (out * gy).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["attn_dx"], atol=5e-5, rtol=1e-4)
+    for n in ("pos_bias_u", "pos_bias_v", "linear_q.weight", "linear_pos.weight", "linear_out.bias"):
+        np.testing.assert_allclose(p[pre + n].grad.numpy(), g["attn_grad." + n], atol=2e-4, rtol=1e-4)
+    # whole block
+    for t in p.values():
+        if t.grad is not None:
+            t.grad = None
+    x2 = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = O.conformer_block(x2, pos, mask, p, "encoder.encoders.0.", c, c.enc_kernel, True)
+    np.testing.assert_allclose(y.detach().numpy(), g["block_out"], atol=5e-5, rtol=1e-4)
+    (y * gy).sum().backward()
+    np.testing.assert_allclose(x2.grad.numpy(), g["block_dx"], atol=2e-4, rtol=1e-3)
+    for n, ref in zip(g["block_gradnames"], g["block_gradnorm"]):
+        got = float(p["encoder.encoders.0." + str(n)].grad.norm())
+        assert abs(got - ref) <= 1e-3 * max(ref, 1e-2), (n, got, ref)  # dw bias grad is analytically 0 (BN)
+
+
+def _tiny_batch():
+    c = O.tiny_config()
+    return c, O.synthetic_batch(c, B=2, T_mel=48, T_phn=8, seed=11, lengths=[48, 37], text_lengths=[8, 6])
+
+
+def test_e2e_tiny_train_and_eval():
+    g = _load("e2e_tiny.npz")
+    c, batch = _tiny_batch()
+    p = O.to_torch_state(O.procedural_state(O.param_shapes(c), seed=1), requires_grad=True)
+    stats = {}
+    loss, before, after = O.forward_loss(p, batch, c, True, stats)
+    assert abs(float(loss) - float(g["loss"])) < 1e-3          # |loss| ~ 6e2 -> 2e-6 relative
+    np.testing.assert_allclose(before.detach().numpy(), g["before"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(after.detach().numpy(), g["after"], atol=1e-4, rtol=1e-4)
+    loss.backward()
+    for k in g.files:
+        if k.startswith("grad."):
+            n = k[5:]
+            got = p[n].grad
+            got = np.zeros(p[n].shape, np.float32) if got is None else got.numpy()
+            ref = g[k]
+            np.testing.assert_allclose(got, ref, atol=3e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, err_msg=n)
+    # BN running stats after one train step (momentum 0.1, unbiased var)
+    for pre, (mean, var_u) in stats.items():
+        rm = 0.9 * p[pre + ".running_mean"] + 0.1 * mean
+        rv = 0.9 * p[pre + ".running_var"] + 0.1 * var_u
+        np.testing.assert_allclose(rm.numpy(), g["buf." + pre + ".running_mean"], atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(rv.numpy(), g["buf." + pre + ".running_var"], atol=1e-5, rtol=1e-4)
+    with torch.no_grad():
+        le, _, _ = O.forward_loss(p, batch, c, False)
+        assert abs(float(le) - float(g["loss_eval"])) < 1e-3
+        b1 = {k: v[:1] for k, v in batch.items()}
+        sp = O.inference_splice(p, b1, c, (10, 30))
+    np.testing.assert_allclose(sp.numpy(), g["infer_splice"], atol=1e-4, rtol=1e-4)
+
+
+def test_e2e_reference_yaml():
+    g = _load("e2e_refyaml.npz")
+    c = O.A3TConfig()
+    batch = O.synthetic_batch(c, B=2, T_mel=200, T_phn=30, seed=12, lengths=[200, 163], text_lengths=[30, 24])
+    p = O.to_torch_state(O.procedural_state(O.param_shapes(c), seed=3), requires_grad=True)
+    loss, before, after = O.forward_loss(p, batch, c, True)
+    assert abs(float(loss) - float(g["loss"])) < 1e-3
+    np.testing.assert_allclose(before.detach().numpy(), g["before"], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(after.detach().numpy(), g["after"], atol=2e-4, rtol=1e-4)
+    loss.backward()
+    for n, gn, gs in zip(g["grad_names"], g["grad_norm"], g["grad_sum"]):
+        gr = p[str(n)].grad.double()
+        assert abs(float(gr.norm()) - gn) <= 2e-3 * max(gn, 1e-2), (n, float(gr.norm()), gn)
+
+
+def test_pwg():
+    g = _load("pwg.npz")
+    cfg = O.PWGConfig()
+    shapes = O.pwg_param_shapes(cfg)
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(g["n_params"]) == 1334311
+    state = O.procedural_state(shapes, seed=4)
+    for k in state:
+        if "up_layers" in k:
+            state[k] = np.abs(state[k]) / np.abs(state[k]).sum()
+    p = O.to_torch_state(state)
+    taps = {}
+    with torch.no_grad():
+        wav = O.pwg_forward(p, torch.from_numpy(g["c"]).T[None], torch.from_numpy(g["z"]).T[None], cfg, taps)
+    np.testing.assert_allclose(wav[0].T.numpy(), g["wav"], atol=1e-5, rtol=1e-4)
+    for k in ("x0", "skip0", "x1", "skip1"):
+        np.testing.assert_allclose(taps[k].numpy()[..., :256], g[k], atol=1e-5, rtol=1e-4)
+
+
+def test_noam_and_adam_against_torch():
+    # NoamLR formula + Adam/clip restatement vs torch.optim.Adam + clip_grad_norm_
+    rs = np.random.RandomState(0)
+    ps = [torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for s in [(7, 5), (11,), (3, 4, 2)]]
+    ref = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam(ref, lr=1.0)
+    m = [torch.zeros_like(p) for p in ps]
+    v = [torch.zeros_like(p) for p in ps]
+    for step in range(1, 4):
+        gs = [torch.from_numpy(rs.standard_normal(p.shape).astype(np.float32)) * 3 for p in ps]
+        lr = O.noam_lr(step, 1.0, 384, 4000)
+        for g_ in opt.param_groups:
+            g_["lr"] = lr
+        for r, g_ in zip(ref, gs):
+            r.grad = g_.clone()
+        tn = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt.step()
+        n = O.clip_adam_step(ps, gs, m, v, step, lr, 1.0)
+        assert abs(float(n) - float(tn)) < 1e-4
+        for a, b in zip(ps, ref):
+            np.testing.assert_allclose(a.numpy(), b.detach().numpy(), atol=1e-6, rtol=1e-5)
+    assert abs(O.noam_lr(1, 1.0, 384, 4000) - 384 ** -0.5 * 4000 ** -1.5) < 1e-12
