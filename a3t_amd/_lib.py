@@ -1,0 +1,97 @@
+"""ctypes binding of liba3t_hip.so (include/a3t_hip.h).  Fails loudly when the HIP library is
+missing: there is no CPU fallback anywhere in the product path."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "liba3t_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3
+ACC_STORE, ACC_ADD, ACC_ATOMIC = 0, 1, 2
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("R", c_void_p), ("S", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("a_rs", c_int64), ("a_cs", c_int64),
+        ("b_rs", c_int64), ("b_cs", c_int64), ("b_ts", c_int64),
+        ("c_rs", c_int64),
+        ("batch", c_int32), ("batch_inner", c_int32),
+        ("a_bs0", c_int64), ("a_bs1", c_int64), ("b_bs0", c_int64), ("b_bs1", c_int64),
+        ("c_bs0", c_int64), ("c_bs1", c_int64),
+        ("taps", c_int32), ("pad", c_int32), ("dil", c_int32), ("Tseq", c_int32), ("kshift", c_int32),
+        ("alpha", c_float),
+        ("act", c_int32), ("accumulate", c_int32), ("splitk", c_int32),
+        ("a_dtype", c_int32), ("b_dtype", c_int32), ("c_dtype", c_int32), ("compute", c_int32),
+    ]
+
+
+_P = c_void_p
+_SIGS = {
+    "a3t_gemm": [POINTER(GemmDesc), _P],
+    "a3t_layernorm_fwd": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P],
+    "a3t_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    "a3t_col_reduce": [_P, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
+    "a3t_f64_to_f32_add": [_P, _P, c_int, c_float, _P],
+    "a3t_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_int, c_int, _P],
+    "a3t_bn_act_bwd_a": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "a3t_bn_act_bwd_b": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "a3t_glu_dwconv_fwd": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "a3t_glu_dwconv_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "a3t_add_pos_bias": [_P, _P, _P, _P, _P, c_int, c_int, _P],
+    "a3t_add_pos_bias_bwd": [_P, _P, _P, c_int, c_int, _P],
+    "a3t_relpos_softmax_fwd": [_P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P],
+    "a3t_relpos_softmax_bwd": [_P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P],
+    "a3t_mask_fill": [_P, _P, _P, _P, c_int, c_int, _P],
+    "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
+    "a3t_embed_finish_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    "a3t_scale": [_P, _P, c_int64, c_float, _P],
+    "a3t_axpy": [_P, _P, c_int64, c_float, _P],
+    "a3t_slice_rows": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "a3t_mlm_loss": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
+    "a3t_mlm_loss_scratch_floats": [c_int],
+    "a3t_sumsq": [_P, c_int64, _P, _P],
+    "a3t_clip_adam": [_P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, c_float,
+                      _P],
+    "a3t_pwg_gate": [_P, _P, _P, c_int64, c_int, _P],
+    "a3t_pwg_res_skip": [_P, _P, _P, c_int64, c_int, c_int, _P],
+    "a3t_pwg_upsample": [_P, _P, _P, c_int64, c_int, c_int, _P],
+    "a3t_replicate_pad": [_P, _P, c_int64, c_int, c_int, _P],
+    "a3t_bias_act": [_P, _P, c_int64, c_int, c_int, c_float, _P],
+    "a3t_dropout": [_P, _P, c_int64, c_float, c_uint64, c_uint64, _P],
+}
+EXPORTS = sorted(list(_SIGS) + ["a3t_version"])
+
+_lib = None
+
+
+class A3TLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liba3t_hip.so (built by a3t_amd/build.py).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise A3TLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m a3t_amd.build` (hipcc --offload-arch=gfx950). "
+            "a3t_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = c_int
+    lib.a3t_version.restype = c_char_p
+    lib.a3t_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise A3TLibraryError(f"liba3t_hip call failed ({what}): rc={rc}")

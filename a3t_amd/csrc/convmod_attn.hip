@@ -1,0 +1,284 @@
+// convmod_attn.hip -- Conformer convolution-module kernels (GLU + depthwise Conv1d with the time
+// window staged in LDS) and the rel-pos softmax kernels of the materialised attention path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/a3t_hip.h"
+
+#define WAVE 64
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// GLU + depthwise conv.  Block = 64 channels (lanes) x 4 row lanes; time tile TT rows of one
+// utterance; the GLU'd window [t0-pad, t0+TT+pad) x 64 channels lives in LDS (<= 94x64 floats).
+// ------------------------------------------------------------------------------------------
+#define DW_TT 64
+#define DW_KMAX 31
+
+__global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const float* __restrict__ g, const float* __restrict__ wdw,
+                                                             const float* __restrict__ bdw, float* __restrict__ glu,
+                                                             float* __restrict__ z, int C, int K, int Tseq,
+                                                             int tiles_t) {
+    __shared__ float win[DW_TT + DW_KMAX - 1][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int b = blockIdx.y / tiles_t, t0 = (blockIdx.y % tiles_t) * DW_TT;
+    const int pad = (K - 1) / 2;
+    const int64_t mbase = (int64_t)b * Tseq;
+    const int rows = DW_TT + K - 1;
+    for (int r = ty; r < rows; r += 4) {
+        int t = t0 - pad + r;
+        float v = 0.f;
+        if (c < C && t >= 0 && t < Tseq) {
+            const float* gr = g + (mbase + t) * (int64_t)(2 * C);
+            v = gr[c] * sigm(gr[C + c]);
+            if (r >= pad && r < pad + DW_TT) glu[(mbase + t) * (int64_t)C + c] = v;
+        }
+        win[r][tx] = v;
+    }
+    __syncthreads();
+    if (c >= C) return;
+    float w[DW_KMAX];
+#pragma unroll
+    for (int k = 0; k < DW_KMAX; ++k) w[k] = (k < K) ? wdw[(int64_t)c * K + k] : 0.f;
+    const float bias = bdw[c];
+    for (int r = ty; r < DW_TT; r += 4) {
+        int t = t0 + r;
+        if (t >= Tseq) break;
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < DW_KMAX; ++k)
+            if (k < K) acc += w[k] * win[r + k][tx];
+        z[(mbase + t) * (int64_t)C + c] = acc;
+    }
+}
+
+extern "C" int a3t_glu_dwconv_fwd(const float* g, const float* wdw, const float* bdw, float* glu, float* z, int M,
+                                  int C, int K, int Tseq, void* stream) {
+    if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
+    int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
+    dim3 grid((C + 63) / 64, B * tiles_t);
+    hipLaunchKernelGGL(glu_dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, wdw, bdw, glu, z, C, K, Tseq,
+                       tiles_t);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ g,
+                                                             const float* __restrict__ glu,
+                                                             const float* __restrict__ wdw, float* __restrict__ dg,
+                                                             float* dwdw, float* dbdw, int C, int K, int Tseq,
+                                                             int tiles_t) {
+    __shared__ float wdz[DW_TT + DW_KMAX - 1][64];   // dz window  (rows t0-pad .. t0+TT+pad)
+    __shared__ float wgl[DW_TT + DW_KMAX - 1][64];   // glu window
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int b = blockIdx.y / tiles_t, t0 = (blockIdx.y % tiles_t) * DW_TT;
+    const int pad = (K - 1) / 2;
+    const int64_t mbase = (int64_t)b * Tseq;
+    const int rows = DW_TT + K - 1;
+    for (int r = ty; r < rows; r += 4) {
+        int t = t0 - pad + r;
+        float a = 0.f, q = 0.f;
+        if (c < C && t >= 0 && t < Tseq) {
+            a = dz[(mbase + t) * (int64_t)C + c];
+            q = glu[(mbase + t) * (int64_t)C + c];
+        }
+        wdz[r][tx] = a;
+        wgl[r][tx] = q;
+    }
+    __syncthreads();
+    float w[DW_KMAX], dw[DW_KMAX];
+#pragma unroll
+    for (int k = 0; k < DW_KMAX; ++k) {
+        w[k] = (k < K && c < C) ? wdw[(int64_t)c * K + k] : 0.f;
+        dw[k] = 0.f;
+    }
+    float db = 0.f;
+    if (c < C) {
+        for (int r = ty; r < DW_TT; r += 4) {
+            int t = t0 + r;
+            if (t >= Tseq) break;
+            // data gradient: dglu[t] = sum_k w[k] * dz[t + pad - k]  (window row r + 2*pad - k ... )
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < DW_KMAX; ++k)
+                if (k < K) acc += w[k] * wdz[r + 2 * pad - k][tx];
+            const float* gr = g + (mbase + t) * (int64_t)(2 * C);
+            float ga = gr[c], sb = sigm(gr[C + c]);
+            float* dgr = dg + (mbase + t) * (int64_t)(2 * C);
+            dgr[c] = acc * sb;
+            dgr[C + c] = acc * ga * sb * (1.f - sb);
+            // weight gradient: dw[k] += dz[t] * glu[t + k - pad]
+            float dzt = wdz[r + pad][tx];
+            db += dzt;
+#pragma unroll
+            for (int k = 0; k < DW_KMAX; ++k)
+                if (k < K) dw[k] += dzt * wgl[r + k][tx];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DW_KMAX; ++k) {
+        if (k >= K) break;
+        red[ty][tx] = dw[k];
+        __syncthreads();
+        if (ty == 0 && c < C) atomicAdd(&dwdw[(int64_t)c * K + k], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+        __syncthreads();
+    }
+    red[ty][tx] = db;
+    __syncthreads();
+    if (ty == 0 && c < C) atomicAdd(&dbdw[c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+extern "C" int a3t_glu_dwconv_bwd(const float* dz, const float* g, const float* glu, const float* wdw, float* dg,
+                                  float* dwdw, float* dbdw, int M, int C, int K, int Tseq, void* stream) {
+    if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
+    int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
+    dim3 grid((C + 63) / 64, B * tiles_t);
+    hipLaunchKernelGGL(glu_dwconv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, g, glu, wdw, dg, dwdw, dbdw,
+                       C, K, Tseq, tiles_t);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// attention helpers
+// ------------------------------------------------------------------------------------------
+__global__ void add_pos_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bu,
+                                    const float* __restrict__ bv, float* __restrict__ qu, float* __restrict__ qv,
+                                    int64_t n, int d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / d;
+        int c = (int)(i - m * d);
+        float q = qkv[m * 3 * d + c];
+        qu[i] = q + bu[c];
+        qv[i] = q + bv[c];
+    }
+}
+extern "C" int a3t_add_pos_bias(const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv,
+                                int M, int d, void* stream) {
+    int64_t n = (int64_t)M * d;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_pos_bias_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, bias_u, bias_v, qu,
+                       qv, n, d);
+    return (int)hipGetLastError();
+}
+__global__ void add_pos_bias_bwd_kernel(const float* __restrict__ dqu, const float* __restrict__ dqv,
+                                        float* __restrict__ dqkv, int64_t n, int d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t m = i / d;
+        int c = (int)(i - m * d);
+        dqkv[m * 3 * d + c] = dqu[i] + dqv[i];
+    }
+}
+extern "C" int a3t_add_pos_bias_bwd(const float* dqu, const float* dqv, float* dqkv, int M, int d, void* stream) {
+    int64_t n = (int64_t)M * d;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_pos_bias_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dqu, dqv, dqkv, n, d);
+    return (int)hipGetLastError();
+}
+
+// Legacy rel_shift (attention.py:145-165) in closed form on the COMPACT BD = (q+v) P^T matrix:
+//   j <= i : BD[i][T-1-(i-j)]     j == i+1 : 0     j > i+1 : BD[i+1][j-i-2]
+// i.e. each shifted row is two contiguous segments of BD -> coalesced reads, no padded copy.
+__device__ __forceinline__ float bd_shift(const float* __restrict__ BDz, int T, int i, int j) {
+    if (j <= i) return BDz[(int64_t)i * T + (T - 1 - i + j)];
+    if (j == i + 1) return 0.f;
+    return BDz[(int64_t)(i + 1) * T + (j - i - 2)];
+}
+
+// one wave per (z, i) row; three coalesced passes over the row (L1/L2 resident after pass 1)
+__global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __restrict__ ac,
+                                                                 const float* __restrict__ bd,
+                                                                 const uint8_t* __restrict__ keymask,
+                                                                 float* __restrict__ probs, int H, int T,
+                                                                 int64_t ac_bs, int64_t bd_bs, int64_t p_bs,
+                                                                 float scale, int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t zz = row / T;
+    const int i = (int)(row - zz * T);
+    const int b = (int)(zz / H);
+    const float* ar = ac + zz * ac_bs + (int64_t)i * T;
+    const float* bz = bd + zz * bd_bs;
+    const uint8_t* mk = keymask + (int64_t)b * T;
+    float* pr = probs + zz * p_bs + (int64_t)i * T;
+    float mx = -3.4028235e38f;
+    int any = 0;
+    for (int j = lane; j < T; j += 64)
+        if (mk[j]) {
+            mx = fmaxf(mx, (ar[j] + bd_shift(bz, T, i, j)) * scale);
+            any = 1;
+        }
+    mx = wmax(mx);
+    any = __any(any);
+    if (!any) {  // every key padded: softmax over equal fills then masked_fill(0) -> zeros
+        for (int j = lane; j < T; j += 64) pr[j] = 0.f;
+        return;
+    }
+    float s = 0.f;
+    for (int j = lane; j < T; j += 64)
+        if (mk[j]) s += expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx);
+    s = wsum(s);
+    const float inv = 1.f / s;
+    for (int j = lane; j < T; j += 64)
+        pr[j] = mk[j] ? expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx) * inv : 0.f;
+}
+
+extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, float* probs, int B,
+                                      int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs, float scale,
+                                      void* stream) {
+    int64_t nrows = (int64_t)B * H * T;
+    hipLaunchKernelGGL(relpos_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       ac, bd, keymask, probs, H, T, ac_bs, bd_bs, p_bs, scale, nrows);
+    return (int)hipGetLastError();
+}
+
+// ds (in place over dprobs) = probs*(dprobs - sum_j dprobs*probs)*scale, and the un-shifted scatter
+// of the same values into the compact dBD matrix (every dBD element is written exactly once).
+__global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const float* __restrict__ probs,
+                                                                 float* __restrict__ dprobs,
+                                                                 float* __restrict__ dbd, int T, int64_t p_bs,
+                                                                 int64_t dp_bs, int64_t dbd_bs, float scale,
+                                                                 int64_t nrows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t zz = row / T;
+    const int i = (int)(row - zz * T);
+    const float* pr = probs + zz * p_bs + (int64_t)i * T;
+    float* dr = dprobs + zz * dp_bs + (int64_t)i * T;
+    float* dz = dbd + zz * dbd_bs;
+    float s = 0.f;
+    for (int j = lane; j < T; j += 64) s += pr[j] * dr[j];
+    s = wsum(s);
+    for (int j = lane; j < T; j += 64) {
+        float v = pr[j] * (dr[j] - s) * scale;
+        dr[j] = v;
+        if (j <= i)
+            dz[(int64_t)i * T + (T - 1 - i + j)] = v;
+        else if (j > i + 1)
+            dz[(int64_t)(i + 1) * T + (j - i - 2)] = v;
+    }
+    if (i == 0)  // BD[0][0..T-2] never reaches the scores
+        for (int j = lane; j < T - 1; j += 64) dz[j] = 0.f;
+}
+
+extern "C" int a3t_relpos_softmax_bwd(const float* probs, float* dprobs, float* dbd, int B, int H, int T,
+                                      int64_t p_bs, int64_t dp_bs, int64_t dbd_bs, float scale, void* stream) {
+    int64_t nrows = (int64_t)B * H * T;
+    hipLaunchKernelGGL(relpos_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       probs, dprobs, dbd, T, p_bs, dp_bs, dbd_bs, scale, nrows);
+    return (int)hipGetLastError();
+}

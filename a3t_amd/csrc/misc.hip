@@ -1,0 +1,406 @@
+// misc.hip -- encoder prologue, masked L1/L2 loss, flat-buffer clip+Adam, ParallelWaveGAN
+// element-wise helpers, counter-based dropout.  All HBM-bound, coalesced row-major access.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/a3t_hip.h"
+
+static inline int nblocks(int64_t n, int cap = 4096) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- encoder prologue
+__global__ void mask_fill_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
+                                 const float* __restrict__ mf, float* __restrict__ y, int64_t n, int C) {
+    GRID_STRIDE(i, n) {
+        int64_t r = i / C;
+        int c = (int)(i - r * C);
+        y[i] = m[r] ? mf[c] : x[i];
+    }
+}
+extern "C" int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, float* out, int M,
+                             int C, void* stream) {
+    int64_t n = (int64_t)M * C;
+    hipLaunchKernelGGL(mask_fill_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, speech, masked,
+                       mask_feature, out, n, C);
+    return (int)hipGetLastError();
+}
+
+__global__ void embed_finish_fwd_kernel(const float* __restrict__ e, const float* __restrict__ emb,
+                                        const float* __restrict__ seg, const int64_t* __restrict__ text,
+                                        const int64_t* __restrict__ spos, const int64_t* __restrict__ tpos,
+                                        float* __restrict__ xs, int B, int Tm, int Tp, int D, float xscale) {
+    const int T = Tm + Tp;
+    const int64_t n = (int64_t)B * T * D;
+    GRID_STRIDE(i, n) {
+        int64_t row = i / D;
+        int c = (int)(i - row * D);
+        int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+        float v;
+        if (t < Tm) {
+            int64_t r = (int64_t)b * Tm + t;
+            v = fmaxf(e[r * D + c], 0.f) * xscale + seg[spos[r] * D + c];
+        } else {
+            int64_t r = (int64_t)b * Tp + (t - Tm);
+            v = emb[text[r] * D + c] * xscale + seg[tpos[r] * D + c];
+        }
+        xs[i] = v;
+    }
+}
+extern "C" int a3t_embed_finish_fwd(const float* e, const float* emb, const float* seg, const int64_t* text,
+                                    const int64_t* spos, const int64_t* tpos, float* xs, int B, int Tm, int Tp, int D,
+                                    float xscale, void* stream) {
+    int64_t n = (int64_t)B * (Tm + Tp) * D;
+    hipLaunchKernelGGL(embed_finish_fwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, e, emb, seg, text,
+                       spos, tpos, xs, B, Tm, Tp, D, xscale);
+    return (int)hipGetLastError();
+}
+
+__global__ void embed_finish_bwd_kernel(const float* __restrict__ dxs, const float* __restrict__ e,
+                                        const int64_t* __restrict__ text, const int64_t* __restrict__ spos,
+                                        const int64_t* __restrict__ tpos, float* __restrict__ de, float* demb,
+                                        float* dseg, int B, int Tm, int Tp, int D, int V, int nseg, float xscale) {
+    const int T = Tm + Tp;
+    const int64_t n = (int64_t)B * T * D;
+    GRID_STRIDE(i, n) {
+        int64_t row = i / D;
+        int c = (int)(i - row * D);
+        int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
+        float g = dxs[i];
+        if (t < Tm) {
+            int64_t r = (int64_t)b * Tm + t;
+            de[r * D + c] = (e[r * D + c] > 0.f) ? g * xscale : 0.f;
+            int64_t s = spos[r];
+            if (s != nseg - 1) atomicAdd(&dseg[s * D + c], g);  // padding_idx=-1 -> last row gets no grad
+        } else {
+            int64_t r = (int64_t)b * Tp + (t - Tm);
+            int64_t tok = text[r];
+            if (tok != V - 1) atomicAdd(&demb[tok * D + c], g * xscale);
+            int64_t s = tpos[r];
+            if (s != nseg - 1) atomicAdd(&dseg[s * D + c], g);
+        }
+    }
+}
+extern "C" int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, const int64_t* spos,
+                                    const int64_t* tpos, float* de, float* demb, float* dseg, int B, int Tm, int Tp,
+                                    int D, int V, int nseg, float xscale, void* stream) {
+    int64_t n = (int64_t)B * (Tm + Tp) * D;
+    hipLaunchKernelGGL(embed_finish_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, dxs, e, text, spos,
+                       tpos, de, demb, dseg, B, Tm, Tp, D, V, nseg, xscale);
+    return (int)hipGetLastError();
+}
+
+__global__ void scale_kernel(const float* x, float* y, int64_t n, float s) {
+    GRID_STRIDE(i, n) y[i] = x[i] * s;
+}
+extern "C" int a3t_scale(const float* x, float* y, int64_t n, float s, void* stream) {
+    hipLaunchKernelGGL(scale_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, s);
+    return (int)hipGetLastError();
+}
+__global__ void axpy_kernel(const float* x, float* y, int64_t n, float a) {
+    GRID_STRIDE(i, n) y[i] += a * x[i];
+}
+extern "C" int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stream) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, a);
+    return (int)hipGetLastError();
+}
+__global__ void slice_rows_kernel(const float* x, float* y, int B, int T, int Tm, int D, int reverse) {
+    const int64_t n = (int64_t)B * Tm * D;
+    GRID_STRIDE(i, n) {
+        int64_t r = i / D;
+        int c = (int)(i - r * D);
+        int b = (int)(r / Tm), t = (int)(r - (int64_t)b * Tm);
+        int64_t j = ((int64_t)b * T + t) * D + c;
+        if (reverse)
+            ((float*)x)[j] += y[i];
+        else
+            y[i] = x[j];
+    }
+}
+extern "C" int a3t_slice_rows(const float* x, float* y, int B, int T, int Tm, int D, int reverse_add, void* stream) {
+    int64_t n = (int64_t)B * Tm * D;
+    hipLaunchKernelGGL(slice_rows_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, B, T, Tm, D,
+                       reverse_add);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- masked L1/L2 loss
+// stage 1: one wave per row, block partial (sum, count) -> scratch[2 + 2*blk]; deterministic.
+#define LOSS_BLOCKS 512
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restrict__ before,
+                                                           const float* __restrict__ after,
+                                                           const float* __restrict__ target,
+                                                           const uint8_t* __restrict__ masked, float* scratch, int M,
+                                                           int C, int l2) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float s = 0.f, cnt = 0.f;
+    for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+        if (!masked[row]) continue;
+        cnt += 1.f;
+        for (int c = lane; c < C; c += 64) {
+            int64_t i = (int64_t)row * C + c;
+            float y = target[i], d0 = before[i] - y, d1 = after[i] - y;
+            s += l2 ? (d0 * d0 + d1 * d1) : (fabsf(d0) + fabsf(d1));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        red[0][wv] = s;
+        red[1][wv] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scratch[2 + 2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        scratch[3 + 2 * blockIdx.x] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+__global__ void loss_final_kernel(float* scratch, float* loss_out, int nblk) {
+    __shared__ double rs[256], rc[256];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        s += (double)scratch[2 + 2 * i];
+        c += (double)scratch[3 + 2 * i];
+    }
+    rs[threadIdx.x] = s;
+    rc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            rs[threadIdx.x] += rs[threadIdx.x + o];
+            rc[threadIdx.x] += rc[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float n = (float)rc[0];
+        float inv = 1.0f / (n + 1e-10f);
+        loss_out[0] = (float)rs[0] * inv;
+        scratch[0] = inv;
+        scratch[1] = n;
+    }
+}
+__global__ void loss_grad_kernel(const float* __restrict__ before, const float* __restrict__ after,
+                                 const float* __restrict__ target, const uint8_t* __restrict__ masked,
+                                 const float* scratch, float* __restrict__ db, float* __restrict__ da, int64_t n, int C,
+                                 int l2, float gscale) {
+    const float k = scratch[0] * gscale;
+    GRID_STRIDE(i, n) {
+        int64_t r = i / C;
+        float g0 = 0.f, g1 = 0.f;
+        if (masked[r]) {
+            float y = target[i], d0 = before[i] - y, d1 = after[i] - y;
+            if (l2) {
+                g0 = 2.f * d0 * k;
+                g1 = 2.f * d1 * k;
+            } else {
+                g0 = (d0 > 0.f ? k : (d0 < 0.f ? -k : 0.f));
+                g1 = (d1 > 0.f ? k : (d1 < 0.f ? -k : 0.f));
+            }
+        }
+        db[i] = g0;
+        da[i] = g1;
+    }
+}
+extern "C" int a3t_mlm_loss_scratch_floats(int M) {
+    (void)M;
+    return 2 + 2 * LOSS_BLOCKS;
+}
+extern "C" int a3t_mlm_loss(const float* before, const float* after, const float* target, const uint8_t* masked,
+                            float* loss_out, float* d_before, float* d_after, float* scratch, int M, int C, int l2,
+                            float gscale, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int nblk = (M + 3) / 4;
+    if (nblk > LOSS_BLOCKS) nblk = LOSS_BLOCKS;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nblk), dim3(256), 0, s, before, after, target, masked, scratch, M, C,
+                       l2);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, scratch, loss_out, nblk);
+    if (d_before && d_after) {
+        int64_t n = (int64_t)M * C;
+        hipLaunchKernelGGL(loss_grad_kernel, dim3(nblocks(n)), dim3(256), 0, s, before, after, target, masked, scratch,
+                           d_before, d_after, n, C, l2, gscale);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- clip + Adam on one flat buffer
+#define SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* partial) {
+    __shared__ double red[256];
+    double s = 0.0;
+    float f = 0.f;
+    int cnt = 0;
+    GRID_STRIDE(i, n) {
+        float v = g[i];
+        f += v * v;
+        if (++cnt == 64) {
+            s += f, f = 0.f, cnt = 0;
+        }
+    }
+    s += f;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+extern "C" int a3t_sumsq(const float* g, int64_t n, double* partial, void* stream) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, g, n, partial);
+    return (int)hipGetLastError();
+}
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const double* partial, float* norm_out, int64_t n, float lr,
+                                                        float b1, float b2, float eps, float bc1, float bc2s,
+                                                        float clip, float gscale) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < SUMSQ_BLOCKS; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float norm = (float)sqrt(red[0]) * fabsf(gscale);
+    if (blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+    if (!isfinite(norm)) return;  // trainer.py:640-656: non-finite grad norm -> skip the update
+    float coef = clip > 0.f ? clip / (norm + 1e-6f) : 1.f;
+    coef = (coef > 1.f ? 1.f : coef) * gscale;
+    const float step_size = lr / bc1;
+    GRID_STRIDE(i, n) {
+        float gi = g[i] * coef;
+        float mi = m[i] * b1 + (1.f - b1) * gi;
+        float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+extern "C" int a3t_clip_adam(float* p, const float* g, float* m, float* v, const double* partial, float* norm_out,
+                             int64_t n, float lr, float beta1, float beta2, float eps, int step, float clip,
+                             float gscale, void* stream) {
+    float bc1 = 1.f - powf(beta1, (float)step);
+    float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(nblocks(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, partial,
+                       norm_out, n, lr, beta1, beta2, eps, bc1, bc2s, clip, gscale);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- ParallelWaveGAN helpers
+__global__ void pwg_gate_kernel(const float* __restrict__ y, const float* __restrict__ c, float* __restrict__ out,
+                                int64_t n, int H) {
+    GRID_STRIDE(i, n) {
+        int64_t t = i / H;
+        int h = (int)(i - t * H);
+        int64_t j = t * 2 * H + h;
+        float a = y[j] + c[j], b = y[j + H] + c[j + H];
+        out[i] = tanhf(a) * (1.f / (1.f + __expf(-b)));
+    }
+}
+extern "C" int a3t_pwg_gate(const float* y, const float* c, float* out, int64_t T, int H, void* stream) {
+    int64_t n = T * H;
+    hipLaunchKernelGGL(pwg_gate_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, y, c, out, n, H);
+    return (int)hipGetLastError();
+}
+__global__ void pwg_res_skip_kernel(const float* __restrict__ o, float* __restrict__ x, float* __restrict__ skips,
+                                    int64_t T, int R, int S) {
+    const int W = R + S;
+    const int64_t n = T * W;
+    GRID_STRIDE(i, n) {
+        int64_t t = i / W;
+        int c = (int)(i - t * W);
+        if (c < R)
+            x[t * R + c] = (o[i] + x[t * R + c]) * 0.70710678118654752440f;
+        else
+            skips[t * S + (c - R)] += o[i];
+    }
+}
+extern "C" int a3t_pwg_res_skip(const float* o, float* x, float* skips, int64_t T, int R, int S, void* stream) {
+    int64_t n = T * (R + S);
+    hipLaunchKernelGGL(pwg_res_skip_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, o, x, skips, T, R, S);
+    return (int)hipGetLastError();
+}
+// out[t][c] = sum_j w[j] * c_stretched[t + j - scale][c], c_stretched[u] = c[u / scale], zero outside
+__global__ void pwg_upsample_kernel(const float* __restrict__ c, const float* __restrict__ w, float* __restrict__ out,
+                                    int64_t Tin, int C, int scale) {
+    const int64_t Tout = Tin * scale;
+    const int64_t n = Tout * C;
+    GRID_STRIDE(i, n) {
+        int64_t t = i / C;
+        int ch = (int)(i - t * C);
+        float acc = 0.f;
+        for (int j = 0; j <= 2 * scale; ++j) {
+            int64_t u = t + j - scale;
+            if (u >= 0 && u < Tout) acc += w[j] * c[(u / scale) * C + ch];
+        }
+        out[i] = acc;
+    }
+}
+extern "C" int a3t_pwg_upsample(const float* c, const float* w, float* out, int64_t Tin, int C, int scale,
+                                void* stream) {
+    int64_t n = Tin * scale * C;
+    hipLaunchKernelGGL(pwg_upsample_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, c, w, out, Tin, C,
+                       scale);
+    return (int)hipGetLastError();
+}
+__global__ void replicate_pad_kernel(const float* x, float* y, int64_t T, int C, int pad) {
+    const int64_t n = (T + 2 * pad) * C;
+    GRID_STRIDE(i, n) {
+        int64_t t = i / C - pad;
+        int c = (int)(i % C);
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        y[i] = x[t * C + c];
+    }
+}
+extern "C" int a3t_replicate_pad(const float* x, float* y, int64_t T, int C, int pad, void* stream) {
+    int64_t n = (T + 2 * pad) * C;
+    hipLaunchKernelGGL(replicate_pad_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, T, C, pad);
+    return (int)hipGetLastError();
+}
+__global__ void bias_act_kernel(float* x, const float* bias, int64_t n, int C, int act, float scale) {
+    GRID_STRIDE(i, n) {
+        float v = x[i] * scale;
+        if (bias) v += bias[i % C];
+        if (act == A3T_ACT_RELU)
+            v = fmaxf(v, 0.f);
+        else if (act == A3T_ACT_TANH)
+            v = tanhf(v);
+        x[i] = v;
+    }
+}
+extern "C" int a3t_bias_act(float* x, const float* bias, int64_t M, int C, int act, float scale, void* stream) {
+    int64_t n = M * C;
+    hipLaunchKernelGGL(bias_act_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, bias, n, C, act, scale);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- dropout (splitmix64 counter RNG)
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void dropout_kernel(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset) {
+    const float inv = 1.f / (1.f - p);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    GRID_STRIDE(i, n) {
+        uint64_t r = mix64(seed ^ mix64(offset + (uint64_t)i));
+        y[i] = ((uint32_t)r >= thr) ? x[i] * inv : 0.f;
+    }
+}
+extern "C" int a3t_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset,
+                           void* stream) {
+    if (p < 0.f || p >= 1.f) return A3T_EINVAL;
+    hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, seed, offset);
+    return (int)hipGetLastError();
+}
+
+extern "C" const char* a3t_version(void) { return "a3t_hip 0.1 (gfx950)"; }

@@ -1,0 +1,347 @@
+// norm_reduce.hip -- HBM-bound row/column kernels of the A3T path for gfx950:
+// LayerNorm fwd/bwd (one wave64 per row, __shfl_xor butterflies), column reductions with
+// double-precision atomics (bias grads, BatchNorm statistics), BatchNorm(+Swish/tanh) fwd/bwd.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/a3t_hip.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: rows of D <= 64*MAXV floats, one wave per row, values kept in registers.
+// ------------------------------------------------------------------------------------------
+#define LN_MAXV 24  // D <= 1536
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                     int D, float eps) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * D;
+    float v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = lane + i * 64;
+        v[i] = (c < D) ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = lane + i * 64;
+        float dlt = (c < D) ? (v[i] - mu) : 0.f;
+        q += dlt * dlt;
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rs = 1.0f / sqrtf(var + eps);
+    float* yr = y + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = lane + i * 64;
+        if (c < D) yr[c] = (v[i] - mu) * rs * g[c] + b[c];
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ g, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* dres,
+                                                     float* dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int D) {
+    __shared__ float red[2][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float gam[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        int c = lane + i * 64;
+        gam[i] = (c < D) ? g[c] : 0.f;
+        ag[i] = 0.f;
+        ab[i] = 0.f;
+    }
+    for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const float* xr = x + (int64_t)row * D;
+        const float* dr = dy + (int64_t)row * D;
+        float xh[LN_MAXV], dg[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + i * 64;
+            float d = (c < D) ? dr[c] : 0.f;
+            xh[i] = (c < D) ? (xr[c] - mu) * rs : 0.f;
+            dg[i] = d * gam[i];
+            s1 += dg[i];
+            s2 += dg[i] * xh[i];
+            ag[i] += d * xh[i];
+            ab[i] += d;
+        }
+        s1 = wave_sum(s1) / (float)D;
+        s2 = wave_sum(s2) / (float)D;
+        float* dxr = dx + (int64_t)row * D;
+        const float* rr = dres ? dres + (int64_t)row * D : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            int c = lane + i * 64;
+            if (c < D) {
+                float o = rs * (dg[i] - s1 - xh[i] * s2);
+                if (rr) o += rr[c];
+                dxr[c] = o;
+            }
+        }
+    }
+    // reduce the 4 waves' column partials, one atomic per column per block
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i * 64 >= D) break;
+        red[0][wv][lane] = ag[i];
+        red[1][wv][lane] = ab[i];
+        __syncthreads();
+        if (wv == 0) {
+            int c = lane + i * 64;
+            if (c < D) {
+                atomicAdd(&dgamma[c], red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
+                atomicAdd(&dbeta[c], red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                 float* rstd, int M, int D, float eps, void* stream) {
+    if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
+                       rstd, M, D, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int a3t_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                                 const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                                 int M, int D, void* stream) {
+    if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
+    int blocks = (M + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dres,
+                       dx, dgamma, dbeta, M, D);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// column reductions: block = 64 columns x 4 row lanes; grid (ceil(C/64), row blocks)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const uint8_t* __restrict__ rowmask, double* out0,
+                                                         double* out1, int M, int C, int64_t ld, int mode,
+                                                         int rows_per_block) {
+    __shared__ double red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+        float f0 = 0.f, f1 = 0.f;
+        int cnt = 0;
+        for (int r = r0 + ty; r < r1; r += 4) {
+            if (rowmask && !rowmask[r]) continue;
+            float v = x[(int64_t)r * ld + c];
+            f0 += v;
+            if (mode == 1)
+                f1 += v * v;
+            else if (mode == 2)
+                f1 += v * y[(int64_t)r * ld + c];
+            if (++cnt == 32) {
+                a0 += f0, a1 += f1, f0 = f1 = 0.f, cnt = 0;
+            }
+        }
+        a0 += f0, a1 += f1;
+    }
+    red[0][ty][tx] = a0;
+    red[1][ty][tx] = a1;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        atomicAdd(&out0[c], red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx]);
+        if (mode) atomicAdd(&out1[c], red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx]);
+    }
+}
+
+extern "C" int a3t_col_reduce(const float* x, const float* y, const uint8_t* rowmask, double* out0, double* out1,
+                              int M, int C, int64_t ld, int mode, void* stream) {
+    if (M <= 0 || C <= 0) return A3T_EINVAL;
+    int rpb = 256;
+    dim3 grid((C + 63) / 64, (M + rpb - 1) / rpb);
+    hipLaunchKernelGGL(col_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, rowmask, out0, out1, M, C, ld,
+                       mode, rpb);
+    return (int)hipGetLastError();
+}
+
+__global__ void f64_to_f32_add_kernel(const double* src, float* dst, int n, float scale) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += (float)(src[i] * (double)scale);
+}
+extern "C" int a3t_f64_to_f32_add(const double* src, float* dst, int n, float scale, void* stream) {
+    hipLaunchKernelGGL(f64_to_f32_add_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, n,
+                       scale);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm1d (+ activation), channels-last
+// ------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* stats, float* running_mean, float* running_var, float* mean_out,
+                                   float* rstd_out, int M, int C, float eps, float momentum, int training) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (training) {
+        double mu = stats[c] / (double)M;
+        double var = stats[C + c] / (double)M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        mean_out[c] = (float)mu;
+        rstd_out[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (momentum > 0.f && running_mean) {
+            double unb = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    } else {
+        mean_out[c] = running_mean[c];
+        rstd_out[c] = 1.0f / sqrtf(running_var[c] + eps);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         int64_t n, int C, int act) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        float bn = (z[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
+        float o = bn;
+        if (act == A3T_ACT_SWISH)
+            o = bn * sigmoidf_(bn);
+        else if (act == A3T_ACT_TANH)
+            o = tanhf(bn);
+        y[i] = o;
+    }
+}
+
+extern "C" int a3t_bn_act_fwd(const float* z, const double* stats, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* y,
+                              int M, int C, float eps, float momentum, int training, int act, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, running_mean, running_var,
+                       mean_out, rstd_out, M, C, eps, momentum, training);
+    int64_t n = (int64_t)M * C;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, s, z, mean_out, rstd_out, gamma, beta, y, n, C,
+                       act);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dbn,
+                                                           double* sums, int M, int C, int act, int rows_per_block) {
+    __shared__ double red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+        const float mu = mean[c], rs = rstd[c], g = gamma[c], b = beta[c];
+        float f0 = 0.f, f1 = 0.f;
+        int cnt = 0;
+        for (int r = r0 + ty; r < r1; r += 4) {
+            int64_t i = (int64_t)r * C + c;
+            float zh = (z[i] - mu) * rs;
+            float bn = zh * g + b;
+            float d = dy[i];
+            if (act == A3T_ACT_SWISH) {
+                float sg = sigmoidf_(bn);
+                d *= sg * (1.f + bn * (1.f - sg));
+            } else if (act == A3T_ACT_TANH) {
+                float t = tanhf(bn);
+                d *= (1.f - t * t);
+            }
+            dbn[i] = d;
+            f0 += d;
+            f1 += d * zh;
+            if (++cnt == 32) {
+                a0 += f0, a1 += f1, f0 = f1 = 0.f, cnt = 0;
+            }
+        }
+        a0 += f0, a1 += f1;
+    }
+    red[0][ty][tx] = a0;
+    red[1][ty][tx] = a1;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        atomicAdd(&sums[c], red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx]);
+        atomicAdd(&sums[C + c], red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx]);
+    }
+}
+
+extern "C" int a3t_bn_act_bwd_a(const float* dy, const float* z, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, float* dbn, double* sums, int M, int C,
+                                int act, void* stream) {
+    int rpb = 256;
+    dim3 grid((C + 63) / 64, (M + rpb - 1) / rpb);
+    hipLaunchKernelGGL(bn_act_bwd_a_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, z, mean, rstd, gamma, beta, dbn,
+                       sums, M, C, act, rpb);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_b_kernel(const float* __restrict__ dbn, const float* __restrict__ z,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const double* sums,
+                                                           float* __restrict__ dz, float* dgamma, float* dbeta,
+                                                           int M, int C, int training) {
+    const int64_t n = (int64_t)M * C;
+    const double invM = 1.0 / (double)M;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            dgamma[c] += (float)sums[C + c];
+            dbeta[c] += (float)sums[c];
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        float rs = rstd[c];
+        float d = dbn[i];
+        if (training) {
+            float zh = (z[i] - mean[c]) * rs;
+            d = d - (float)(sums[c] * invM) - zh * (float)(sums[C + c] * invM);
+        }
+        dz[i] = gamma[c] * rs * d;
+    }
+}
+
+extern "C" int a3t_bn_act_bwd_b(const float* dbn, const float* z, const float* mean, const float* rstd,
+                                const float* gamma, const double* sums, float* dz, float* dgamma, float* dbeta, int M,
+                                int C, int training, void* stream) {
+    int64_t n = (int64_t)M * C;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_act_bwd_b_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dbn, z, mean, rstd, gamma,
+                       sums, dz, dgamma, dbeta, M, C, training);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,414 @@
+"""Forward / backward sequencing of the A3T masked-mel training step on one MI355X.
+
+This is the host-side replacement for the autograd graph the reference builds out of
+nn.Modules (ESPnetMLMEncAsDecoderModel._forward, espnet2/tts/sedit/sedit_model.py:350-375,
+MLMEncoder/MLMDecoder conformer/encoder.py:522-614, EncoderLayer conformer/encoder_layer.py:80-180):
+an explicit, allocation-free schedule of liba3t_hip launches on the current HIP stream, with a
+hand-derived backward pass.  torch supplies device buffers only.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import ACC_ADD, ACC_ATOMIC, ACC_STORE, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
+from .config import A3TConfig
+from .params import ParamStore
+
+
+def legacy_pe_table(c: A3TConfig) -> torch.Tensor:
+    """LegacyRelPositionalEncoding table (transformer/embedding.py:59-80 with reverse=True): a
+    constant computed once on the host with the same fp32 formula, row t = PE(max_len-1-t)."""
+    d = c.adim
+    position = torch.arange(c.max_len - 1, -1, -1.0, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(c.max_len, d)
+    pe[:, 0::2] = torch.sin(position * div)
+    pe[:, 1::2] = torch.cos(position * div)
+    return pe
+
+
+class Workspace:
+    """Named device buffers, allocated on first use and reused every step (static shapes)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[tuple, torch.Tensor] = {}
+
+    def get(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class MLMEngine:
+    def __init__(self, cfg: A3TConfig, store: ParamStore, compute: str = "f32", training: bool = True):
+        self.c = cfg
+        self.store = store
+        self.dev = store.device
+        self.ws = Workspace(self.dev)
+        self.bf16 = (compute == "bf16")
+        self.training = training
+        self.pe = legacy_pe_table(cfg).to(self.dev)
+        self.sv = {}
+        self.scratch64 = torch.zeros(4 * max(cfg.ff, 3 * cfg.adim, cfg.postnet_chans, 64), dtype=torch.float64,
+                                     device=self.dev)
+        self.bn_momentum = 0.1
+
+    # ------------------------------------------------------------------ helpers
+    def _cmp(self, *dims):
+        if self.bf16 and all(d % 8 == 0 for d in dims):
+            return BF16
+        return F32
+
+    def _ln_fwd(self, tag, x, pre, eps=1e-12):
+        p = self.store.p
+        M, D = x.shape
+        y = self.ws.get(tag + ".y", (M, D))
+        mean = self.ws.get(tag + ".mean", (M,))
+        rstd = self.ws.get(tag + ".rstd", (M,))
+        ops.layernorm_fwd(x, p[pre + ".g"], p[pre + ".b"], y, mean, rstd, eps)
+        self.sv[tag] = (x, y, mean, rstd)
+        return y
+
+    def _ln_bwd(self, tag, dy, pre, dres, dx):
+        p, g = self.store.p, self.store.g
+        x, _, mean, rstd = self.sv[tag]
+        ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"])
+
+    def _bias_grad(self, dy, gb, scale=1.0):
+        ops.bias_grad(dy, gb, self.scratch64, scale)
+
+    # ------------------------------------------------------------------ FFN (MultiLayeredConv1d)
+    def _ffn_fwd(self, tag, pre, x, T):
+        p, c = self.store.p, self.c
+        M = x.shape[0]
+        pad = (c.ff_kernel - 1) // 2
+        y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
+        h = self.ws.get(tag + ".h", (M, c.ff))
+        cmp = self._cmp(c.adim, c.ff)
+        ops.conv_fwd(y, p[pre + ".w1"], h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=cmp)
+        xo = self.ws.get(tag + ".xo", (M, c.adim))
+        ops.conv_fwd(h, p[pre + ".w2"], xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=cmp)
+        self.sv[tag] = (y, h)
+        return xo
+
+    def _ffn_bwd(self, tag, pre, g, T):
+        """g = grad wrt the sub-layer output (residual stream); returns grad wrt its input (in place)."""
+        p, gr, c = self.store.p, self.store.g, self.c
+        y, h = self.sv[tag]
+        M = g.shape[0]
+        pad = (c.ff_kernel - 1) // 2
+        cmp = self._cmp(c.adim, c.ff)
+        dh = self.ws.get("tmp.dh", (M, c.ff))
+        ops.conv_bwd_data(g, p[pre + ".w2"], dh, T, pad, S=h, alpha=0.5, compute=cmp)
+        ops.conv_bwd_weight(g, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=cmp)
+        self._bias_grad(g, gr[pre + ".b2"], 0.5)
+        dy = self.ws.get("tmp.dy", (M, c.adim))
+        ops.conv_bwd_data(dh, p[pre + ".w1"], dy, T, pad, compute=cmp)
+        ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=cmp)
+        self._bias_grad(dh, gr[pre + ".b1"])
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g)
+        return g
+
+    # ------------------------------------------------------------------ rel-pos self-attention
+    def _mha_fwd(self, tag, pre, x, pos, keymask, B, T):
+        p, c = self.store.p, self.c
+        d, H, dk = c.adim, c.heads, c.dk
+        M = B * T
+        y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
+        cmp = self._cmp(d)
+        cat = self._cmp(d, dk, T)
+        qkv = self.ws.get(tag + ".qkv", (M, 3 * d))
+        ops.linear_fwd(y, p[pre + ".wqkv"], qkv, bias=p[pre + ".bqkv"], compute=cmp)
+        qu = self.ws.get(tag + ".qu", (M, d))
+        qv = self.ws.get(tag + ".qv", (M, d))
+        ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
+        P = self.ws.get(tag + ".P", (T, d))
+        ops.linear_fwd(pos, p[pre + ".wpos"], P, compute=cmp)
+        ac = self.ws.get("tmp.ac", (B, H, T, T))
+        bd = self.ws.get("tmp.bd", (B, H, T, T))
+        kk = qkv.view(-1)[d:]
+        vv = qkv.view(-1)[2 * d:]
+        # ac[b,h] = (q+u) k^T ; bd[b,h] = (q+v) P_h^T   (attention.py:190-203)
+        ops.gemm(qu, kk, ac, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
+                 b_bs=(T * 3 * d, dk), c_bs=(H * T * T, T * T), compute=cat)
+        ops.gemm(qv, P, bd, T, T, dk, d, 1, d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(0, dk),
+                 c_bs=(H * T * T, T * T), compute=cat)
+        probs = self.ws.get(tag + ".probs", (B, H, T, T))
+        ops.relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, 1.0 / math.sqrt(dk))
+        ctx = self.ws.get(tag + ".ctx", (M, d))
+        # ctx[b,:,h,:] = probs[b,h] V[b,h]
+        ops.gemm(probs, vv, ctx, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=(H * T * T, T * T),
+                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cat)
+        xo = self.ws.get(tag + ".xo", (M, d))
+        ops.linear_fwd(ctx, p[pre + ".wo"], xo, bias=p[pre + ".bo"], R=x, compute=cmp)
+        self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos)
+        return xo
+
+    def _mha_bwd(self, tag, pre, g, B, T):
+        p, gr, c = self.store.p, self.store.g, self.c
+        d, H, dk = c.adim, c.heads, c.dk
+        M = B * T
+        y, qkv, qu, qv, P, probs, ctx, pos = self.sv[tag]
+        cmp = self._cmp(d)
+        cat = self._cmp(d, dk, T)
+        scale = 1.0 / math.sqrt(dk)
+        dctx = self.ws.get("tmp.dctx", (M, d))
+        ops.linear_bwd_data(g, p[pre + ".wo"], dctx, compute=cmp)
+        ops.linear_bwd_weight(g, ctx, gr[pre + ".wo"], compute=cmp)
+        self._bias_grad(g, gr[pre + ".bo"])
+        kk = qkv.view(-1)[d:]
+        vv = qkv.view(-1)[2 * d:]
+        dqkv = self.ws.get("tmp.dqkv", (M, 3 * d))
+        dkk = dqkv.view(-1)[d:]
+        dvv = dqkv.view(-1)[2 * d:]
+        ds = self.ws.get("tmp.ac", (B, H, T, T))      # reuse score buffers
+        dbd = self.ws.get("tmp.bd", (B, H, T, T))
+        zb = (H * T * T, T * T)
+        # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
+        ops.gemm(dctx, vv, ds, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
+                 b_bs=(T * 3 * d, dk), c_bs=zb, compute=cat)
+        # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
+        ops.gemm(probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb,
+                 b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cat)
+        ops.relpos_softmax_bwd(probs, ds, dbd, B, H, T, scale)
+        dqu = self.ws.get("tmp.dqu", (M, d))
+        dqv = self.ws.get("tmp.dqv", (M, d))
+        # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
+        ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
+                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cat)
+        ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
+                 c_bs=(T * 3 * d, dk), compute=cat)
+        # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
+        ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
+                 c_bs=(T * d, dk), compute=cat)
+        dP = self.ws.get("tmp.dP", (T, d), zero=True)
+        ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
+                 c_bs=(0, dk), acc=ACC_ATOMIC, compute=cat)
+        ops.linear_bwd_weight(dP, pos, gr[pre + ".wpos"], compute=cmp)
+        ops.add_pos_bias_bwd(dqu, dqv, dqkv)
+        self._bias_grad(dqu, gr[pre + ".u"])
+        self._bias_grad(dqv, gr[pre + ".v"])
+        dy = self.ws.get("tmp.dy", (M, d))
+        ops.linear_bwd_data(dqkv, p[pre + ".wqkv"], dy, compute=cmp)
+        ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp)
+        self._bias_grad(dqkv, gr[pre + ".bqkv"])
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g)
+        return g
+
+    # ------------------------------------------------------------------ convolution module
+    def _bn_fwd(self, tag, z, pre, bufpre, act, out):
+        p, b = self.store.p, self.store.buf
+        M, C = z.shape
+        stats = self.ws.get(tag + ".stats", (2 * C,), torch.float64)
+        if self.training:
+            stats.zero_()
+            ops.col_reduce(z, stats[:C], stats[C:], mode=1)
+        mean = self.ws.get(tag + ".bnmean", (C,))
+        rstd = self.ws.get(tag + ".bnrstd", (C,))
+        ops.bn_act_fwd(z, stats, p[pre + ".g"], p[pre + ".b"], b[bufpre + ".rm"], b[bufpre + ".rv"], mean, rstd, out,
+                       1e-5, self.bn_momentum if self.training else 0.0, self.training, act)
+        if self.training:
+            self.store.nbt[bufpre] = self.store.nbt.get(bufpre, 0) + 1
+        self.sv[tag + ".bn"] = (z, mean, rstd)
+
+    def _bn_bwd(self, tag, dy, pre, act, dz):
+        p, gr = self.store.p, self.store.g
+        z, mean, rstd = self.sv[tag + ".bn"]
+        M, C = z.shape
+        dbn = self.ws.get("tmp.dbn", (M, C))
+        sums = self.ws.get("tmp.bnsums", (2 * C,), torch.float64)
+        ops.bn_act_bwd(dy, z, mean, rstd, p[pre + ".g"], p[pre + ".b"], dbn, sums, dz, gr[pre + ".g"], gr[pre + ".b"],
+                       self.training, act)
+
+    def _conv_fwd(self, tag, pre, x, T):
+        p, c = self.store.p, self.c
+        M, d = x.shape
+        cmp = self._cmp(d)
+        y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
+        g2 = self.ws.get(tag + ".g", (M, 2 * d))
+        ops.linear_fwd(y, p[pre + ".pw1"], g2, bias=p[pre + ".pb1"], compute=cmp)
+        glu = self.ws.get(tag + ".glu", (M, d))
+        z = self.ws.get(tag + ".z", (M, d))
+        ops.glu_dwconv_fwd(g2, p[pre + ".dw"], p[pre + ".db"], glu, z, T)
+        s = self.ws.get(tag + ".s", (M, d))
+        self._bn_fwd(tag, z, pre + ".bn", pre + ".bn", ACT_SWISH, s)
+        xo = self.ws.get(tag + ".xo", (M, d))
+        ops.linear_fwd(s, p[pre + ".pw2"], xo, bias=p[pre + ".pb2"], R=x, compute=cmp)
+        self.sv[tag] = (y, g2, glu, s)
+        return xo
+
+    def _conv_bwd(self, tag, pre, g, T):
+        p, gr, c = self.store.p, self.store.g, self.c
+        M, d = g.shape
+        cmp = self._cmp(d)
+        y, g2, glu, s = self.sv[tag]
+        ds = self.ws.get("tmp.ds", (M, d))
+        ops.linear_bwd_data(g, p[pre + ".pw2"], ds, compute=cmp)
+        ops.linear_bwd_weight(g, s, gr[pre + ".pw2"], compute=cmp)
+        self._bias_grad(g, gr[pre + ".pb2"])
+        dz = self.ws.get("tmp.dz", (M, d))
+        self._bn_bwd(tag, ds, pre + ".bn", ACT_SWISH, dz)
+        dg = self.ws.get("tmp.dg", (M, 2 * d))
+        ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T)
+        dy = self.ws.get("tmp.dy", (M, d))
+        ops.linear_bwd_data(dg, p[pre + ".pw1"], dy, compute=cmp)
+        ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp)
+        self._bias_grad(dg, gr[pre + ".pb1"])
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g)
+        return g
+
+    # ------------------------------------------------------------------ one Conformer block
+    def block_fwd(self, pre, x, pos, keymask, B, T):
+        x = self._ffn_fwd(pre + ".ffm", pre + ".ffm", x, T)
+        x = self._mha_fwd(pre + ".mha", pre + ".mha", x, pos, keymask, B, T)
+        x = self._conv_fwd(pre + ".cnv", pre + ".cnv", x, T)
+        x = self._ffn_fwd(pre + ".ff", pre + ".ff", x, T)
+        return self._ln_fwd(pre + ".fin", x, pre + ".fin.ln")
+
+    def block_bwd(self, pre, g, B, T):
+        self._ln_bwd(pre + ".fin", g, pre + ".fin.ln", None, g)
+        self._ffn_bwd(pre + ".ff", pre + ".ff", g, T)
+        self._conv_bwd(pre + ".cnv", pre + ".cnv", g, T)
+        self._mha_bwd(pre + ".mha", pre + ".mha", g, B, T)
+        self._ffn_bwd(pre + ".ffm", pre + ".ffm", g, T)
+        return g
+
+    # ------------------------------------------------------------------ whole model
+    def forward(self, batch: Dict[str, torch.Tensor], need_grad: bool = True, gscale: float = 1.0):
+        c, p, ws = self.c, self.store.p, self.ws
+        speech = batch["speech"].contiguous()
+        B, Tm, idim = speech.shape
+        text = batch["text"].contiguous()
+        Tp = text.shape[1]
+        T = Tm + Tp
+        d = c.adim
+        self.dims = (B, Tm, Tp, T)
+        masked = batch["masked_position"].contiguous().view(torch.uint8)
+        keymask = ws.get("keymask", (B, T), torch.uint8)
+        keymask[:, :Tm].copy_(batch["speech_mask"].reshape(B, Tm).view(torch.uint8))
+        keymask[:, Tm:].copy_(batch["text_mask"].reshape(B, Tp).view(torch.uint8))
+        spos = batch["speech_segment_pos"].contiguous()
+        tpos = batch["text_segment_pos"].contiguous()
+        speech2 = speech.view(B * Tm, idim)
+        # --- encoder prologue (conformer/encoder.py:522-553)
+        xm = ws.get("emb.xm", (B * Tm, idim))
+        ops.mask_fill(speech2, masked, p["mask_feature"], xm)
+        e0 = ws.get("emb.e0", (B * Tm, d))
+        ops.linear_fwd(xm, p["emb.w"], e0, bias=p["emb.b"], compute=self._cmp(idim, d))
+        e = self._ln_fwd("emb.ln", e0, "emb.ln", eps=1e-5)
+        xs = ws.get("emb.xs", (B * T, d))
+        xscale = math.sqrt(d)
+        ops.embed_finish_fwd(e, p["temb"], p["seg"], text, spos, tpos, xs, B, Tm, Tp, d, xscale)
+        pos_e = ws.get("pos.enc", (T, d))
+        pos_e[:Tm].copy_(self.pe[:Tm])
+        pos_e[Tm:].copy_(self.pe[:Tp])
+        pos_d = ws.get("pos.dec", (T, d))
+        pos_d.copy_(self.pe[:T])
+        self.sv["embed"] = (xm, e, text, spos, tpos, masked, speech2)
+        x = xs
+        for i in range(c.enc_blocks):
+            x = self.block_fwd(f"enc.{i}", x, pos_e, keymask, B, T)
+        x = self._ln_fwd("enc.after", x, "enc.after")
+        # --- decoder (conformer/encoder.py:568-614): x*sqrt(d), contiguous rel-pos table
+        xd = ws.get("dec.in", (B * T, d))
+        ops.scale(x, xd, xscale)
+        x = xd
+        for i in range(c.dec_blocks):
+            x = self.block_fwd(f"dec.{i}", x, pos_d, keymask, B, T)
+        x = self._ln_fwd("dec.after", x, "dec.after")
+        # --- head: slice speech frames, sfc, postnet, loss (sedit_model.py:363-372,320-340)
+        hs = ws.get("head.hs", (B * Tm, d))
+        ops.slice_rows(x, hs, B, T, Tm, d)
+        before = ws.get("head.before", (B * Tm, c.odim))
+        ops.linear_fwd(hs, p["sfc.w"], before, bias=p["sfc.b"], compute=self._cmp(d, c.odim))
+        y = before
+        pad = (c.postnet_filts - 1) // 2
+        for l in range(c.postnet_layers):
+            W = p[f"post.{l}.w"]
+            oc = W.shape[0]
+            z = ws.get(f"post.{l}.z", (B * Tm, oc))
+            ops.conv_fwd(y, W, z, Tm, pad, compute=self._cmp(y.shape[1], oc))
+            o = ws.get(f"post.{l}.o", (B * Tm, oc))
+            act = ACT_TANH if l != c.postnet_layers - 1 else ACT_NONE
+            self._bn_fwd(f"post.{l}", z, f"post.{l}.bn", f"post.{l}.bn", act, o)
+            self.sv[f"post.{l}"] = y
+            y = o
+        if c.postnet_layers > 0:
+            after = ws.get("head.after", (B * Tm, c.odim))
+            after.copy_(before)
+            ops.axpy(y, after, 1.0)
+        else:
+            after = before
+        loss = ws.get("head.loss", (1,))
+        scratch = ws.get("head.lscratch", (ops.loss_scratch_floats(B * Tm),))
+        db = ws.get("head.dbefore", (B * Tm, c.odim)) if need_grad else None
+        da = ws.get("head.dafter", (B * Tm, c.odim)) if need_grad else None
+        ops.mlm_loss(before, after, speech2, masked, loss, db, da, scratch, l2=c.lsm_weight > 50, gscale=gscale)
+        self.sv["head"] = (hs, before, after, db, da)
+        return dict(loss=loss, before=before.view(B, Tm, c.odim), after=after.view(B, Tm, c.odim))
+
+    def backward(self):
+        """Accumulates d loss / d param (times the gscale given to forward) into store.grad."""
+        c, p, gr, ws = self.c, self.store.p, self.store.g, self.ws
+        B, Tm, Tp, T = self.dims
+        d = c.adim
+        hs, before, after, db, da = self.sv["head"]
+        pad = (c.postnet_filts - 1) // 2
+        if c.postnet_layers > 0:
+            g = da                                    # grad wrt last BN output
+            for l in reversed(range(c.postnet_layers)):
+                W = p[f"post.{l}.w"]
+                oc = W.shape[0]
+                act = ACT_TANH if l != c.postnet_layers - 1 else ACT_NONE
+                dz = ws.get(f"tmp.post.dz{oc}", (B * Tm, oc))
+                self._bn_bwd(f"post.{l}", g, f"post.{l}.bn", act, dz)
+                yin = self.sv[f"post.{l}"]
+                ic = yin.shape[1]
+                cmp = self._cmp(ic, oc)
+                ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=cmp)
+                gi = ws.get(f"tmp.post.g{l % 2}.{ic}", (B * Tm, ic))
+                ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=cmp)
+                g = gi
+            ops.axpy(da, db, 1.0)                     # after = before + postnet(before)
+            ops.axpy(g, db, 1.0)
+        dhs = ws.get("tmp.dhs", (B * Tm, d))
+        cmp = self._cmp(d, c.odim)
+        ops.linear_bwd_data(db, p["sfc.w"], dhs, compute=cmp)
+        ops.linear_bwd_weight(db, hs, gr["sfc.w"], compute=cmp)
+        self._bias_grad(db, gr["sfc.b"])
+        g = ws.get("grad.x", (B * T, d), zero=True)
+        ops.slice_rows(g, dhs, B, T, Tm, d, reverse_add=True)
+        self._ln_bwd("dec.after", g, "dec.after", None, g)
+        for i in reversed(range(c.dec_blocks)):
+            self.block_bwd(f"dec.{i}", g, B, T)
+        ops.scale(g, g, math.sqrt(d))
+        self._ln_bwd("enc.after", g, "enc.after", None, g)
+        for i in reversed(range(c.enc_blocks)):
+            self.block_bwd(f"enc.{i}", g, B, T)
+        # --- prologue backward
+        xm, e, text, spos, tpos, masked, speech2 = self.sv["embed"]
+        de = ws.get("tmp.de", (B * Tm, d))
+        ops.embed_finish_bwd(g, e, text, spos, tpos, de, gr["temb"], gr["seg"], B, Tm, Tp, d, c.vocab, c.seg_table,
+                             math.sqrt(d))
+        de0 = ws.get("tmp.de0", (B * Tm, d))
+        self._ln_bwd("emb.ln", de, "emb.ln", None, de0)
+        cmp = self._cmp(c.idim, d)
+        ops.linear_bwd_weight(de0, xm, gr["emb.w"], compute=cmp)
+        self._bias_grad(de0, gr["emb.b"])
+        dxm = ws.get("tmp.dxm", (B * Tm, c.idim))
+        ops.linear_bwd_data(de0, p["emb.w"], dxm, compute=cmp)
+        s64 = self.scratch64[:c.idim]
+        s64.zero_()
+        ops.col_reduce(dxm, s64, rowmask=masked.view(-1), mode=0)
+        ops.f64_to_f32_add(s64, gr["mask_feature"], 1.0)

@@ -1,0 +1,272 @@
+"""Thin host wrappers over the C ABI (include/a3t_hip.h): torch tensors supply device memory and
+the current HIP stream, every computation happens in liba3t_hip.so.  No torch math here."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from ._lib import ACC_ADD, ACC_ATOMIC, ACC_STORE, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
+
+__all__ = ["gemm", "linear_fwd", "linear_bwd_data", "linear_bwd_weight", "conv_fwd", "conv_bwd_data",
+           "conv_bwd_weight"]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
+         batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
+         act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32):
+    """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
+    lib = L.load()
+    d = L.GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.R = R.data_ptr() if R is not None else None
+    d.S = S.data_ptr() if S is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.a_rs, d.a_cs, d.b_rs, d.b_cs, d.b_ts, d.c_rs = a_rs, a_cs, b_rs, b_cs, b_ts, c_rs
+    d.batch, d.batch_inner = batch, batch_inner
+    d.a_bs0, d.a_bs1 = a_bs
+    d.b_bs0, d.b_bs1 = b_bs
+    d.c_bs0, d.c_bs1 = c_bs
+    d.taps, d.pad, d.dil, d.Tseq, d.kshift = taps, pad, dil, Tseq, kshift
+    d.alpha, d.act, d.accumulate, d.splitk = alpha, act, acc, splitk
+    d.a_dtype, d.b_dtype, d.c_dtype, d.compute = _dt(A), _dt(B), _dt(C), compute
+    L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
+
+
+def _splitk_for(n_tiles, K, target=1024, ktile=32):
+    """Token-reduction GEMMs (weight gradients) have few output tiles: split K over workgroups
+    until the grid covers the 256 CUs a few times."""
+    s = max(1, target // max(n_tiles, 1))
+    s = min(s, max(1, K // (ktile * 8)))
+    return int(s)
+
+
+# ---- y = x W^T (+bias): torch.nn.Linear / 1x1 Conv1d -----------------------------------------
+def linear_fwd(x, W, out, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32):
+    M, K = x.shape
+    N = W.shape[0]
+    gemm(x, W, out, M, N, K, K, 1, K, 1, N, bias=bias, R=R, alpha=alpha, act=act, compute=compute)
+
+
+def linear_bwd_data(dy, W, dx, S=None, alpha=1.0, acc=ACC_STORE, compute=F32):
+    """dx[M,K] = alpha * relu_mask_S(dy[M,N] @ W[N,K])"""
+    M, N = dy.shape
+    K = W.shape[1]
+    gemm(dy, W, dx, M, K, N, N, 1, 1, K, K, S=S, alpha=alpha, acc=acc, compute=compute)
+
+
+def linear_bwd_weight(dy, x, dW, alpha=1.0, compute=F32):
+    """dW[N,K] += alpha * dy[M,N]^T @ x[M,K]   (reduction over tokens, split-K + fp32 atomics)"""
+    M, N = dy.shape
+    K = x.shape[1]
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    gemm(dy, x, dW, N, K, M, 1, N, 1, K, K, alpha=alpha, acc=ACC_ATOMIC, splitk=_splitk_for(tiles, M),
+         compute=compute)
+
+
+# ---- Conv1d over time as implicit-im2col GEMM; weights kept as Wk[N][taps][Cin] --------------
+def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32):
+    M, Cin = x.shape
+    N, taps, _ = Wk.shape
+    gemm(x, Wk, out, M, N, taps * Cin, Cin, 1, taps * Cin, 1, N, b_ts=Cin, bias=bias, R=R, taps=taps, pad=pad,
+         dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute)
+
+
+def conv_bwd_data(dy, Wk, dx, Tseq, pad, dil=1, S=None, alpha=1.0, compute=F32):
+    """dx[m][c] = sum_tap sum_n dy[m-(tap-pad)*dil][n] Wk[n][tap][c]: the same im2col loader on dy
+    with the taps read back to front (pad' = taps-1-pad) and B addressed as W^T via strides."""
+    M, N = dy.shape
+    _, taps, Cin = Wk.shape
+    Wv = Wk.view(-1)[(taps - 1) * Cin:]
+    gemm(dy, Wv, dx, M, Cin, taps * N, N, 1, 1, taps * Cin, Cin, b_ts=-Cin, S=S, taps=taps, pad=taps - 1 - pad,
+         dil=dil, Tseq=Tseq, alpha=alpha, compute=compute)
+
+
+def conv_bwd_weight(dy, x, dWk, Tseq, pad, dil=1, alpha=1.0, compute=F32):
+    """dWk[n][tap][c] += alpha * sum_m dy[m][n] x[m+(tap-pad)*dil][c]  (one token-shifted TN GEMM per tap)"""
+    M, N = dy.shape
+    Cin = x.shape[1]
+    taps = dWk.shape[1]
+    tiles = ((N + 127) // 128) * ((Cin + 127) // 128)
+    sk = _splitk_for(tiles, M)
+    flat = dWk.view(-1)
+    for tap in range(taps):
+        gemm(dy, x, flat[tap * Cin:], N, Cin, M, 1, N, 1, Cin, taps * Cin, Tseq=Tseq, kshift=(tap - pad) * dil,
+             alpha=alpha, acc=ACC_ATOMIC, splitk=sk, compute=compute)
+
+
+# ---- row / column kernels --------------------------------------------------------------------
+def layernorm_fwd(x, g, b, y, mean, rstd, eps):
+    M, D = x.shape
+    L.check(L.load().a3t_layernorm_fwd(_ptr(x), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), M, D, eps,
+                                       _stream()), "ln_fwd")
+
+
+def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db):
+    M, D = x.shape
+    L.check(L.load().a3t_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
+                                       _ptr(dg), _ptr(db), M, D, _stream()), "ln_bwd")
+
+
+def col_reduce(x, out0, out1=None, y=None, rowmask=None, mode=0, ld=None):
+    M, C = x.shape
+    L.check(L.load().a3t_col_reduce(_ptr(x), _ptr(y), _ptr(rowmask), _ptr(out0), _ptr(out1), M, C,
+                                    ld if ld is not None else x.stride(0), mode, _stream()), "col_reduce")
+
+
+def f64_to_f32_add(src, dst, scale=1.0):
+    L.check(L.load().a3t_f64_to_f32_add(_ptr(src), _ptr(dst), dst.numel(), scale, _stream()), "f64_to_f32_add")
+
+
+def bias_grad(dy, dbias, scratch64, scale=1.0):
+    """dbias += scale * colsum(dy) via the double-precision column reducer."""
+    n = dy.shape[1]
+    s = scratch64[:n]
+    s.zero_()
+    col_reduce(dy, s, mode=0)
+    f64_to_f32_add(s, dbias, scale)
+
+
+def bn_act_fwd(z, stats, g, b, rmean, rvar, mean_out, rstd_out, y, eps, momentum, training, act):
+    M, C = z.shape
+    L.check(L.load().a3t_bn_act_fwd(_ptr(z), _ptr(stats), _ptr(g), _ptr(b), _ptr(rmean), _ptr(rvar), _ptr(mean_out),
+                                    _ptr(rstd_out), _ptr(y), M, C, eps, momentum, int(training), act, _stream()),
+            "bn_act_fwd")
+
+
+def bn_act_bwd(dy, z, mean, rstd, g, b, dbn, sums, dz, dg, db, training, act):
+    M, C = z.shape
+    lib = L.load()
+    sums.zero_()
+    L.check(lib.a3t_bn_act_bwd_a(_ptr(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(dbn), _ptr(sums),
+                                 M, C, act, _stream()), "bn_bwd_a")
+    L.check(lib.a3t_bn_act_bwd_b(_ptr(dbn), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(sums), _ptr(dz), _ptr(dg),
+                                 _ptr(db), M, C, int(training), _stream()), "bn_bwd_b")
+
+
+def glu_dwconv_fwd(g, wdw, bdw, glu, z, Tseq):
+    M, C = glu.shape
+    L.check(L.load().a3t_glu_dwconv_fwd(_ptr(g), _ptr(wdw), _ptr(bdw), _ptr(glu), _ptr(z), M, C, wdw.shape[1], Tseq,
+                                        _stream()), "glu_dwconv_fwd")
+
+
+def glu_dwconv_bwd(dz, g, glu, wdw, dg, dwdw, dbdw, Tseq):
+    M, C = glu.shape
+    L.check(L.load().a3t_glu_dwconv_bwd(_ptr(dz), _ptr(g), _ptr(glu), _ptr(wdw), _ptr(dg), _ptr(dwdw), _ptr(dbdw), M,
+                                        C, wdw.shape[1], Tseq, _stream()), "glu_dwconv_bwd")
+
+
+def add_pos_bias(qkv, u, v, qu, qv):
+    M, d = qu.shape
+    L.check(L.load().a3t_add_pos_bias(_ptr(qkv), _ptr(u), _ptr(v), _ptr(qu), _ptr(qv), M, d, _stream()), "pos_bias")
+
+
+def add_pos_bias_bwd(dqu, dqv, dqkv):
+    M, d = dqu.shape
+    L.check(L.load().a3t_add_pos_bias_bwd(_ptr(dqu), _ptr(dqv), _ptr(dqkv), M, d, _stream()), "pos_bias_bwd")
+
+
+def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale):
+    L.check(L.load().a3t_relpos_softmax_fwd(_ptr(ac), _ptr(bd), _ptr(keymask), _ptr(probs), B, H, T, T * T, T * T,
+                                            T * T, scale, _stream()), "softmax_fwd")
+
+
+def relpos_softmax_bwd(probs, dprobs, dbd, B, H, T, scale):
+    L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _ptr(dprobs), _ptr(dbd), B, H, T, T * T, T * T, T * T, scale,
+                                            _stream()), "softmax_bwd")
+
+
+def mask_fill(speech, masked, mask_feature, out):
+    M, C = out.shape
+    L.check(L.load().a3t_mask_fill(_ptr(speech), _ptr(masked), _ptr(mask_feature), _ptr(out), M, C, _stream()),
+            "mask_fill")
+
+
+def embed_finish_fwd(e, emb, seg, text, spos, tpos, xs, B, Tm, Tp, D, xscale):
+    L.check(L.load().a3t_embed_finish_fwd(_ptr(e), _ptr(emb), _ptr(seg), _ptr(text), _ptr(spos), _ptr(tpos), _ptr(xs),
+                                          B, Tm, Tp, D, xscale, _stream()), "embed_fwd")
+
+
+def embed_finish_bwd(dxs, e, text, spos, tpos, de, demb, dseg, B, Tm, Tp, D, V, nseg, xscale):
+    L.check(L.load().a3t_embed_finish_bwd(_ptr(dxs), _ptr(e), _ptr(text), _ptr(spos), _ptr(tpos), _ptr(de),
+                                          _ptr(demb), _ptr(dseg), B, Tm, Tp, D, V, nseg, xscale, _stream()),
+            "embed_bwd")
+
+
+def scale(x, y, s):
+    L.check(L.load().a3t_scale(_ptr(x), _ptr(y), x.numel(), s, _stream()), "scale")
+
+
+def axpy(x, y, a=1.0):
+    L.check(L.load().a3t_axpy(_ptr(x), _ptr(y), x.numel(), a, _stream()), "axpy")
+
+
+def slice_rows(x, y, B, T, Tm, D, reverse_add=False):
+    L.check(L.load().a3t_slice_rows(_ptr(x), _ptr(y), B, T, Tm, D, int(reverse_add), _stream()), "slice_rows")
+
+
+def mlm_loss(before, after, target, masked, loss_out, d_before, d_after, scratch, l2=False, gscale=1.0):
+    M, C = before.shape
+    L.check(L.load().a3t_mlm_loss(_ptr(before), _ptr(after), _ptr(target), _ptr(masked), _ptr(loss_out),
+                                  _ptr(d_before), _ptr(d_after), _ptr(scratch), M, C, int(l2), gscale, _stream()),
+            "mlm_loss")
+
+
+def loss_scratch_floats(M):
+    return L.load().a3t_mlm_loss_scratch_floats(M)
+
+
+def sumsq(g, partial):
+    L.check(L.load().a3t_sumsq(_ptr(g), g.numel(), _ptr(partial), _stream()), "sumsq")
+
+
+def clip_adam(p, g, m, v, partial, norm_out, lr, step, clip=1.0, gscale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    L.check(L.load().a3t_clip_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(partial), _ptr(norm_out), p.numel(), lr,
+                                   betas[0], betas[1], eps, step, clip, gscale, _stream()), "clip_adam")
+
+
+def pwg_gate(y, c, out):
+    T, H = out.shape
+    L.check(L.load().a3t_pwg_gate(_ptr(y), _ptr(c), _ptr(out), T, H, _stream()), "pwg_gate")
+
+
+def pwg_res_skip(o, x, skips):
+    T, R = x.shape
+    L.check(L.load().a3t_pwg_res_skip(_ptr(o), _ptr(x), _ptr(skips), T, R, skips.shape[1], _stream()), "pwg_res_skip")
+
+
+def pwg_upsample(c, w, out, scale_):
+    Tin, C = c.shape
+    L.check(L.load().a3t_pwg_upsample(_ptr(c), _ptr(w), _ptr(out), Tin, C, scale_, _stream()), "pwg_upsample")
+
+
+def replicate_pad(x, y, pad):
+    T, C = x.shape
+    L.check(L.load().a3t_replicate_pad(_ptr(x), _ptr(y), T, C, pad, _stream()), "replicate_pad")
+
+
+def bias_act(x, bias, act, scale_=1.0):
+    M, C = x.shape
+    L.check(L.load().a3t_bias_act(_ptr(x), _ptr(bias), M, C, act, scale_, _stream()), "bias_act")
+
+
+def dropout(x, y, p, seed, offset):
+    L.check(L.load().a3t_dropout(_ptr(x), _ptr(y), x.numel(), p, seed, offset, _stream()), "dropout")

@@ -1,0 +1,198 @@
+/* a3t_hip.h -- C ABI of liba3t_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for
+ * the A3T masked-mel training step and the ParallelWaveGAN inference path.
+ *
+ * The reference (richardbaihe/a3t) has no FFI for this path: every device op is a PyTorch
+ * ATen call made from Python nn.Modules.  The boundary this library
+ * replaces is therefore the ATen op sequence D1-D23 / V1-V6; each entry point below cites the
+ * reference module whose forward (and autograd backward) it implements.  The Python host
+ * (a3t_amd/) binds these symbols with ctypes -- see INTEGRATION.md for the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted.
+ *   - `stream` is a hipStream_t passed as void*.  Launches are stream-ordered, no allocation,
+ *     no host sync, no global mutable state (thread-compatible).
+ *   - every function returns 0 on success or a hipError_t / negative A3T_E* code.
+ *   - activations are row-major (rows = tokens m = b*T + t, cols = channels), fp32 unless a
+ *     dtype field says otherwise.
+ */
+#ifndef A3T_HIP_H
+#define A3T_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3T_F32 0
+#define A3T_BF16 1
+
+#define A3T_EINVAL (-22)
+
+#define A3T_ACT_NONE 0
+#define A3T_ACT_RELU 1
+#define A3T_ACT_TANH 2
+#define A3T_ACT_SWISH 3
+
+#define A3T_ACC_STORE 0  /* C  = v           */
+#define A3T_ACC_ADD 1    /* C += v           */
+#define A3T_ACC_ATOMIC 2 /* atomicAdd(C, v)  */
+
+/* One descriptor drives every dense contraction on the path (torch.nn.Linear, Conv1d as
+ * implicit-im2col GEMM, the attention bmm's and all their weight/data gradients):
+ *
+ *   C[z][m][n] (op)= alpha * relu_mask( act( sum_k A(m,k) * B(n,k) + bias[n] ) ) + R[m][n]
+ *
+ * A(m,k):  plain  : A[m*a_rs + k*a_cs]
+ *          conv   : taps>1, k=(tap,c) with c in [0,K/taps): row m' = m + (tap-pad)*dil, zero when
+ *                   (m % Tseq) + (tap-pad)*dil is outside [0,Tseq)  (Conv1d zero padding per
+ *                   utterance; reference: transformer/multi_layer_conv.py:36-63,
+ *                   tacotron2/decoder.py:165-267, wavenet/residual_block.py:82-96)
+ * B(n,k):  B[n*b_rs + tap*b_ts + c*b_cs]          (k=(tap,c), taps as above; taps==1: k*b_cs)
+ *          with kshift/Tseq (token-reduction GEMMs, taps==1): row k' = k + kshift, zero when
+ *          (k % Tseq) + kshift is outside [0,Tseq)   (Conv1d weight gradient, one tap per launch)
+ * One of a_rs/a_cs (and of b_rs/b_cs) must be 1.
+ * Batching: z in [0,batch): z0 = z / batch_inner, z1 = z % batch_inner; X += z0*x_bs0 + z1*x_bs1.
+ * splitk>1 splits K over extra workgroups; requires accumulate == A3T_ACC_ATOMIC.
+ */
+typedef struct a3t_gemm_desc {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;  /* [N] or NULL */
+    const float* R;     /* residual, same layout/strides as C, or NULL */
+    const float* S;     /* relu-mask source (keep where S>0), same layout as C, or NULL */
+    int32_t M, N, K;
+    int64_t a_rs, a_cs;
+    int64_t b_rs, b_cs, b_ts;
+    int64_t c_rs;
+    int32_t batch, batch_inner;
+    int64_t a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1;
+    int32_t taps, pad, dil, Tseq, kshift;
+    float alpha;
+    int32_t act;
+    int32_t accumulate;
+    int32_t splitk;
+    int32_t a_dtype, b_dtype, c_dtype; /* A3T_F32 | A3T_BF16 (storage) */
+    int32_t compute;                   /* A3T_F32: v_mfma_f32_32x32x2_f32 (exact f32);
+                                          A3T_BF16: v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+} a3t_gemm_desc;
+
+int a3t_gemm(const a3t_gemm_desc* d, void* stream);
+
+/* LayerNorm over the last dim (transformer/layer_norm.py:12-42 eps=1e-12; torch.nn.LayerNorm
+ * eps=1e-5 in the speech embed, conformer/encoder.py:404).  mean/rstd: [M] saved for backward. */
+int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                      float* rstd, int M, int D, float eps, void* stream);
+/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta are ACCUMULATED (atomicAdd). */
+int a3t_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                      int M, int D, void* stream);
+
+/* Column reductions over rows of x[M][C] (row stride ld), accumulated with atomics:
+ *   mode 0: out0[c] += sum x            (bias gradients)
+ *   mode 1: out0 += sum x, out1 += sum x*x      (BatchNorm batch statistics)
+ *   mode 2: out0 += sum x, out1 += sum x*y      (BatchNorm backward)
+ * rowmask (optional, uint8 [M]): only rows with rowmask!=0 contribute. out are double[C]. */
+int a3t_col_reduce(const float* x, const float* y, const uint8_t* rowmask, double* out0, double* out1,
+                   int M, int C, int64_t ld, int mode, void* stream);
+int a3t_f64_to_f32_add(const double* src, float* dst, int n, float scale, void* stream);
+
+/* BatchNorm1d(+activation) over channels-last [M][C] (conformer/convolution.py:74,
+ * tacotron2/decoder.py:165-267).  stats = double[2][C] (sum, sumsq) from a3t_col_reduce when
+ * training; running_mean/var updated in place when momentum > 0 (unbiased var).
+ * saves mean/rstd (float[C]) for backward. */
+int a3t_bn_act_fwd(const float* z, const double* stats, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* y,
+                   int M, int C, float eps, float momentum, int training, int act, void* stream);
+/* step A: dbn = dy * act'(bn) written to dbn; sums += (sum dbn, sum dbn*zhat) (double[2][C]) */
+int a3t_bn_act_bwd_a(const float* dy, const float* z, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, float* dbn, double* sums, int M, int C, int act,
+                     void* stream);
+/* step B: dz = gamma*rstd*(dbn - sum0/M - zhat*sum1/M) (training) or gamma*rstd*dbn (eval);
+ * dgamma += sum1, dbeta += sum0 */
+int a3t_bn_act_bwd_b(const float* dbn, const float* z, const float* mean, const float* rstd,
+                     const float* gamma, const double* sums, float* dz, float* dgamma, float* dbeta, int M,
+                     int C, int training, void* stream);
+
+/* GLU + depthwise Conv1d (conformer/convolution.py:66-72): g[M][2C] -> glu[M][C] (saved) and
+ * z[m][c] = bdw[c] + sum_k wdw[c][k] * glu[m+k-(K-1)/2][c], zero padded per utterance (Tseq). */
+int a3t_glu_dwconv_fwd(const float* g, const float* wdw, const float* bdw, float* glu, float* z, int M,
+                       int C, int K, int Tseq, void* stream);
+/* dz -> dg[M][2C]; dwdw[C][K], dbdw[C] accumulated (atomics) */
+int a3t_glu_dwconv_bwd(const float* dz, const float* g, const float* glu, const float* wdw, float* dg,
+                       float* dwdw, float* dbdw, int M, int C, int K, int Tseq, void* stream);
+
+/* Attention helpers around the batched GEMMs (transformer/attention.py:167-209).
+ * qkv [M][3d] (q|k|v); qu/qv [M][d] = q + pos_bias_{u,v}. */
+int a3t_add_pos_bias(const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv, int M,
+                     int d, void* stream);
+/* dq = dqu + dqv written into dqkv[:, 0:d] (row stride 3d) */
+int a3t_add_pos_bias_bwd(const float* dqu, const float* dqv, float* dqkv, int M, int d, void* stream);
+/* probs[z][i][j] = softmax_j( (ac[z][i][j] + shift(bd)[z][i][j]) * scale ) with key mask
+ * (masked_fill(min) -> softmax -> masked_fill(0), attention.py:78-86).  bd is the COMPACT
+ * (q+v)P^T matrix; the legacy rel_shift (attention.py:145-165) is applied on the fly in closed
+ * form: j<=i -> bd[i][T-1-i+j], j==i+1 -> 0, j>i+1 -> bd[i+1][j-i-2].
+ * z = b*H + h; keymask uint8 [B][T]; *_bs = per-z strides (elements). */
+int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, float* probs, int B,
+                           int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs, float scale,
+                           void* stream);
+/* ds = probs * (dprobs - sum_j dprobs*probs) * scale, written in place of dprobs (= gradient of
+ * ac) and scattered un-shifted into dbd (= gradient of the compact bd; fully overwritten). */
+int a3t_relpos_softmax_bwd(const float* probs, float* dprobs, float* dbd, int B, int H, int T,
+                           int64_t p_bs, int64_t dp_bs, int64_t dbd_bs, float scale, void* stream);
+
+/* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
+int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, float* out, int M,
+                  int C, void* stream);
+/* xs[b][t] (t<Tm): relu(e[b*Tm+t]) * xscale + seg[spos];  (t>=Tm): emb[text]*xscale + seg[tpos] */
+int a3t_embed_finish_fwd(const float* e, const float* emb, const float* seg, const int64_t* text,
+                         const int64_t* spos, const int64_t* tpos, float* xs, int B, int Tm, int Tp, int D,
+                         float xscale, void* stream);
+int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, const int64_t* spos,
+                         const int64_t* tpos, float* de, float* demb, float* dseg, int B, int Tm, int Tp,
+                         int D, int V, int nseg, float xscale, void* stream);
+/* y = x * s (decoder entry xscale, conformer/encoder.py:585-588) */
+int a3t_scale(const float* x, float* y, int64_t n, float s, void* stream);
+int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stream); /* y += a*x */
+/* copy rows [b][0:Tm] of x[B][T][D] into y[B][Tm][D] (sedit_model.py:363) and the reverse scatter-add */
+int a3t_slice_rows(const float* x, float* y, int B, int T, int Tm, int D, int reverse_add, void* stream);
+
+/* Masked L1/L2 loss (sedit_model.py:320-340).  scratch: float[2 + nblk*2].
+ * loss_out[0] = sum_masked(|before-y|+|after-y|)/(n_masked+1e-10); d_before/d_after = gradients
+ * times gscale (may be NULL for no-grad). */
+int a3t_mlm_loss(const float* before, const float* after, const float* target, const uint8_t* masked,
+                 float* loss_out, float* d_before, float* d_after, float* scratch, int M, int C, int l2,
+                 float gscale, void* stream);
+int a3t_mlm_loss_scratch_floats(int M);
+
+/* Trainer tail (espnet2/train/trainer.py:631-679, torch.optim.Adam, schedulers/noam_lr.py:58-65) on
+ * ONE flat parameter buffer: grad-norm partials, then clip + finite check + Adam, no host sync.
+ * norm_out[0] = total L2 norm; the update is skipped on device when it is not finite. */
+int a3t_sumsq(const float* g, int64_t n, double* partial /*[1024]*/, void* stream);
+int a3t_clip_adam(float* p, const float* g, float* m, float* v, const double* partial, float* norm_out,
+                  int64_t n, float lr, float beta1, float beta2, float eps, int step, float clip,
+                  float gscale, void* stream);
+
+/* ParallelWaveGAN helpers (espnet2/gan_tts/wavenet/residual_block.py:114-169,
+ * parallel_wavegan/upsample.py:22-189), channels-last [T][C]. */
+/* g = tanh(xa+ca)*sigmoid(xb+cb), y/c [T][2H] (a|b), out [T][H] */
+int a3t_pwg_gate(const float* y, const float* c, float* out, int64_t T, int H, void* stream);
+/* o [T][R+S] -> x = (o[:, :R] + x) * sqrt(.5); skips += o[:, R:] */
+int a3t_pwg_res_skip(const float* o, float* x, float* skips, int64_t T, int R, int S, void* stream);
+/* nearest stretch by `scale` then 1-D smoothing conv (2*scale+1 taps, zero pad) per channel */
+int a3t_pwg_upsample(const float* c, const float* w, float* out, int64_t Tin, int C, int scale,
+                     void* stream);
+int a3t_replicate_pad(const float* x, float* y, int64_t T, int C, int pad, void* stream);
+int a3t_bias_act(float* x, const float* bias, int64_t M, int C, int act, float scale, void* stream);
+
+/* Dropout (counter-based; same (seed, offset) reproduces the mask in backward).
+ * y = x * keep/(1-p), in place allowed. */
+int a3t_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+const char* a3t_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,244 @@
+"""GPU parity tests: every HIP kernel (called through the C ABI) against the CPU oracle /
+plain torch-CPU fp32 math on identical seeded inputs.  Run with `pytest -m gpu` on an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import a3t_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from a3t_amd import ops
+    return ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _close(got, ref, atol, rtol, msg=""):
+    got = got.detach().float().cpu().numpy()
+    ref = ref.detach().float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=atol, rtol=rtol, err_msg=msg)
+
+
+TOL = {"f32": dict(atol=2e-4, rtol=2e-4), "bf16": dict(atol=0.15, rtol=5e-2)}
+
+
+@pytest.mark.parametrize("cmp", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 80, 384), (1120, 192, 96), (37, 50, 24), (333, 264, 1152)])
+def test_linear_fwd_bwd(cmp, M, N, K):
+    ops = _ops()
+    from a3t_amd._lib import BF16, F32, ACT_RELU
+    c = BF16 if cmp == "bf16" else F32
+    if cmp == "bf16" and (K % 8 or N % 8):
+        pytest.skip("bf16 path needs 8-element alignment")
+    x, W, b, R = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, seed=3), _rand(M, N, seed=4)
+    xd, Wd, bd, Rd = x.to(DEV), W.to(DEV), b.to(DEV), R.to(DEV)
+    out = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xd, Wd, out, bias=bd, R=Rd, alpha=0.5, act=ACT_RELU, compute=c)
+    ref = 0.5 * torch.relu(F.linear(x, W, b)) + R
+    _close(out, ref, **TOL[cmp])
+    dy = _rand(M, N, seed=5)
+    dyd = dy.to(DEV)
+    dx = torch.empty(M, K, device=DEV)
+    ops.linear_bwd_data(dyd, Wd, dx, compute=c)
+    _close(dx, dy @ W, **TOL[cmp])
+    dW = torch.zeros(N, K, device=DEV)
+    ops.linear_bwd_weight(dyd, xd, dW, compute=c)
+    tol = dict(TOL[cmp])
+    tol["atol"] *= math.sqrt(M)
+    _close(dW, dy.t() @ x, **tol)
+
+
+@pytest.mark.parametrize("cmp", ["f32", "bf16"])
+@pytest.mark.parametrize("B,T,Cin,Cout,taps,dil", [(2, 56, 32, 64, 3, 1), (3, 37, 80, 256, 5, 1), (1, 300, 64, 128, 3, 4),
+                                                   (2, 200, 384, 1536, 3, 1)])
+def test_conv_as_gemm(cmp, B, T, Cin, Cout, taps, dil):
+    ops = _ops()
+    from a3t_amd._lib import BF16, F32
+    c = BF16 if cmp == "bf16" else F32
+    pad = (taps - 1) // 2
+    x = _rand(B, T, Cin, seed=1).requires_grad_(True)
+    W = _rand(Cout, Cin, taps, seed=2, scale=(Cin * taps) ** -0.5).requires_grad_(True)
+    b = _rand(Cout, seed=3)
+    y = F.conv1d(x.transpose(1, 2), W, b, padding=pad * dil, dilation=dil).transpose(1, 2)
+    dy = _rand(B, T, Cout, seed=4)
+    y.backward(dy)
+    Wk = W.detach().permute(0, 2, 1).contiguous().to(DEV)
+    xd = x.detach().reshape(B * T, Cin).to(DEV)
+    out = torch.empty(B * T, Cout, device=DEV)
+    ops.conv_fwd(xd, Wk, out, T, pad, dil, bias=b.to(DEV), compute=c)
+    _close(out.view(B, T, Cout), y, **TOL[cmp])
+    dyd = dy.reshape(B * T, Cout).to(DEV)
+    dx = torch.empty(B * T, Cin, device=DEV)
+    ops.conv_bwd_data(dyd, Wk, dx, T, pad, dil, compute=c)
+    _close(dx.view(B, T, Cin), x.grad, **TOL[cmp])
+    dWk = torch.zeros_like(Wk)
+    ops.conv_bwd_weight(dyd, xd, dWk, T, pad, dil, compute=c)
+    tol = dict(TOL[cmp])
+    tol["atol"] *= math.sqrt(B * T)
+    _close(dWk.permute(0, 2, 1), W.grad, **tol)
+
+
+@pytest.mark.parametrize("M,D,eps", [(7, 384, 1e-12), (1000, 384, 1e-5), (130, 32, 1e-12), (65, 80, 1e-12)])
+def test_layernorm(M, D, eps):
+    ops = _ops()
+    x = _rand(M, D, seed=1, scale=2.0).requires_grad_(True)
+    g = (1 + 0.1 * _rand(D, seed=2)).requires_grad_(True)
+    b = _rand(D, seed=3).requires_grad_(True)
+    y = F.layer_norm(x, (D,), g, b, eps)
+    dy, res = _rand(M, D, seed=4), _rand(M, D, seed=5)
+    y.backward(dy)
+    xd = x.detach().to(DEV)
+    yd, mean, rstd = torch.empty(M, D, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(xd, g.detach().to(DEV), b.detach().to(DEV), yd, mean, rstd, eps)
+    _close(yd, y, atol=2e-5, rtol=1e-5)
+    dx = torch.empty(M, D, device=DEV)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), xd, g.detach().to(DEV), mean, rstd, res.to(DEV), dx, dg, db)
+    _close(dx, x.grad + res, atol=5e-5, rtol=1e-4)
+    _close(dg, g.grad, atol=1e-4 * math.sqrt(M), rtol=1e-4)
+    _close(db, b.grad, atol=1e-4 * math.sqrt(M), rtol=1e-4)
+
+
+@pytest.mark.parametrize("act", ["swish", "tanh", "none"])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_act(act, training):
+    ops = _ops()
+    from a3t_amd._lib import ACT_NONE, ACT_SWISH, ACT_TANH
+    A = dict(swish=ACT_SWISH, tanh=ACT_TANH, none=ACT_NONE)[act]
+    M, C = 777, 96
+    z = (_rand(M, C, seed=1) * 1.5 + 0.3).requires_grad_(True)
+    g = (1 + 0.2 * _rand(C, seed=2)).requires_grad_(True)
+    b = (0.1 * _rand(C, seed=3)).requires_grad_(True)
+    rm, rv = 0.1 * _rand(C, seed=4), 0.5 + torch.rand(C)
+    rm0, rv0 = rm.clone(), rv.clone()
+    bn = F.batch_norm(z.t()[None], rm, rv, g, b, training, 0.1, 1e-5)[0].t()
+    y = bn * torch.sigmoid(bn) if act == "swish" else (torch.tanh(bn) if act == "tanh" else bn)
+    dy = _rand(M, C, seed=5)
+    y.backward(dy)
+    zd = z.detach().to(DEV)
+    stats = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    if training:
+        ops.col_reduce(zd, stats[:C], stats[C:], mode=1)
+    rmd, rvd = rm0.to(DEV), rv0.to(DEV)
+    mean, rstd, yd = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(M, C, device=DEV)
+    ops.bn_act_fwd(zd, stats, g.detach().to(DEV), b.detach().to(DEV), rmd, rvd, mean, rstd, yd, 1e-5,
+                   0.1 if training else 0.0, training, A)
+    _close(yd, y, atol=2e-5, rtol=1e-4)
+    _close(rmd, rm, atol=1e-6, rtol=1e-5)
+    _close(rvd, rv, atol=1e-6, rtol=1e-5)
+    dbn, dz = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_act_bwd(dy.to(DEV), zd, mean, rstd, g.detach().to(DEV), b.detach().to(DEV), dbn, sums, dz, dg, db,
+                   training, A)
+    _close(dz, z.grad, atol=5e-5, rtol=1e-3)
+    _close(dg, g.grad, atol=2e-3, rtol=1e-4)
+    _close(db, b.grad, atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,C,K", [(2, 50, 32, 7), (3, 130, 96, 31), (1, 64, 384, 7)])
+def test_glu_dwconv(B, T, C, K):
+    ops = _ops()
+    g = _rand(B, T, 2 * C, seed=1).requires_grad_(True)
+    w = _rand(C, 1, K, seed=2, scale=K ** -0.5).requires_grad_(True)
+    b = _rand(C, seed=3).requires_grad_(True)
+    glu = F.glu(g.transpose(1, 2), dim=1)
+    z = F.conv1d(glu, w, b, padding=(K - 1) // 2, groups=C).transpose(1, 2)
+    dz = _rand(B, T, C, seed=4)
+    z.backward(dz)
+    gd, wd, bd = g.detach().reshape(B * T, 2 * C).to(DEV), w.detach().reshape(C, K).contiguous().to(DEV), b.detach().to(DEV)
+    glud, zd = torch.empty(B * T, C, device=DEV), torch.empty(B * T, C, device=DEV)
+    ops.glu_dwconv_fwd(gd, wd, bd, glud, zd, T)
+    _close(zd.view(B, T, C), z, atol=2e-5, rtol=1e-4)
+    dg = torch.empty(B * T, 2 * C, device=DEV)
+    dw, dbb = torch.zeros(C, K, device=DEV), torch.zeros(C, device=DEV)
+    ops.glu_dwconv_bwd(dz.reshape(B * T, C).to(DEV), gd, glud, wd, dg, dw, dbb, T)
+    _close(dg.view(B, T, 2 * C), g.grad, atol=2e-5, rtol=1e-4)
+    _close(dw, w.grad.view(C, K), atol=2e-4, rtol=1e-4)
+    _close(dbb, b.grad, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,T", [(3, 2, 37), (2, 2, 64), (1, 4, 130)])
+def test_relpos_softmax(B, H, T):
+    ops = _ops()
+    ac = _rand(B, H, T, T, seed=1, scale=3.0).requires_grad_(True)
+    bd = _rand(B, H, T, T, seed=2, scale=3.0).requires_grad_(True)
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    if B > 1:
+        mask[1, 0, T // 2:] = False
+    if B > 2:
+        mask[2] = False
+    scale = 0.3
+    s = (ac + O.rel_shift_legacy(bd)) * scale
+    m = mask.unsqueeze(1).eq(0)
+    pr = torch.softmax(s.masked_fill(m, float(np.finfo(np.float32).min)), dim=-1).masked_fill(m, 0.0)
+    dp = _rand(B, H, T, T, seed=3)
+    pr.backward(dp)
+    probs = torch.empty(B, H, T, T, device=DEV)
+    ops.relpos_softmax_fwd(ac.detach().to(DEV), bd.detach().to(DEV), mask.view(B, T).to(DEV).view(torch.uint8), probs,
+                           B, H, T, scale)
+    _close(probs, pr, atol=1e-6, rtol=1e-4)
+    ds = dp.to(DEV).clone()
+    dbd = torch.full((B, H, T, T), 7.0, device=DEV)
+    ops.relpos_softmax_bwd(probs, ds, dbd, B, H, T, scale)
+    _close(ds, ac.grad, atol=1e-6, rtol=1e-3)
+    _close(dbd, bd.grad, atol=1e-6, rtol=1e-3)
+
+
+def test_loss_and_optimizer():
+    ops = _ops()
+    M, C = 500, 80
+    before, after, y = _rand(M, C, seed=1).requires_grad_(True), _rand(M, C, seed=2).requires_grad_(True), _rand(M, C, seed=3)
+    masked = torch.from_numpy(np.random.RandomState(4).rand(M) < 0.8)
+    loss = O.mlm_loss(before[None], after[None], y[None], masked[None], O.A3TConfig())
+    loss.backward()
+    lo = torch.empty(1, device=DEV)
+    db, da = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    scratch = torch.empty(ops.loss_scratch_floats(M), device=DEV)
+    ops.mlm_loss(before.detach().to(DEV), after.detach().to(DEV), y.to(DEV), masked.to(DEV).view(torch.uint8), lo, db,
+                 da, scratch)
+    assert abs(float(lo) - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
+    _close(db, before.grad, atol=1e-8, rtol=1e-5)
+    _close(da, after.grad, atol=1e-8, rtol=1e-5)
+    # clip + Adam on a flat buffer vs the oracle restatement, 3 steps with Noam LR
+    n = 100003
+    p = _rand(n, seed=5)
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pr, mr, vr = [p.clone()], [torch.zeros(n)], [torch.zeros(n)]
+    partial = torch.zeros(1024, dtype=torch.float64, device=DEV)
+    norm = torch.zeros(1, device=DEV)
+    for step in range(1, 4):
+        g = _rand(n, seed=10 + step, scale=0.01 * step)
+        lr = O.noam_lr(step, 1.0, 384, 4000)
+        gn = O.clip_adam_step(pr, [g], mr, vr, step, lr, 1.0)
+        gd = g.to(DEV)
+        ops.sumsq(gd, partial)
+        ops.clip_adam(pd, gd, m, v, partial, norm, lr, step, clip=1.0)
+        assert abs(float(norm) - float(gn)) < 1e-4 * float(gn)
+        _close(pd, pr[0], atol=1e-6, rtol=1e-5)
+
+
+def test_dropout_statistics_and_replay():
+    ops = _ops()
+    n = 1 << 20
+    x = torch.ones(n, device=DEV)
+    y1, y2, y3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    ops.dropout(x, y1, 0.2, 1234, 0)
+    ops.dropout(x, y2, 0.2, 1234, 0)
+    ops.dropout(x, y3, 0.2, 1234, n)
+    assert torch.equal(y1, y2)
+    keep = float((y1 > 0).float().mean())
+    assert abs(keep - 0.8) < 5e-3
+    assert abs(float(y1.mean()) - 1.0) < 1e-2
+    assert not torch.equal(y1, y3)
