@@ -4,6 +4,11 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
+# torch ships its own libamdhip64.so; it must be the HIP runtime already resident in the process
+# when liba3t_hip.so is dlopen'ed, otherwise the kernels would launch on a second, device-less
+# runtime (hipErrorNoDevice).  Streams and device pointers come from torch anyway.
+import torch  # noqa: F401  (load order matters)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "liba3t_hip.so")
 

@@ -11,6 +11,19 @@ __all__ = ["gemm", "linear_fwd", "linear_bwd_data", "linear_bwd_weight", "conv_f
            "conv_bwd_weight"]
 
 
+# bench.py sets PROFILE = [] to bracket every GEMM launch with HIP events on the launch stream:
+# entries are (kernel name as rocprofv3 prints it, algorithmic FLOPs of the launch, start, end).
+PROFILE = None
+
+
+def _kernel_name(compute, a_cs, b_cs, A, B):
+    tn = {torch.float32: "float", torch.bfloat16: "unsigned short"}
+    ak, bk = "true" if a_cs == 1 else "false", "true" if b_cs == 1 else "false"
+    if compute == F32:
+        return f"gemm_f32_kernel<{ak}, {bk}, *>"
+    return f"gemm_bf16_kernel<{tn[A.dtype]}, {tn[B.dtype]}, {ak}, {bk}>"
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -48,6 +61,13 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.taps, d.pad, d.dil, d.Tseq, d.kshift = taps, pad, dil, Tseq, kshift
     d.alpha, d.act, d.accumulate, d.splitk = alpha, act, acc, splitk
     d.a_dtype, d.b_dtype, d.c_dtype, d.compute = _dt(A), _dt(B), _dt(C), compute
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()          # torch's current stream == the stream handed to a3t_gemm
+        L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
+        e1.record()
+        PROFILE.append((_kernel_name(compute, a_cs, b_cs, A, B), 2.0 * M * N * K * batch, e0, e1))
+        return
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
 
 

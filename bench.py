@@ -1,0 +1,250 @@
+"""bench.py -- A3T masked-mel training-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]         (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward + loss + full backward + (RCCL gradient all-reduce if N>1) + grad-norm/clip/Adam
+of one synthetic batch that is already resident in HBM when the timed region
+starts.  Workload = BASELINE.json configs[1]: 6 enc + 6 dec Conformer blocks ("12L"), d=384,
+B=32/GPU, T_mel=1000, T_phn=120, bf16 MFMA compute with fp32 accumulation/master weights.
+Prints ONE JSON line on rank 0.  The CPU oracle is imported only for the cpu_baseline leg.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # TFLOP/s dense, MI355X_MICROARCH.md
+HBM_PEAK = 8000.0                            # GB/s
+
+
+def fwd_flops_per_step(c, B, Tm, Tp):
+    """Algorithmic forward FLOPs (SURVEY §8d / BASELINE.md §4)."""
+    T = Tm + Tp
+    d, ff = c.adim, c.ff
+
+    def blk(K):
+        return 8 * d * ff * c.ff_kernel + 8 * d * d + 6 * T * d + 6 * d * d + 2 * d * K
+
+    blocks = B * T * (c.enc_blocks * blk(c.enc_kernel) + c.dec_blocks * blk(c.dec_kernel))
+    blocks += (c.enc_blocks + c.dec_blocks) * 2 * d * d * T
+    n, ch, k = c.postnet_layers, c.postnet_chans, c.postnet_filts
+    post = 2 * k * (c.odim * ch + (n - 2) * ch * ch + ch * c.odim) if n >= 2 else 0
+    head = B * Tm * (2 * c.idim * d + 2 * d * c.odim + post)
+    return blocks + head
+
+
+class Trainer:
+    """Minimal mirror of Trainer.train_one_epoch's step body (espnet2/train/trainer.py:528-703)."""
+
+    def __init__(self, cfg, device, compute, world, lr=1.0, warmup=4000, clip=1.0):
+        from a3t_amd.engine import MLMEngine
+        from a3t_amd.params import ParamStore
+        from a3t_amd.init import xavier_init_
+        self.cfg, self.world = cfg, world
+        self.store = ParamStore(cfg, device)
+        xavier_init_(self.store, seed=0, bn_gamma=1.0)  # non-degenerate BN so no GEMM sees zeros
+        if world > 1:
+            dist.broadcast(self.store.flat, 0)     # C5: parameters start identical on every rank
+        self.engine = MLMEngine(cfg, self.store, compute=compute, training=True)
+        self.m = torch.zeros_like(self.store.flat)
+        self.v = torch.zeros_like(self.store.flat)
+        self.partial = torch.zeros(1024, dtype=torch.float64, device=device)
+        self.norm = torch.zeros(1, device=device)
+        self.step_no = 0
+        self.lr, self.warm, self.clip = lr, warmup, clip
+
+    def step(self, batch):
+        from a3t_amd import ops
+        self.step_no += 1
+        self.store.zero_grad()
+        out = self.engine.forward(batch)
+        self.engine.backward()
+        gscale = 1.0
+        if self.world > 1:
+            dist.all_reduce(self.store.grad)       # C1: one flat fp32 bucket over RCCL/xGMI
+            gscale = 1.0 / self.world
+        lr = self.lr * self.cfg.adim ** -0.5 * min(self.step_no ** -0.5, self.step_no * self.warm ** -1.5)
+        ops.sumsq(self.store.grad, self.partial)
+        ops.clip_adam(self.store.flat, self.store.grad, self.m, self.v, self.partial, self.norm, lr, self.step_no,
+                      clip=self.clip, gscale=gscale)
+        return out["loss"]
+
+
+def cpu_baseline_worker(blocks, Tm, Tp, threads, budget_s):
+    """Runs in a child process: the oracle (CPU restatement of the reference) fwd+bwd+clip+Adam on
+    `threads` host cores over a bounded sample of the same workload.  Prints one JSON line."""
+    from oracle import a3t_oracle as O
+    torch.set_num_threads(threads)
+    oc = O.A3TConfig(enc_blocks=blocks, dec_blocks=blocks)
+    B = 4
+    batch = O.synthetic_batch(oc, B, Tm, Tp, seed=1234)
+    p = O.to_torch_state(O.procedural_state(O.param_shapes(oc), 0), requires_grad=True)
+    params = [t for t in p.values() if t.requires_grad]
+    m = [torch.zeros_like(t) for t in params]
+    v = [torch.zeros_like(t) for t in params]
+
+    def one(step):
+        for t in params:
+            t.grad = None
+        loss, _, _ = O.forward_loss(p, batch, oc, True)
+        loss.backward()
+        with torch.no_grad():
+            O.clip_adam_step([t.data for t in params], [t.grad for t in params], m, v, step,
+                             O.noam_lr(step, 1.0, oc.adim, 4000))
+
+    t0 = time.time()
+    one(1)
+    warm = time.time() - t0
+    n = max(1, min(3, int((budget_s - warm) / max(warm, 1e-3))))
+    t0 = time.time()
+    for i in range(n):
+        one(2 + i)
+    dt = (time.time() - t0) / n
+    print(json.dumps(dict(value=B * Tm / dt, unit="mel-frames/s", cores=threads, kind="port",
+                          sample=f"oracle fwd+bwd+clip+Adam fp32, {blocks}+{blocks} blocks, B={B} T_mel={Tm} "
+                                 f"T_phn={Tp}, 1 warm-up + {n} timed steps ({dt:.2f} s/step)")), flush=True)
+
+
+def cpu_baseline(blocks, Tm, Tp, budget_s=20.0, hard_timeout_s=150.0):
+    """Bounded: child process + hard timeout, so the default bench run always finishes."""
+    import subprocess
+    threads = min(os.cpu_count() or 1, 32)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--blocks", str(blocks), "--tmel",
+           str(Tm), "--tphn", str(Tp), "--threads", str(threads), "--budget", str(budget_s)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=hard_timeout_s,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # noqa: BLE001
+        return dict(value=None, unit="mel-frames/s", cores=threads, kind="port",
+                    sample=f"cpu baseline did not finish within {hard_timeout_s:.0f}s ({type(e).__name__})")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--tmel", type=int, default=1000)
+    ap.add_argument("--tphn", type=int, default=120)
+    ap.add_argument("--blocks", type=int, default=6, help="encoder blocks = decoder blocks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--threads", type=int, default=32)
+    ap.add_argument("--budget", type=float, default=20.0)
+    a = ap.parse_args()
+    if a.cpu_baseline_worker:
+        cpu_baseline_worker(a.blocks, a.tmel, a.tphn, a.threads, a.budget)
+        return
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(a.blocks, a.tmel, a.tphn, a.budget)))
+        return
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from a3t_amd import ops
+    from a3t_amd.collate import synthetic_batch
+    from a3t_amd.config import config_c2
+    cfg = config_c2(enc_blocks=a.blocks, dec_blocks=a.blocks)
+    B, Tm, Tp = a.batch, a.tmel, a.tphn
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log("building trainer")
+    tr = Trainer(cfg, dev, a.compute, world)
+    batch = synthetic_batch(cfg, B, Tm, Tp, seed=1234 + rank, device=dev)
+    log(f"params {tr.store.n_params}; warm-up")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tr.step(batch)
+    sync()
+    log("timed region")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms = dt / a.steps * 1e3
+    frames = B * Tm * world
+    value = frames / (ms * 1e-3)
+    step_flops = 3.0 * fwd_flops_per_step(cfg, B, Tm, Tp)
+    final_loss = float(loss)
+    log(f"{ms:.1f} ms/step, {value:.0f} frames/s, loss {final_loss:.4f}")
+
+    roofline = None
+    if rank == 0 and not a.no_kernel_profile:
+        # one extra, untimed step with every GEMM launch bracketed by HIP events on the launch stream
+        ops.PROFILE = []
+        tr.step(batch)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for name, flops, e0, e1 in prof:
+            t = e0.elapsed_time(e1) * 1e-3
+            s = agg.setdefault(name, [0.0, 0.0, 0])
+            s[0] += flops
+            s[1] += t
+            s[2] += 1
+        name, (fl, tt, n) = max(agg.items(), key=lambda kv: kv[1][1])
+        achieved = fl / tt / 1e12
+        peak = MFMA_PEAK["bf16" if "bf16" in name else "f32"]
+        roofline = dict(bound="mfma", kernel=name, launches=n, avg_us=tt / n * 1e6, achieved=achieved, peak=peak,
+                        unit="TFLOP/s", frac=achieved / peak, traffic=None,
+                        gemm_time_share=sum(v[1] for v in agg.values()) / (ms * 1e-3),
+                        step_tflops=step_flops / (ms * 1e-3) / 1e12)
+    if rank == 0:
+        out = {
+            "metric": "mel-frames/sec (train)", "value": value, "unit": "mel-frames/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.compute, "data": "synthetic",
+            "config": {"workload": f"VCTK A3T masked-mel train step: {a.blocks}+{a.blocks} Conformer blocks d=384 "
+                                   f"H=2 ff=1536(k3), B={B}/GPU, T_mel={Tm}, T_phn={Tp}, postnet 5x256x5, "
+                                   f"fwd+bwd+clip+Adam, dropout=off",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "params": tr.store.n_params,
+                       "masked_fraction": float(batch["masked_position"].float().mean()),
+                       "algorithmic_tflop_per_step": step_flops / 1e12, "final_loss": final_loss},
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (oracle on host cores, child process)")
+            out["cpu_baseline"] = cpu_baseline(a.blocks, Tm, Tp, a.budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

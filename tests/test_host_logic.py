@@ -1,0 +1,68 @@
+"""CPU tests of the product's host-side logic (collate mirror, init, config translation)."""
+import os
+
+import numpy as np
+import torch
+
+from a3t_amd import collate as C
+from a3t_amd.config import A3TConfig
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_host_masks_bit_exact_vs_reference_golden():
+    g = np.load(os.path.join(G, "masks.npz"))
+    for i in range(7):
+        k = f"c{i}."
+        P, T = int(g[k + "P"]), int(g[k + "T"])
+        smask = np.arange(T)[None] < g[k + "tl"][:, None]
+        np.random.seed(int(g[k + "seed"]))
+        mp = C.phones_masking(T, smask, g[k + "a_s"], g[k + "a_e"], g[k + "lens"], float(g[k + "prob"]),
+                              int(g[k + "span"]))
+        assert np.array_equal(mp, g[k + "masked"]), i
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g[k + "rng_after"]), i
+        sp, tp = C.get_segment_pos(T, P, g[k + "a_s"], g[k + "a_e"], g[k + "lens"], True)
+        assert np.array_equal(sp, g[k + "sp"]) and np.array_equal(tp, g[k + "tp"])
+    T = int(g["sb.T"])
+    smask = np.arange(T)[None] < g["sb.tl"][:, None]
+    mp = C.phones_masking(T, smask, np.zeros((2, 3), np.int32), np.zeros((2, 3), np.int32), [3, 3], 0.8, 8,
+                          span_boundary=g["sb.sb"])
+    assert np.array_equal(mp, g["sb.masked"])
+    np.random.seed(5)
+    assert np.array_equal(C.random_spans_noise_mask(37, 0.8, 8), g["rsnm.len37"])
+    assert np.array_equal(C.random_spans_noise_mask(2, 0.8, 8), g["rsnm.len2"])
+    assert np.array_equal(C.align_to_frames(g["align.sec"], 24000, 300), g["align.frames"])
+
+
+def test_synthetic_batch_shapes_and_mask_fraction():
+    c = A3TConfig()
+    b = C.synthetic_batch(c, 4, 1000, 120, seed=1234)
+    assert b["speech"].shape == (4, 1000, 80) and b["text"].shape == (4, 120)
+    frac = float(b["masked_position"].float().mean())
+    assert 0.7 < frac < 0.9
+    assert int(b["speech_segment_pos"].max()) == 120 and int(b["speech_segment_pos"].min()) == 1
+
+
+def test_init_matches_recipe_rules():
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    c = A3TConfig(adim=32, heads=2, ff=64, enc_blocks=1, dec_blocks=1, postnet_layers=2, postnet_chans=16, vocab=11)
+    s = xavier_init_(ParamStore(c, "cpu"), seed=0)
+    sd = s.state_dict()
+    assert float(sd["encoder.encoders.0.conv_module.norm.weight"].abs().max()) == 0.0      # BN gamma zeroed
+    assert float(sd["encoder.encoders.0.norm_mha.weight"].min()) == 1.0                     # LN reset
+    assert float(sd["encoder.text_embed.0.weight"][-1].abs().max()) == 0.0                  # padding row
+    w = sd["encoder.encoders.0.feed_forward.w_1.weight"]                                    # (ff, d, 3)
+    bound = (6.0 / (32 * 3 + 64 * 3)) ** 0.5
+    assert float(w.abs().max()) <= bound and float(w.abs().max()) > 0.8 * bound
+    assert float(sd["sfc.bias"].abs().max()) == 0.0
+
+
+def test_config_from_espnet_yaml_dicts():
+    enc = dict(input_layer="sega_mlm", attention_dim=384, attention_heads=2, linear_units=1536, num_blocks=4,
+               cnn_module_kernel=7, positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3,
+               macaron_style=True, use_cnn_module=True, dropout_rate=0.2)
+    dec = dict(attention_dim=384, attention_heads=2, linear_units=1536, num_blocks=4, cnn_module_kernel=31)
+    mc = dict(postnet_layers=5, postnet_chans=256, postnet_filts=5, lsm_weight=0.1, mlm_prob=0.8, mean_phn_span=8)
+    c = A3TConfig.from_espnet(enc, dec, mc, input_size=80, odim=80, vocab=73)
+    assert (c.enc_kernel, c.dec_kernel, c.ff, c.dk) == (7, 31, 1536, 192)
