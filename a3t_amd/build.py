@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liba3t_hip.so")
-SOURCES = ["gemm.hip", "norm_reduce.hip", "convmod_attn.hip", "misc.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "norm_reduce.hip", "convmod_attn.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 
 
@@ -33,7 +33,7 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src, hdr]):
+        if force or _stale(obj, [src, hdr, os.path.join(CSRC, "gemm_common.h")]):
             jobs.append([_hipcc(), *FLAGS, "-c", src, "-o", obj])
 
     def run(cmd):

@@ -1,8 +1,10 @@
 // convmod_attn.hip -- Conformer convolution-module kernels (GLU + depthwise Conv1d with the time
 // window staged in LDS) and the rel-pos softmax kernels of the materialised attention path.
+// Tensors that feed / come from the MFMA GEMMs may be stored in bf16 (runtime dtype flags).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/a3t_hip.h"
+#include "dtype_io.h"
 
 #define WAVE 64
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
@@ -24,9 +26,10 @@ __device__ __forceinline__ float wmax(float v) {
 #define DW_TT 64
 #define DW_KMAX 31
 
-__global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const float* __restrict__ g, const float* __restrict__ wdw,
-                                                             const float* __restrict__ bdw, float* __restrict__ glu,
-                                                             float* __restrict__ z, int C, int K, int Tseq,
+__global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const void* __restrict__ g, int g_dt,
+                                                             const float* __restrict__ wdw,
+                                                             const float* __restrict__ bdw, void* __restrict__ glu,
+                                                             int glu_dt, float* __restrict__ z, int C, int K, int Tseq,
                                                              int tiles_t) {
     __shared__ float win[DW_TT + DW_KMAX - 1][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -39,9 +42,9 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const float* __rest
         int t = t0 - pad + r;
         float v = 0.f;
         if (c < C && t >= 0 && t < Tseq) {
-            const float* gr = g + (mbase + t) * (int64_t)(2 * C);
-            v = gr[c] * sigm(gr[C + c]);
-            if (r >= pad && r < pad + DW_TT) glu[(mbase + t) * (int64_t)C + c] = v;
+            const int64_t gi = (mbase + t) * (int64_t)(2 * C);
+            v = ldx(g, g_dt, gi + c) * sigm(ldx(g, g_dt, gi + C + c));
+            if (r >= pad && r < pad + DW_TT) stx(glu, glu_dt, (mbase + t) * (int64_t)C + c, v);
         }
         win[r][tx] = v;
     }
@@ -62,21 +65,21 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const float* __rest
     }
 }
 
-extern "C" int a3t_glu_dwconv_fwd(const float* g, const float* wdw, const float* bdw, float* glu, float* z, int M,
-                                  int C, int K, int Tseq, void* stream) {
+extern "C" int a3t_glu_dwconv_fwd(const void* g, int g_dtype, const float* wdw, const float* bdw, void* glu,
+                                  int glu_dtype, float* z, int M, int C, int K, int Tseq, void* stream) {
     if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
     int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
     dim3 grid((C + 63) / 64, B * tiles_t);
-    hipLaunchKernelGGL(glu_dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, wdw, bdw, glu, z, C, K, Tseq,
-                       tiles_t);
+    hipLaunchKernelGGL(glu_dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, g_dtype, wdw, bdw, glu,
+                       glu_dtype, z, C, K, Tseq, tiles_t);
     return (int)hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ g,
-                                                             const float* __restrict__ glu,
-                                                             const float* __restrict__ wdw, float* __restrict__ dg,
-                                                             float* dwdw, float* dbdw, int C, int K, int Tseq,
-                                                             int tiles_t) {
+__global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __restrict__ dz, const void* __restrict__ g,
+                                                             int g_dt, const void* __restrict__ glu, int glu_dt,
+                                                             const float* __restrict__ wdw, void* __restrict__ dg,
+                                                             int dg_dt, float* dwdw, float* dbdw, int C, int K,
+                                                             int Tseq, int tiles_t) {
     __shared__ float wdz[DW_TT + DW_KMAX - 1][64];   // dz window  (rows t0-pad .. t0+TT+pad)
     __shared__ float wgl[DW_TT + DW_KMAX - 1][64];   // glu window
     __shared__ float red[4][64];
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
         float a = 0.f, q = 0.f;
         if (c < C && t >= 0 && t < Tseq) {
             a = dz[(mbase + t) * (int64_t)C + c];
-            q = glu[(mbase + t) * (int64_t)C + c];
+            q = ldx(glu, glu_dt, (mbase + t) * (int64_t)C + c);
         }
         wdz[r][tx] = a;
         wgl[r][tx] = q;
@@ -108,16 +111,15 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
         for (int r = ty; r < DW_TT; r += 4) {
             int t = t0 + r;
             if (t >= Tseq) break;
-            // data gradient: dglu[t] = sum_k w[k] * dz[t + pad - k]  (window row r + 2*pad - k ... )
+            // data gradient: dglu[t] = sum_k w[k] * dz[t + pad - k]  (window row r + 2*pad - k)
             float acc = 0.f;
 #pragma unroll
             for (int k = 0; k < DW_KMAX; ++k)
                 if (k < K) acc += w[k] * wdz[r + 2 * pad - k][tx];
-            const float* gr = g + (mbase + t) * (int64_t)(2 * C);
-            float ga = gr[c], sb = sigm(gr[C + c]);
-            float* dgr = dg + (mbase + t) * (int64_t)(2 * C);
-            dgr[c] = acc * sb;
-            dgr[C + c] = acc * ga * sb * (1.f - sb);
+            const int64_t gi = (mbase + t) * (int64_t)(2 * C);
+            float ga = ldx(g, g_dt, gi + c), sb = sigm(ldx(g, g_dt, gi + C + c));
+            stx(dg, dg_dt, gi + c, acc * sb);
+            stx(dg, dg_dt, gi + C + c, acc * ga * sb * (1.f - sb));
             // weight gradient: dw[k] += dz[t] * glu[t + k - pad]
             float dzt = wdz[r + pad][tx];
             db += dzt;
@@ -139,52 +141,55 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
     if (ty == 0 && c < C) atomicAdd(&dbdw[c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }
 
-extern "C" int a3t_glu_dwconv_bwd(const float* dz, const float* g, const float* glu, const float* wdw, float* dg,
-                                  float* dwdw, float* dbdw, int M, int C, int K, int Tseq, void* stream) {
+extern "C" int a3t_glu_dwconv_bwd(const float* dz, const void* g, int g_dtype, const void* glu, int glu_dtype,
+                                  const float* wdw, void* dg, int dg_dtype, float* dwdw, float* dbdw, int M, int C,
+                                  int K, int Tseq, void* stream) {
     if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
     int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
     dim3 grid((C + 63) / 64, B * tiles_t);
-    hipLaunchKernelGGL(glu_dwconv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, g, glu, wdw, dg, dwdw, dbdw,
-                       C, K, Tseq, tiles_t);
+    hipLaunchKernelGGL(glu_dwconv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, g, g_dtype, glu, glu_dtype,
+                       wdw, dg, dg_dtype, dwdw, dbdw, C, K, Tseq, tiles_t);
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
 // attention helpers
 // ------------------------------------------------------------------------------------------
-__global__ void add_pos_bias_kernel(const float* __restrict__ qkv, const float* __restrict__ bu,
-                                    const float* __restrict__ bv, float* __restrict__ qu, float* __restrict__ qv,
-                                    int64_t n, int d) {
+__global__ void add_pos_bias_kernel(const void* __restrict__ qkv, const float* __restrict__ bu,
+                                    const float* __restrict__ bv, void* __restrict__ qu, void* __restrict__ qv,
+                                    int dt, int64_t n, int d) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t m = i / d;
         int c = (int)(i - m * d);
-        float q = qkv[m * 3 * d + c];
-        qu[i] = q + bu[c];
-        qv[i] = q + bv[c];
+        float q = ldx(qkv, dt, m * 3 * d + c);
+        stx(qu, dt, i, q + bu[c]);
+        stx(qv, dt, i, q + bv[c]);
     }
 }
-extern "C" int a3t_add_pos_bias(const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv,
-                                int M, int d, void* stream) {
+extern "C" int a3t_add_pos_bias(const void* qkv, const float* bias_u, const float* bias_v, void* qu, void* qv,
+                                int dtype, int M, int d, void* stream) {
     int64_t n = (int64_t)M * d;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(add_pos_bias_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, bias_u, bias_v, qu,
-                       qv, n, d);
+                       qv, dtype, n, d);
     return (int)hipGetLastError();
 }
-__global__ void add_pos_bias_bwd_kernel(const float* __restrict__ dqu, const float* __restrict__ dqv,
-                                        float* __restrict__ dqkv, int64_t n, int d) {
+__global__ void add_pos_bias_bwd_kernel(const void* __restrict__ dqu, const void* __restrict__ dqv,
+                                        void* __restrict__ dqkv, int dt, int64_t n, int d) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t m = i / d;
         int c = (int)(i - m * d);
-        dqkv[m * 3 * d + c] = dqu[i] + dqv[i];
+        stx(dqkv, dt, m * 3 * d + c, ldx(dqu, dt, i) + ldx(dqv, dt, i));
     }
 }
-extern "C" int a3t_add_pos_bias_bwd(const float* dqu, const float* dqv, float* dqkv, int M, int d, void* stream) {
+extern "C" int a3t_add_pos_bias_bwd(const void* dqu, const void* dqv, void* dqkv, int dtype, int M, int d,
+                                    void* stream) {
     int64_t n = (int64_t)M * d;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(add_pos_bias_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dqu, dqv, dqkv, n, d);
+    hipLaunchKernelGGL(add_pos_bias_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dqu, dqv, dqkv, dtype,
+                       n, d);
     return (int)hipGetLastError();
 }
 
@@ -201,7 +206,7 @@ __device__ __forceinline__ float bd_shift(const float* __restrict__ BDz, int T, 
 __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __restrict__ ac,
                                                                  const float* __restrict__ bd,
                                                                  const uint8_t* __restrict__ keymask,
-                                                                 float* __restrict__ probs, int H, int T,
+                                                                 void* __restrict__ probs, int p_dt, int H, int T,
                                                                  int64_t ac_bs, int64_t bd_bs, int64_t p_bs,
                                                                  float scale, int64_t nrows) {
     const int lane = threadIdx.x & 63;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     const float* ar = ac + zz * ac_bs + (int64_t)i * T;
     const float* bz = bd + zz * bd_bs;
     const uint8_t* mk = keymask + (int64_t)b * T;
-    float* pr = probs + zz * p_bs + (int64_t)i * T;
+    const int64_t po = zz * p_bs + (int64_t)i * T;
     float mx = -3.4028235e38f;
     int any = 0;
     for (int j = lane; j < T; j += 64)
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     mx = wmax(mx);
     any = __any(any);
     if (!any) {  // every key padded: softmax over equal fills then masked_fill(0) -> zeros
-        for (int j = lane; j < T; j += 64) pr[j] = 0.f;
+        for (int j = lane; j < T; j += 64) stx(probs, p_dt, po + j, 0.f);
         return;
     }
     float s = 0.f;
@@ -233,52 +238,52 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     s = wsum(s);
     const float inv = 1.f / s;
     for (int j = lane; j < T; j += 64)
-        pr[j] = mk[j] ? expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx) * inv : 0.f;
+        stx(probs, p_dt, po + j, mk[j] ? expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx) * inv : 0.f);
 }
 
-extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, float* probs, int B,
-                                      int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs, float scale,
-                                      void* stream) {
+extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, void* probs,
+                                      int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs,
+                                      int64_t p_bs, float scale, void* stream) {
     int64_t nrows = (int64_t)B * H * T;
     hipLaunchKernelGGL(relpos_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       ac, bd, keymask, probs, H, T, ac_bs, bd_bs, p_bs, scale, nrows);
+                       ac, bd, keymask, probs, probs_dtype, H, T, ac_bs, bd_bs, p_bs, scale, nrows);
     return (int)hipGetLastError();
 }
 
-// ds (in place over dprobs) = probs*(dprobs - sum_j dprobs*probs)*scale, and the un-shifted scatter
-// of the same values into the compact dBD matrix (every dBD element is written exactly once).
-__global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const float* __restrict__ probs,
-                                                                 float* __restrict__ dprobs,
-                                                                 float* __restrict__ dbd, int T, int64_t p_bs,
-                                                                 int64_t dp_bs, int64_t dbd_bs, float scale,
-                                                                 int64_t nrows) {
+// ds = probs*(dprobs - sum_j dprobs*probs)*scale: written to ds (same dtype as dbd; may alias dprobs
+// when fp32) and scattered un-shifted into the compact dBD (every dBD element written exactly once).
+__global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __restrict__ probs, int p_dt,
+                                                                 const float* dprobs, void* ds, void* __restrict__ dbd,
+                                                                 int o_dt, int T, int64_t p_bs, int64_t dp_bs,
+                                                                 int64_t o_bs, float scale, int64_t nrows) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
     const int64_t zz = row / T;
     const int i = (int)(row - zz * T);
-    const float* pr = probs + zz * p_bs + (int64_t)i * T;
-    float* dr = dprobs + zz * dp_bs + (int64_t)i * T;
-    float* dz = dbd + zz * dbd_bs;
+    const int64_t po = zz * p_bs + (int64_t)i * T;
+    const float* dr = dprobs + zz * dp_bs + (int64_t)i * T;
+    const int64_t oz = zz * o_bs;
     float s = 0.f;
-    for (int j = lane; j < T; j += 64) s += pr[j] * dr[j];
+    for (int j = lane; j < T; j += 64) s += ldx(probs, p_dt, po + j) * dr[j];
     s = wsum(s);
     for (int j = lane; j < T; j += 64) {
-        float v = pr[j] * (dr[j] - s) * scale;
-        dr[j] = v;
+        float v = ldx(probs, p_dt, po + j) * (dr[j] - s) * scale;
+        stx(ds, o_dt, oz + (int64_t)i * T + j, v);
         if (j <= i)
-            dz[(int64_t)i * T + (T - 1 - i + j)] = v;
+            stx(dbd, o_dt, oz + (int64_t)i * T + (T - 1 - i + j), v);
         else if (j > i + 1)
-            dz[(int64_t)(i + 1) * T + (j - i - 2)] = v;
+            stx(dbd, o_dt, oz + (int64_t)(i + 1) * T + (j - i - 2), v);
     }
     if (i == 0)  // BD[0][0..T-2] never reaches the scores
-        for (int j = lane; j < T - 1; j += 64) dz[j] = 0.f;
+        for (int j = lane; j < T - 1; j += 64) stx(dbd, o_dt, oz + j, 0.f);
 }
 
-extern "C" int a3t_relpos_softmax_bwd(const float* probs, float* dprobs, float* dbd, int B, int H, int T,
-                                      int64_t p_bs, int64_t dp_bs, int64_t dbd_bs, float scale, void* stream) {
+extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const float* dprobs, void* ds, void* dbd,
+                                      int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
+                                      float scale, void* stream) {
     int64_t nrows = (int64_t)B * H * T;
     hipLaunchKernelGGL(relpos_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       probs, dprobs, dbd, T, p_bs, dp_bs, dbd_bs, scale, nrows);
+                       probs, probs_dtype, dprobs, ds, dbd, out_dtype, T, p_bs, dp_bs, o_bs, scale, nrows);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,351 @@
+// gemm_bf16.hip -- bf16-operand MFMA GEMM for gfx950 with direct global->LDS staging.
+//
+// The production contraction kernel of the bf16 compute path (activations feeding GEMMs are
+// stored in bf16, weights are cast once per step).  Per 128x128x64 tile:
+//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip);
+//     LDS images are lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
+//     address and undone on the fragment read (same XOR involution on both sides);
+//   * k-contiguous operands ([rows][k], NT GEMMs and the im2col conv loader) are read back with
+//     conflict-free ds_read_b128; reduction-strided operands ([k][rows]: W for data gradients,
+//     activations for weight gradients) are read with ds_read_b64_tr_b16, the CDNA4 LDS
+//     transpose read, so no register transposes are needed for the NN / TN layouts;
+//   * 4 waves x (2x2) v_mfma_f32_32x32x16_bf16 accumulators, LDS double buffered, one barrier
+//     per K-tile with the next tile's DMA in flight across the MFMA block.
+// Out-of-range rows / im2col padding / K tails read a 16-byte device zero page instead of
+// branching around the DMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/a3t_hip.h"
+#include "gemm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+__device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
+
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
+
+enum { L_NT = 0, L_NN = 1, L_TN = 2 };
+
+template <int LAYOUT>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
+    constexpr int BM = 128, BN = 128, BK = 64;
+    constexpr bool A_KC = (LAYOUT != L_TN), B_KC = (LAYOUT == L_NT);
+    constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A|B][16 KiB]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware remap (bijective): workgroup b runs on XCD b%8, so give every XCD a contiguous run
+    // of tile ids; neighbours in a run share the A row-panel / B panel in that XCD's private L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int ks = blockIdx.y % p.splitk, bz = blockIdx.y / p.splitk;
+    const int z0 = bz / p.batch_inner, z1 = bz % p.batch_inner;
+    const u16* A = (const u16*)p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
+    const u16* B = (const u16*)p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
+    const int64_t zoff = z0 * p.c_bs0 + z1 * p.c_bs1;
+    const u16* ZP = (const u16*)a3t_zero_page;
+
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    // ---- per-lane source bookkeeping (4 DMA instructions per operand per tile) ---------------
+    // k-contiguous image: instr q of wave w covers tile rows (w*4+q)*8 + (lane>>3), 16-B chunk
+    //   position c = lane&7 holds source chunk c ^ (row&7).
+    // row-contiguous image: instr q covers k-rows (w*4+q)*4 + (lane>>4), chunk position
+    //   c = lane&15 holds source chunk c ^ ((krow&3)<<2).
+    const u16* a_row[4];   // A_KC: row base pointer (nullptr-equivalent = invalid -> zero page)
+    int a_tp[4];           // A_KC conv: position in utterance
+    bool a_ok[4];
+    int a_sw[4];           // swizzled source chunk (elements offset = *8)
+    const u16* b_row[4];
+    bool b_ok[4];
+    int b_sw[4];
+    int a_tap[4], a_cc[4];  // running (tap, channel) of this lane's chunk for the im2col loader
+    int b_tap[4], b_cc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        a_tap[q] = 0, a_cc[q] = 0, b_tap[q] = 0, b_cc[q] = 0;
+        if (A_KC) {
+            int r = (w * 4 + q) * 8 + (lane >> 3);
+            int m = tm * BM + r;
+            a_ok[q] = m < p.M;
+            a_tp[q] = (p.taps > 1) ? (m % p.Tseq) : 0;
+            a_row[q] = A + (int64_t)m * p.a_rs;
+            a_sw[q] = ((lane & 7) ^ (r & 7)) * 8;
+            if (p.taps > 1) {
+                int kg = kt0 * BK + a_sw[q];
+                a_tap[q] = kg / p.Kc;
+                a_cc[q] = kg - a_tap[q] * p.Kc;
+            }
+        } else {
+            int kr = (w * 4 + q) * 4 + (lane >> 4);
+            int col = tm * BM + (((lane & 15) ^ ((kr & 3) << 2)) * 8);
+            a_ok[q] = col < p.M;
+            a_row[q] = A + col;
+            a_sw[q] = kr;
+            a_tp[q] = 0;
+        }
+        if (B_KC) {
+            int r = (w * 4 + q) * 8 + (lane >> 3);
+            int n = tn * BN + r;
+            b_ok[q] = n < p.N;
+            b_row[q] = B + (int64_t)n * p.b_rs;
+            b_sw[q] = ((lane & 7) ^ (r & 7)) * 8;
+        } else {
+            int kr = (w * 4 + q) * 4 + (lane >> 4);
+            int col = tn * BN + (((lane & 15) ^ ((kr & 3) << 2)) * 8);
+            b_ok[q] = col < p.N;
+            b_row[q] = B + col;
+            b_sw[q] = kr;
+            // running decomposition of this lane's reduction index: (tap, channel) for W^T of a conv,
+            // position inside the utterance for the token-shifted weight-gradient operand
+            int kg = kt0 * BK + kr;
+            if (p.taps > 1) {
+                b_tap[q] = kg / p.Kc;
+                b_cc[q] = kg - b_tap[q] * p.Kc;
+            } else if (p.kshift_mode) {
+                b_cc[q] = kg % p.Tseq;
+            }
+        }
+    }
+
+    auto issue = [&](int k0, int stage) {
+        unsigned char* sA = smem + stage * 2 * TILE_BYTES;
+        unsigned char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u16* src = ZP;
+            if (A_KC) {
+                int kg = k0 + a_sw[q];
+                if (p.taps > 1) {
+                    if (a_ok[q] && kg < p.K) {
+                        int off = (a_tap[q] - p.pad) * p.dil, tt = a_tp[q] + off;
+                        if (tt >= 0 && tt < p.Tseq) src = a_row[q] + (int64_t)off * p.a_rs + a_cc[q];
+                    }
+                    a_cc[q] += BK;                       // tiles are issued in order: advance by one K-tile
+                    while (a_cc[q] >= p.Kc) a_cc[q] -= p.Kc, ++a_tap[q];
+                } else if (a_ok[q] && kg < p.K) {
+                    src = a_row[q] + kg;
+                }
+            } else {
+                int kg = k0 + a_sw[q];
+                if (a_ok[q] && kg < p.K) src = a_row[q] + (int64_t)kg * p.a_cs;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * 4 + q) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u16* src = ZP;
+            int kg = k0 + b_sw[q];
+            if (B_KC) {
+                if (b_ok[q] && kg < p.K) {
+                    int64_t koff = kg;
+                    if (p.taps > 1 && p.b_ts != p.Kc) {   // (weights are stored [n][tap][c]: b_ts == Kc, no split)
+                        int tap = kg / p.Kc, cc = kg - tap * p.Kc;
+                        koff = (int64_t)tap * p.b_ts + cc;
+                    }
+                    src = b_row[q] + koff;
+                }
+            } else if (p.taps > 1) {
+                if (b_ok[q] && kg < p.K) src = b_row[q] + (int64_t)b_tap[q] * p.b_ts + (int64_t)b_cc[q] * p.b_cs;
+                b_cc[q] += BK;
+                while (b_cc[q] >= p.Kc) b_cc[q] -= p.Kc, ++b_tap[q];
+            } else if (p.kshift_mode) {
+                int tt = b_cc[q] + p.kshift;
+                if (b_ok[q] && kg < p.K && tt >= 0 && tt < p.Tseq) src = b_row[q] + (int64_t)(kg + p.kshift) * p.b_cs;
+                b_cc[q] += BK;
+                while (b_cc[q] >= p.Tseq) b_cc[q] -= p.Tseq;
+            } else if (b_ok[q] && kg < p.K) {
+                src = b_row[q] + (int64_t)kg * p.b_cs;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64, lr = lane & 31, lk = lane >> 5;
+    // fragment read offsets (bytes inside one operand image), constant over the K loop
+    auto frag_kc = [&](const unsigned char* img, int row, int kk) -> bf16x8 {
+        int kc = kk * 2 + lk;
+        return *(const bf16x8*)(img + row * 128 + ((kc ^ (row & 7)) << 4));
+    };
+    auto frag_rc = [&](const unsigned char* img, int row0, int kk) -> bf16x8 {
+        // 16-lane group g: rows row0 + (g&1)*16 .. +15, k = kk*16 + (g>>1)*8 .. +7 (two 4-k transposed reads)
+        const int g = lane >> 4, pp = lane & 15;
+        const int col = row0 + (g & 1) * 16 + (pp & 3) * 4;
+        const int kb = kk * 16 + (g >> 1) * 8 + (pp >> 2);
+        const int k1 = kb + 4;
+        const unsigned char* a0 = img + kb * 256 + ((((col >> 3) ^ ((kb & 3) << 2))) << 4) + (col & 7) * 2;
+        const unsigned char* a1 = img + k1 * 256 + ((((col >> 3) ^ ((k1 & 3) << 2))) << 4) + (col & 7) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a1));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    issue(kt0 * BK, 0);
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        __syncthreads();  // drains this tile's DMA (vmcnt(0) precedes the barrier) + WAR on the other stage
+        if (kt + 1 < kt1) issue((kt + 1) * BK, stage ^ 1);
+        const unsigned char* sA = smem + stage * 2 * TILE_BYTES;
+        const unsigned char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 a0, a1, b0, b1;
+            if (A_KC) {
+                a0 = frag_kc(sA, wm + lr, kk);
+                a1 = frag_kc(sA, wm + 32 + lr, kk);
+            } else {
+                a0 = frag_rc(sA, wm, kk);
+                a1 = frag_rc(sA, wm + 32, kk);
+            }
+            if (B_KC) {
+                b0 = frag_kc(sB, wn + lr, kk);
+                b1 = frag_kc(sB, wn + 32 + lr, kk);
+            } else {
+                b0 = frag_rc(sB, wn, kk);
+                b1 = frag_rc(sB, wn + 32, kk);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        stage ^= 1;
+    }
+    if (!p.epi_vec) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = tm * BM + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    int col = tn * BN + wn + j * 32 + lr;
+                    epilogue_store(p, zoff, row, col, acc[i][j][r], ks);
+                }
+        return;
+    }
+    // Stage each wave's 64x64 fp32 sub-tile through its own 16 KiB of (now idle) LDS so that every
+    // lane finishes 4 consecutive columns: bias / residual / mask reads and the output stores
+    // become 16-byte (8-byte for bf16) accesses, 256 B contiguous per output row segment.
+    __syncthreads();
+    float* ct = (float*)smem + w * 4096;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = acc[i][j][r];
+    // (only this wave reads its region back; a wave is lock-step, LDS ops are issued in order)
+    const int c4 = (lane & 15) * 4, r4 = lane >> 4;
+    const int col = tn * BN + wn + c4;
+    if (col >= p.N) return;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && ks == 0) bias4 = *(const float4*)(p.bias + col);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int lrow = it * 4 + r4;
+        const int row = tm * BM + wm + lrow;
+        if (row >= p.M) continue;
+        float4 v = *(const float4*)(ct + lrow * 64 + c4);
+        const int64_t idx = zoff + (int64_t)row * p.c_rs + col;
+        v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
+        if (p.act != A3T_ACT_NONE) {
+            v.x = apply_act(v.x, p.act), v.y = apply_act(v.y, p.act);
+            v.z = apply_act(v.z, p.act), v.w = apply_act(v.w, p.act);
+        }
+        if (p.S) {
+            float4 sv;
+            if (p.s_dtype == A3T_BF16) {
+                uint2 t = *(const uint2*)((const u16*)p.S + idx);
+                sv = make_float4(bf2f(t.x & 0xffff), bf2f(t.x >> 16), bf2f(t.y & 0xffff), bf2f(t.y >> 16));
+            } else {
+                sv = *(const float4*)(p.S + idx);
+            }
+            v.x = sv.x > 0.f ? v.x : 0.f, v.y = sv.y > 0.f ? v.y : 0.f;
+            v.z = sv.z > 0.f ? v.z : 0.f, v.w = sv.w > 0.f ? v.w : 0.f;
+        }
+        v.x *= p.alpha, v.y *= p.alpha, v.z *= p.alpha, v.w *= p.alpha;
+        if (p.R && ks == 0) {
+            float4 rv = *(const float4*)(p.R + idx);
+            v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+        }
+        if (p.c_dtype == A3T_BF16) {
+            uint2 o;
+            o.x = f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+            o.y = f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+            *(uint2*)((u16*)p.C + idx) = o;
+        } else {
+            float* C = (float*)p.C + idx;
+            if (p.accumulate == A3T_ACC_STORE) {
+                *(float4*)C = v;
+            } else if (p.accumulate == A3T_ACC_ADD) {
+                float4 o = *(const float4*)C;
+                o.x += v.x, o.y += v.y, o.z += v.z, o.w += v.w;
+                *(float4*)C = o;
+            } else {
+                atomicAdd(C + 0, v.x), atomicAdd(C + 1, v.y), atomicAdd(C + 2, v.z), atomicAdd(C + 3, v.w);
+            }
+        }
+    }
+}
+
+static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+static inline bool m8(int64_t v) { return (v % 8) == 0; }
+
+// returns -1 when the descriptor does not meet the alignment contract of this kernel
+int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t stream) {
+    bool ok = al16(p.A) && al16(p.B) && m8(p.a_bs0) && m8(p.a_bs1) && m8(p.b_bs0) && m8(p.b_bs1) && m8(p.Kc);
+    if (AK)
+        ok = ok && m8(p.a_rs) && m8(p.K);
+    else
+        ok = ok && m8(p.a_cs) && m8(p.M);
+    if (BKC)
+        ok = ok && m8(p.b_rs) && m8(p.K) && m8(p.b_ts);
+    else
+        ok = ok && m8(p.b_cs) && m8(p.b_ts) && m8(p.N);
+    if (!ok) return -1;
+    GP pv = p;
+    // vector epilogue contract: 4-column groups never straddle N and every C/R/S/bias access is aligned
+    pv.epi_vec = (p.N % 4 == 0) && (p.c_rs % 4 == 0) && (p.c_bs0 % 4 == 0) && (p.c_bs1 % 4 == 0) &&
+                 al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
+    const int tiles_m = (p.M + 127) / 128;
+    dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk)), block(256);
+    const size_t lds = 4 * 128 * 64 * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (AK && BKC)
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel<L_NT>, grid, block, lds, stream, pv);
+    else if (AK && !BKC)
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel<L_NN>, grid, block, lds, stream, pv);
+    else
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel<L_TN>, grid, block, lds, stream, pv);
+    return (int)hipGetLastError();
+}

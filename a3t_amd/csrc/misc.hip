@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "../../include/a3t_hip.h"
+#include "dtype_io.h"
 
 static inline int nblocks(int64_t n, int cap = 4096) {
     int64_t b = (n + 255) / 256;
@@ -14,18 +15,18 @@ static inline int nblocks(int64_t n, int cap = 4096) {
 
 // ---------------------------------------------------------------- encoder prologue
 __global__ void mask_fill_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m,
-                                 const float* __restrict__ mf, float* __restrict__ y, int64_t n, int C) {
+                                 const float* __restrict__ mf, void* __restrict__ y, int y_dt, int64_t n, int C) {
     GRID_STRIDE(i, n) {
         int64_t r = i / C;
         int c = (int)(i - r * C);
-        y[i] = m[r] ? mf[c] : x[i];
+        stx(y, y_dt, i, m[r] ? mf[c] : x[i]);
     }
 }
-extern "C" int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, float* out, int M,
-                             int C, void* stream) {
+extern "C" int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,
+                             int out_dtype, int M, int C, void* stream) {
     int64_t n = (int64_t)M * C;
     hipLaunchKernelGGL(mask_fill_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, speech, masked,
-                       mask_feature, out, n, C);
+                       mask_feature, out, out_dtype, n, C);
     return (int)hipGetLastError();
 }
 
@@ -107,7 +108,22 @@ extern "C" int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stre
     hipLaunchKernelGGL(axpy_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, a);
     return (int)hipGetLastError();
 }
-__global__ void slice_rows_kernel(const float* x, float* y, int B, int T, int Tm, int D, int reverse) {
+__global__ void cast_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n4) {
+    GRID_STRIDE(i, n4) {
+        float4 v = ((const float4*)x)[i];
+        uint2 o;
+        o.x = io_f2bf(v.x) | ((unsigned)io_f2bf(v.y) << 16);
+        o.y = io_f2bf(v.z) | ((unsigned)io_f2bf(v.w) << 16);
+        ((uint2*)y)[i] = o;
+    }
+}
+extern "C" int a3t_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
+    if (n % 4 || ((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return A3T_EINVAL;
+    hipLaunchKernelGGL(cast_kernel, dim3(nblocks(n / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short*)y, n / 4);
+    return (int)hipGetLastError();
+}
+__global__ void slice_rows_kernel(const float* x, void* y, int y_dt, int B, int T, int Tm, int D, int reverse) {
     const int64_t n = (int64_t)B * Tm * D;
     GRID_STRIDE(i, n) {
         int64_t r = i / D;
@@ -115,15 +131,16 @@ __global__ void slice_rows_kernel(const float* x, float* y, int B, int T, int Tm
         int b = (int)(r / Tm), t = (int)(r - (int64_t)b * Tm);
         int64_t j = ((int64_t)b * T + t) * D + c;
         if (reverse)
-            ((float*)x)[j] += y[i];
+            ((float*)x)[j] += ldx(y, y_dt, i);
         else
-            y[i] = x[j];
+            stx(y, y_dt, i, x[j]);
     }
 }
-extern "C" int a3t_slice_rows(const float* x, float* y, int B, int T, int Tm, int D, int reverse_add, void* stream) {
+extern "C" int a3t_slice_rows(const float* x, void* y, int y_dtype, int B, int T, int Tm, int D, int reverse_add,
+                              void* stream) {
     int64_t n = (int64_t)B * Tm * D;
-    hipLaunchKernelGGL(slice_rows_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, B, T, Tm, D,
-                       reverse_add);
+    hipLaunchKernelGGL(slice_rows_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, y_dtype, B, T, Tm,
+                       D, reverse_add);
     return (int)hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/a3t_hip.h"
+#include "dtype_io.h"
 
 #define WAVE 64
 
@@ -19,7 +20,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 #define LN_MAXV 24  // D <= 1536
 
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     const float* __restrict__ b, void* __restrict__ y, int y_dt,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M,
                                                      int D, float eps) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -44,11 +45,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     const float var = wave_sum(q) / (float)D;
     const float rs = 1.0f / sqrtf(var + eps);
-    float* yr = y + (int64_t)row * D;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         int c = lane + i * 64;
-        if (c < D) yr[c] = (v[i] - mu) * rs * g[c] + b[c];
+        if (c < D) stx(y, y_dt, (int64_t)row * D + c, (v[i] - mu) * rs * g[c] + b[c]);
     }
     if (lane == 0) {
         mean[row] = mu;
@@ -56,10 +56,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
                                                      const float* __restrict__ g, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* dres,
-                                                     float* dx, float* __restrict__ dgamma,
+                                                     float* dx, unsigned short* __restrict__ dx16,
+                                                     float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D) {
     __shared__ float red[2][4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -74,13 +75,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         const float* xr = x + (int64_t)row * D;
-        const float* dr = dy + (int64_t)row * D;
         float xh[LN_MAXV], dg[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i) {
             int c = lane + i * 64;
-            float d = (c < D) ? dr[c] : 0.f;
+            float d = (c < D) ? ldx(dy, dy_dt, (int64_t)row * D + c) : 0.f;
             xh[i] = (c < D) ? (xr[c] - mu) * rs : 0.f;
             dg[i] = d * gam[i];
             s1 += dg[i];
@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 float o = rs * (dg[i] - s1 - xh[i] * s2);
                 if (rr) o += rr[c];
                 dxr[c] = o;
+                if (dx16) dx16[(int64_t)row * D + c] = io_f2bf(o);
             }
         }
     }
@@ -120,29 +121,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
-extern "C" int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                 float* rstd, int M, int D, float eps, void* stream) {
+extern "C" int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                                 float* mean, float* rstd, int M, int D, float eps, void* stream) {
     if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
-                       rstd, M, D, eps);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, y_dtype,
+                       mean, rstd, M, D, eps);
     return (int)hipGetLastError();
 }
 
-extern "C" int a3t_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                 const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                                 int M, int D, void* stream) {
+extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                                 const float* mean, const float* rstd, const float* dres, float* dx, void* dx_bf16,
+                                 float* dgamma, float* dbeta, int M, int D, void* stream) {
     if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
     int blocks = (M + 3) / 4;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, gamma, mean, rstd, dres,
-                       dx, dgamma, dbeta, M, D);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean,
+                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, M, D);
     return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
 // column reductions: block = 64 columns x 4 row lanes; grid (ceil(C/64), row blocks)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict__ x, int x_dt, const float* __restrict__ y,
                                                          const uint8_t* __restrict__ rowmask, double* out0,
                                                          double* out1, int M, int C, int64_t ld, int mode,
                                                          int rows_per_block) {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
         int cnt = 0;
         for (int r = r0 + ty; r < r1; r += 4) {
             if (rowmask && !rowmask[r]) continue;
-            float v = x[(int64_t)r * ld + c];
+            float v = ldx(x, x_dt, (int64_t)r * ld + c);
             f0 += v;
             if (mode == 1)
                 f1 += v * v;
@@ -177,13 +178,13 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const float* __restrict
     }
 }
 
-extern "C" int a3t_col_reduce(const float* x, const float* y, const uint8_t* rowmask, double* out0, double* out1,
-                              int M, int C, int64_t ld, int mode, void* stream) {
+extern "C" int a3t_col_reduce(const void* x, int x_dtype, const float* y, const uint8_t* rowmask, double* out0,
+                              double* out1, int M, int C, int64_t ld, int mode, void* stream) {
     if (M <= 0 || C <= 0) return A3T_EINVAL;
     int rpb = 256;
     dim3 grid((C + 63) / 64, (M + rpb - 1) / rpb);
-    hipLaunchKernelGGL(col_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, rowmask, out0, out1, M, C, ld,
-                       mode, rpb);
+    hipLaunchKernelGGL(col_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, rowmask, out0, out1, M,
+                       C, ld, mode, rpb);
     return (int)hipGetLastError();
 }
 
@@ -226,8 +227,8 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, float* __restrict__ y,
-                                                         int64_t n, int C, int act) {
+                                                         const float* __restrict__ beta, void* __restrict__ y,
+                                                         int y_dt, int64_t n, int C, int act) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
         float bn = (z[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
@@ -236,25 +237,26 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
             o = bn * sigmoidf_(bn);
         else if (act == A3T_ACT_TANH)
             o = tanhf(bn);
-        y[i] = o;
+        stx(y, y_dt, i, o);
     }
 }
 
 extern "C" int a3t_bn_act_fwd(const float* z, const double* stats, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* y,
-                              int M, int C, float eps, float momentum, int training, int act, void* stream) {
+                              float* running_mean, float* running_var, float* mean_out, float* rstd_out, void* y,
+                              int y_dtype, int M, int C, float eps, float momentum, int training, int act,
+                              void* stream) {
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, running_mean, running_var,
                        mean_out, rstd_out, M, C, eps, momentum, training);
     int64_t n = (int64_t)M * C;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, s, z, mean_out, rstd_out, gamma, beta, y, n, C,
-                       act);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, s, z, mean_out, rstd_out, gamma, beta, y, y_dtype, n,
+                       C, act);
     return (int)hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+__global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ z,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const float* __restri
             int64_t i = (int64_t)r * C + c;
             float zh = (z[i] - mu) * rs;
             float bn = zh * g + b;
-            float d = dy[i];
+            float d = ldx(dy, dy_dt, i);
             if (act == A3T_ACT_SWISH) {
                 float sg = sigmoidf_(bn);
                 d *= sg * (1.f + bn * (1.f - sg));
@@ -299,13 +301,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const float* __restri
     }
 }
 
-extern "C" int a3t_bn_act_bwd_a(const float* dy, const float* z, const float* mean, const float* rstd,
+extern "C" int a3t_bn_act_bwd_a(const void* dy, int dy_dtype, const float* z, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, float* dbn, double* sums, int M, int C,
                                 int act, void* stream) {
     int rpb = 256;
     dim3 grid((C + 63) / 64, (M + rpb - 1) / rpb);
-    hipLaunchKernelGGL(bn_act_bwd_a_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, z, mean, rstd, gamma, beta, dbn,
-                       sums, M, C, act, rpb);
+    hipLaunchKernelGGL(bn_act_bwd_a_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, z, mean, rstd, gamma, beta,
+                       dbn, sums, M, C, act, rpb);
     return (int)hipGetLastError();
 }
 

@@ -5,14 +5,22 @@ nn.Modules (ESPnetMLMEncAsDecoderModel._forward, espnet2/tts/sedit/sedit_model.p
 MLMEncoder/MLMDecoder conformer/encoder.py:522-614, EncoderLayer conformer/encoder_layer.py:80-180):
 an explicit, allocation-free schedule of liba3t_hip launches on the current HIP stream, with a
 hand-derived backward pass.  torch supplies device buffers only.
+
+Two numeric modes:
+  compute="f32"  : everything fp32, GEMMs on the exact-fp32 MFMA  (parity path, 1e-4)
+  compute="bf16" : tensors that feed GEMMs are stored in bf16 (LayerNorm outputs, FFN hidden, q/k/v,
+                   attention probabilities, ...), weights are cast to a bf16 shadow once per step,
+                   GEMMs run on the bf16 MFMA with fp32 accumulation; the residual stream, all
+                   normalisation statistics, softmax, loss, gradients of parameters and the
+                   optimizer stay fp32  (throughput path, 1e-2)
 """
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 
 from . import ops
-from ._lib import ACC_ADD, ACC_ATOMIC, ACC_STORE, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
+from ._lib import ACC_ATOMIC, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
 from .config import A3TConfig
 from .params import ParamStore
 
@@ -57,36 +65,55 @@ class MLMEngine:
         self.dev = store.device
         self.ws = Workspace(self.dev)
         self.bf16 = (compute == "bf16")
+        self.adt = torch.bfloat16 if self.bf16 else torch.float32   # storage of GEMM-operand activations
+        self.cmp = BF16 if self.bf16 else F32
         self.training = training
         self.pe = legacy_pe_table(cfg).to(self.dev)
         self.sv = {}
         self.scratch64 = torch.zeros(4 * max(cfg.ff, 3 * cfg.adim, cfg.postnet_chans, 64), dtype=torch.float64,
                                      device=self.dev)
         self.bn_momentum = 0.1
+        if self.bf16:
+            for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
+                         ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
+                if v % 8:
+                    raise ValueError(f"compute='bf16' needs {n} % 8 == 0 (16-byte DMA granules), got {v}")
+            self.flat16 = torch.zeros(store.total, dtype=torch.bfloat16, device=self.dev)
+            self.p16 = {k: self.flat16[o:o + math.prod(s)].view(s) for k, (o, s) in store.offsets.items()}
 
     # ------------------------------------------------------------------ helpers
-    def _cmp(self, *dims):
-        if self.bf16 and all(d % 8 == 0 for d in dims):
-            return BF16
-        return F32
+    def W(self, name):
+        """GEMM-operand view of a parameter (bf16 shadow in bf16 mode)."""
+        return self.p16[name] if self.bf16 else self.store.p[name]
 
-    def _ln_fwd(self, tag, x, pre, eps=1e-12):
+    def refresh_weights(self):
+        if self.bf16:
+            ops.cast_bf16(self.store.flat, self.flat16)
+
+    def _act(self, name, shape):
+        return self.ws.get(name, shape, self.adt)
+
+    def _ln_fwd(self, tag, x, pre, eps=1e-12, out_dtype=None):
         p = self.store.p
         M, D = x.shape
-        y = self.ws.get(tag + ".y", (M, D))
+        y = self.ws.get(tag + ".y", (M, D), out_dtype or self.adt)
         mean = self.ws.get(tag + ".mean", (M,))
         rstd = self.ws.get(tag + ".rstd", (M,))
         ops.layernorm_fwd(x, p[pre + ".g"], p[pre + ".b"], y, mean, rstd, eps)
         self.sv[tag] = (x, y, mean, rstd)
         return y
 
-    def _ln_bwd(self, tag, dy, pre, dres, dx):
+    def _ln_bwd(self, tag, dy, pre, dres, dx, dx16=None):
         p, g = self.store.p, self.store.g
         x, _, mean, rstd = self.sv[tag]
-        ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"])
+        ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=dx16)
 
     def _bias_grad(self, dy, gb, scale=1.0):
         ops.bias_grad(dy, gb, self.scratch64, scale)
+
+    def _g16(self, g):
+        """bf16 companion of the residual-stream gradient (written by the LayerNorm backward)."""
+        return self.ws.get("grad.x16", tuple(g.shape), torch.bfloat16) if self.bf16 else None
 
     # ------------------------------------------------------------------ FFN (MultiLayeredConv1d)
     def _ffn_fwd(self, tag, pre, x, T):
@@ -94,30 +121,31 @@ class MLMEngine:
         M = x.shape[0]
         pad = (c.ff_kernel - 1) // 2
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
-        h = self.ws.get(tag + ".h", (M, c.ff))
-        cmp = self._cmp(c.adim, c.ff)
-        ops.conv_fwd(y, p[pre + ".w1"], h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=cmp)
+        h = self._act(tag + ".h", (M, c.ff))
+        ops.conv_fwd(y, self.W(pre + ".w1"), h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=self.cmp)
         xo = self.ws.get(tag + ".xo", (M, c.adim))
-        ops.conv_fwd(h, p[pre + ".w2"], xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=cmp)
+        ops.conv_fwd(h, self.W(pre + ".w2"), xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=self.cmp)
         self.sv[tag] = (y, h)
         return xo
 
     def _ffn_bwd(self, tag, pre, g, T):
-        """g = grad wrt the sub-layer output (residual stream); returns grad wrt its input (in place)."""
+        """g = grad wrt the sub-layer output (fp32 residual stream, updated in place to the grad wrt
+        the sub-layer input); in bf16 mode grad.x16 holds the same values in bf16 on entry and exit."""
         p, gr, c = self.store.p, self.store.g, self.c
         y, h = self.sv[tag]
         M = g.shape[0]
         pad = (c.ff_kernel - 1) // 2
-        cmp = self._cmp(c.adim, c.ff)
-        dh = self.ws.get("tmp.dh", (M, c.ff))
-        ops.conv_bwd_data(g, p[pre + ".w2"], dh, T, pad, S=h, alpha=0.5, compute=cmp)
-        ops.conv_bwd_weight(g, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=cmp)
+        g16 = self._g16(g)
+        ga = g16 if self.bf16 else g
+        dh = self._act("tmp.dh", (M, c.ff))
+        ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=0.5, compute=self.cmp)
+        ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp)
         self._bias_grad(g, gr[pre + ".b2"], 0.5)
-        dy = self.ws.get("tmp.dy", (M, c.adim))
-        ops.conv_bwd_data(dh, p[pre + ".w1"], dy, T, pad, compute=cmp)
-        ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=cmp)
+        dy = self._act("tmp.dy", (M, c.adim))
+        ops.conv_bwd_data(dh, self.W(pre + ".w1"), dy, T, pad, compute=self.cmp)
+        ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp)
         self._bias_grad(dh, gr[pre + ".b1"])
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16)
         return g
 
     # ------------------------------------------------------------------ rel-pos self-attention
@@ -125,33 +153,32 @@ class MLMEngine:
         p, c = self.store.p, self.c
         d, H, dk = c.adim, c.heads, c.dk
         M = B * T
+        cmp = self.cmp
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
-        cmp = self._cmp(d)
-        cat = self._cmp(d, dk, T)
-        qkv = self.ws.get(tag + ".qkv", (M, 3 * d))
-        ops.linear_fwd(y, p[pre + ".wqkv"], qkv, bias=p[pre + ".bqkv"], compute=cmp)
-        qu = self.ws.get(tag + ".qu", (M, d))
-        qv = self.ws.get(tag + ".qv", (M, d))
+        qkv = self._act(tag + ".qkv", (M, 3 * d))
+        ops.linear_fwd(y, self.W(pre + ".wqkv"), qkv, bias=p[pre + ".bqkv"], compute=cmp)
+        qu = self._act(tag + ".qu", (M, d))
+        qv = self._act(tag + ".qv", (M, d))
         ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
-        P = self.ws.get(tag + ".P", (T, d))
-        ops.linear_fwd(pos, p[pre + ".wpos"], P, compute=cmp)
+        P = self._act(tag + ".P", (T, d))
+        ops.linear_fwd(pos, self.W(pre + ".wpos"), P, compute=cmp)
         ac = self.ws.get("tmp.ac", (B, H, T, T))
         bd = self.ws.get("tmp.bd", (B, H, T, T))
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
         # ac[b,h] = (q+u) k^T ; bd[b,h] = (q+v) P_h^T   (attention.py:190-203)
         ops.gemm(qu, kk, ac, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
-                 b_bs=(T * 3 * d, dk), c_bs=(H * T * T, T * T), compute=cat)
+                 b_bs=(T * 3 * d, dk), c_bs=(H * T * T, T * T), compute=cmp)
         ops.gemm(qv, P, bd, T, T, dk, d, 1, d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(0, dk),
-                 c_bs=(H * T * T, T * T), compute=cat)
-        probs = self.ws.get(tag + ".probs", (B, H, T, T))
+                 c_bs=(H * T * T, T * T), compute=cmp)
+        probs = self._act(tag + ".probs", (B, H, T, T))
         ops.relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, 1.0 / math.sqrt(dk))
-        ctx = self.ws.get(tag + ".ctx", (M, d))
+        ctx = self._act(tag + ".ctx", (M, d))
         # ctx[b,:,h,:] = probs[b,h] V[b,h]
         ops.gemm(probs, vv, ctx, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=(H * T * T, T * T),
-                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cat)
+                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp)
         xo = self.ws.get(tag + ".xo", (M, d))
-        ops.linear_fwd(ctx, p[pre + ".wo"], xo, bias=p[pre + ".bo"], R=x, compute=cmp)
+        ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp)
         self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos)
         return xo
 
@@ -159,51 +186,61 @@ class MLMEngine:
         p, gr, c = self.store.p, self.store.g, self.c
         d, H, dk = c.adim, c.heads, c.dk
         M = B * T
+        cmp = self.cmp
         y, qkv, qu, qv, P, probs, ctx, pos = self.sv[tag]
-        cmp = self._cmp(d)
-        cat = self._cmp(d, dk, T)
         scale = 1.0 / math.sqrt(dk)
-        dctx = self.ws.get("tmp.dctx", (M, d))
-        ops.linear_bwd_data(g, p[pre + ".wo"], dctx, compute=cmp)
-        ops.linear_bwd_weight(g, ctx, gr[pre + ".wo"], compute=cmp)
+        g16 = self._g16(g)
+        ga = g16 if self.bf16 else g
+        dctx = self._act("tmp.dctx", (M, d))
+        ops.linear_bwd_data(ga, self.W(pre + ".wo"), dctx, compute=cmp)
+        ops.linear_bwd_weight(ga, ctx, gr[pre + ".wo"], compute=cmp)
         self._bias_grad(g, gr[pre + ".bo"])
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
-        dqkv = self.ws.get("tmp.dqkv", (M, 3 * d))
+        dqkv = self._act("tmp.dqkv", (M, 3 * d))
         dkk = dqkv.view(-1)[d:]
         dvv = dqkv.view(-1)[2 * d:]
-        ds = self.ws.get("tmp.ac", (B, H, T, T))      # reuse score buffers
-        dbd = self.ws.get("tmp.bd", (B, H, T, T))
+        dpr = self.ws.get("tmp.ac", (B, H, T, T))      # reuse the fp32 score buffers
         zb = (H * T * T, T * T)
         # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
-        ops.gemm(dctx, vv, ds, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
-                 b_bs=(T * 3 * d, dk), c_bs=zb, compute=cat)
+        ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
+                 b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
         ops.gemm(probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cat)
-        ops.relpos_softmax_bwd(probs, ds, dbd, B, H, T, scale)
-        dqu = self.ws.get("tmp.dqu", (M, d))
-        dqv = self.ws.get("tmp.dqv", (M, d))
+                 b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp)
+        if self.bf16:
+            ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
+            dbd = self.ws.get("tmp.dbd16", (B, H, T, T), torch.bfloat16)
+        else:
+            ds = dpr
+            dbd = self.ws.get("tmp.bd", (B, H, T, T))
+        ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale)
+        dqu = self._act("tmp.dqu", (M, d))
+        dqv = self._act("tmp.dqv", (M, d))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
         ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cat)
+                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp)
         ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                 c_bs=(T * 3 * d, dk), compute=cat)
+                 c_bs=(T * 3 * d, dk), compute=cmp)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
-                 c_bs=(T * d, dk), compute=cat)
+                 c_bs=(T * d, dk), compute=cmp)
         dP = self.ws.get("tmp.dP", (T, d), zero=True)
         ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                 c_bs=(0, dk), acc=ACC_ATOMIC, compute=cat)
+                 c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
+        if self.bf16:
+            dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
+            ops.cast_bf16(dP, dP16)
+            dP = dP16
         ops.linear_bwd_weight(dP, pos, gr[pre + ".wpos"], compute=cmp)
         ops.add_pos_bias_bwd(dqu, dqv, dqkv)
         self._bias_grad(dqu, gr[pre + ".u"])
         self._bias_grad(dqv, gr[pre + ".v"])
-        dy = self.ws.get("tmp.dy", (M, d))
-        ops.linear_bwd_data(dqkv, p[pre + ".wqkv"], dy, compute=cmp)
+        dy = self._act("tmp.dy", (M, d))
+        ops.linear_bwd_data(dqkv, self.W(pre + ".wqkv"), dy, compute=cmp)
         ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp)
         self._bias_grad(dqkv, gr[pre + ".bqkv"])
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16)
         return g
 
     # ------------------------------------------------------------------ convolution module
@@ -234,38 +271,40 @@ class MLMEngine:
     def _conv_fwd(self, tag, pre, x, T):
         p, c = self.store.p, self.c
         M, d = x.shape
-        cmp = self._cmp(d)
+        cmp = self.cmp
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
-        g2 = self.ws.get(tag + ".g", (M, 2 * d))
-        ops.linear_fwd(y, p[pre + ".pw1"], g2, bias=p[pre + ".pb1"], compute=cmp)
-        glu = self.ws.get(tag + ".glu", (M, d))
+        g2 = self._act(tag + ".g", (M, 2 * d))
+        ops.linear_fwd(y, self.W(pre + ".pw1"), g2, bias=p[pre + ".pb1"], compute=cmp)
+        glu = self._act(tag + ".glu", (M, d))
         z = self.ws.get(tag + ".z", (M, d))
         ops.glu_dwconv_fwd(g2, p[pre + ".dw"], p[pre + ".db"], glu, z, T)
-        s = self.ws.get(tag + ".s", (M, d))
+        s = self._act(tag + ".s", (M, d))
         self._bn_fwd(tag, z, pre + ".bn", pre + ".bn", ACT_SWISH, s)
         xo = self.ws.get(tag + ".xo", (M, d))
-        ops.linear_fwd(s, p[pre + ".pw2"], xo, bias=p[pre + ".pb2"], R=x, compute=cmp)
+        ops.linear_fwd(s, self.W(pre + ".pw2"), xo, bias=p[pre + ".pb2"], R=x, compute=cmp)
         self.sv[tag] = (y, g2, glu, s)
         return xo
 
     def _conv_bwd(self, tag, pre, g, T):
         p, gr, c = self.store.p, self.store.g, self.c
         M, d = g.shape
-        cmp = self._cmp(d)
+        cmp = self.cmp
         y, g2, glu, s = self.sv[tag]
+        g16 = self._g16(g)
+        ga = g16 if self.bf16 else g
         ds = self.ws.get("tmp.ds", (M, d))
-        ops.linear_bwd_data(g, p[pre + ".pw2"], ds, compute=cmp)
-        ops.linear_bwd_weight(g, s, gr[pre + ".pw2"], compute=cmp)
+        ops.linear_bwd_data(ga, self.W(pre + ".pw2"), ds, compute=cmp)
+        ops.linear_bwd_weight(ga, s, gr[pre + ".pw2"], compute=cmp)
         self._bias_grad(g, gr[pre + ".pb2"])
         dz = self.ws.get("tmp.dz", (M, d))
         self._bn_bwd(tag, ds, pre + ".bn", ACT_SWISH, dz)
-        dg = self.ws.get("tmp.dg", (M, 2 * d))
+        dg = self._act("tmp.dg", (M, 2 * d))
         ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T)
-        dy = self.ws.get("tmp.dy", (M, d))
-        ops.linear_bwd_data(dg, p[pre + ".pw1"], dy, compute=cmp)
+        dy = self._act("tmp.dy", (M, d))
+        ops.linear_bwd_data(dg, self.W(pre + ".pw1"), dy, compute=cmp)
         ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp)
         self._bias_grad(dg, gr[pre + ".pb1"])
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16)
         return g
 
     # ------------------------------------------------------------------ one Conformer block
@@ -274,10 +313,10 @@ class MLMEngine:
         x = self._mha_fwd(pre + ".mha", pre + ".mha", x, pos, keymask, B, T)
         x = self._conv_fwd(pre + ".cnv", pre + ".cnv", x, T)
         x = self._ffn_fwd(pre + ".ff", pre + ".ff", x, T)
-        return self._ln_fwd(pre + ".fin", x, pre + ".fin.ln")
+        return self._ln_fwd(pre + ".fin", x, pre + ".fin.ln", out_dtype=torch.float32)
 
     def block_bwd(self, pre, g, B, T):
-        self._ln_bwd(pre + ".fin", g, pre + ".fin.ln", None, g)
+        self._ln_bwd(pre + ".fin", g, pre + ".fin.ln", None, g, self._g16(g))
         self._ffn_bwd(pre + ".ff", pre + ".ff", g, T)
         self._conv_bwd(pre + ".cnv", pre + ".cnv", g, T)
         self._mha_bwd(pre + ".mha", pre + ".mha", g, B, T)
@@ -293,7 +332,10 @@ class MLMEngine:
         Tp = text.shape[1]
         T = Tm + Tp
         d = c.adim
+        if self.bf16 and (T % 8 or Tm % 8):
+            raise ValueError(f"compute='bf16' needs T_mel and T_mel+T_phn to be multiples of 8, got {Tm}, {T}")
         self.dims = (B, Tm, Tp, T)
+        self.refresh_weights()
         masked = batch["masked_position"].contiguous().view(torch.uint8)
         keymask = ws.get("keymask", (B, T), torch.uint8)
         keymask[:, :Tm].copy_(batch["speech_mask"].reshape(B, Tm).view(torch.uint8))
@@ -302,46 +344,49 @@ class MLMEngine:
         tpos = batch["text_segment_pos"].contiguous()
         speech2 = speech.view(B * Tm, idim)
         # --- encoder prologue (conformer/encoder.py:522-553)
-        xm = ws.get("emb.xm", (B * Tm, idim))
+        xm = self._act("emb.xm", (B * Tm, idim))
         ops.mask_fill(speech2, masked, p["mask_feature"], xm)
         e0 = ws.get("emb.e0", (B * Tm, d))
-        ops.linear_fwd(xm, p["emb.w"], e0, bias=p["emb.b"], compute=self._cmp(idim, d))
-        e = self._ln_fwd("emb.ln", e0, "emb.ln", eps=1e-5)
+        ops.linear_fwd(xm, self.W("emb.w"), e0, bias=p["emb.b"], compute=self.cmp)
+        e = self._ln_fwd("emb.ln", e0, "emb.ln", eps=1e-5, out_dtype=torch.float32)
         xs = ws.get("emb.xs", (B * T, d))
         xscale = math.sqrt(d)
         ops.embed_finish_fwd(e, p["temb"], p["seg"], text, spos, tpos, xs, B, Tm, Tp, d, xscale)
-        pos_e = ws.get("pos.enc", (T, d))
+        pos_e = self._act("pos.enc", (T, d))
         pos_e[:Tm].copy_(self.pe[:Tm])
         pos_e[Tm:].copy_(self.pe[:Tp])
-        pos_d = ws.get("pos.dec", (T, d))
+        pos_d = self._act("pos.dec", (T, d))
         pos_d.copy_(self.pe[:T])
         self.sv["embed"] = (xm, e, text, spos, tpos, masked, speech2)
         x = xs
         for i in range(c.enc_blocks):
             x = self.block_fwd(f"enc.{i}", x, pos_e, keymask, B, T)
-        x = self._ln_fwd("enc.after", x, "enc.after")
+        x = self._ln_fwd("enc.after", x, "enc.after", out_dtype=torch.float32)
         # --- decoder (conformer/encoder.py:568-614): x*sqrt(d), contiguous rel-pos table
         xd = ws.get("dec.in", (B * T, d))
         ops.scale(x, xd, xscale)
         x = xd
         for i in range(c.dec_blocks):
             x = self.block_fwd(f"dec.{i}", x, pos_d, keymask, B, T)
-        x = self._ln_fwd("dec.after", x, "dec.after")
+        x = self._ln_fwd("dec.after", x, "dec.after", out_dtype=torch.float32)
         # --- head: slice speech frames, sfc, postnet, loss (sedit_model.py:363-372,320-340)
-        hs = ws.get("head.hs", (B * Tm, d))
+        hs = self._act("head.hs", (B * Tm, d))
         ops.slice_rows(x, hs, B, T, Tm, d)
         before = ws.get("head.before", (B * Tm, c.odim))
-        ops.linear_fwd(hs, p["sfc.w"], before, bias=p["sfc.b"], compute=self._cmp(d, c.odim))
+        ops.linear_fwd(hs, self.W("sfc.w"), before, bias=p["sfc.b"], compute=self.cmp)
         y = before
+        if self.bf16 and c.postnet_layers > 0:
+            y = ws.get("head.before16", (B * Tm, c.odim), torch.bfloat16)
+            ops.cast_bf16(before, y)
         pad = (c.postnet_filts - 1) // 2
         for l in range(c.postnet_layers):
-            W = p[f"post.{l}.w"]
+            W = self.W(f"post.{l}.w")
             oc = W.shape[0]
+            last = (l == c.postnet_layers - 1)
             z = ws.get(f"post.{l}.z", (B * Tm, oc))
-            ops.conv_fwd(y, W, z, Tm, pad, compute=self._cmp(y.shape[1], oc))
-            o = ws.get(f"post.{l}.o", (B * Tm, oc))
-            act = ACT_TANH if l != c.postnet_layers - 1 else ACT_NONE
-            self._bn_fwd(f"post.{l}", z, f"post.{l}.bn", f"post.{l}.bn", act, o)
+            ops.conv_fwd(y, W, z, Tm, pad, compute=self.cmp)
+            o = ws.get(f"post.{l}.o", (B * Tm, oc), torch.float32 if last else self.adt)
+            self._bn_fwd(f"post.{l}", z, f"post.{l}.bn", f"post.{l}.bn", ACT_NONE if last else ACT_TANH, o)
             self.sv[f"post.{l}"] = y
             y = o
         if c.postnet_layers > 0:
@@ -363,37 +408,45 @@ class MLMEngine:
         c, p, gr, ws = self.c, self.store.p, self.store.g, self.ws
         B, Tm, Tp, T = self.dims
         d = c.adim
+        cmp = self.cmp
         hs, before, after, db, da = self.sv["head"]
         pad = (c.postnet_filts - 1) // 2
         if c.postnet_layers > 0:
-            g = da                                    # grad wrt last BN output
+            g = da                                    # grad wrt last BN output (fp32)
             for l in reversed(range(c.postnet_layers)):
-                W = p[f"post.{l}.w"]
+                W = self.W(f"post.{l}.w")
                 oc = W.shape[0]
-                act = ACT_TANH if l != c.postnet_layers - 1 else ACT_NONE
+                last = (l == c.postnet_layers - 1)
                 dz = ws.get(f"tmp.post.dz{oc}", (B * Tm, oc))
-                self._bn_bwd(f"post.{l}", g, f"post.{l}.bn", act, dz)
+                self._bn_bwd(f"post.{l}", g, f"post.{l}.bn", ACT_NONE if last else ACT_TANH, dz)
+                if self.bf16:
+                    dz16 = ws.get(f"tmp.post.dz16.{oc}", (B * Tm, oc), torch.bfloat16)
+                    ops.cast_bf16(dz, dz16)
+                    dz = dz16
                 yin = self.sv[f"post.{l}"]
                 ic = yin.shape[1]
-                cmp = self._cmp(ic, oc)
                 ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=cmp)
                 gi = ws.get(f"tmp.post.g{l % 2}.{ic}", (B * Tm, ic))
                 ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=cmp)
                 g = gi
             ops.axpy(da, db, 1.0)                     # after = before + postnet(before)
             ops.axpy(g, db, 1.0)
+        dba = db
+        if self.bf16:
+            dba = ws.get("tmp.db16", (B * Tm, c.odim), torch.bfloat16)
+            ops.cast_bf16(db, dba)
         dhs = ws.get("tmp.dhs", (B * Tm, d))
-        cmp = self._cmp(d, c.odim)
-        ops.linear_bwd_data(db, p["sfc.w"], dhs, compute=cmp)
-        ops.linear_bwd_weight(db, hs, gr["sfc.w"], compute=cmp)
+        ops.linear_bwd_data(dba, self.W("sfc.w"), dhs, compute=cmp)
+        ops.linear_bwd_weight(dba, hs, gr["sfc.w"], compute=cmp)
         self._bias_grad(db, gr["sfc.b"])
         g = ws.get("grad.x", (B * T, d), zero=True)
+        g16 = self._g16(g)
         ops.slice_rows(g, dhs, B, T, Tm, d, reverse_add=True)
-        self._ln_bwd("dec.after", g, "dec.after", None, g)
+        self._ln_bwd("dec.after", g, "dec.after", None, g, g16)
         for i in reversed(range(c.dec_blocks)):
             self.block_bwd(f"dec.{i}", g, B, T)
         ops.scale(g, g, math.sqrt(d))
-        self._ln_bwd("enc.after", g, "enc.after", None, g)
+        self._ln_bwd("enc.after", g, "enc.after", None, g, g16)
         for i in reversed(range(c.enc_blocks)):
             self.block_bwd(f"enc.{i}", g, B, T)
         # --- prologue backward
@@ -402,12 +455,13 @@ class MLMEngine:
         ops.embed_finish_bwd(g, e, text, spos, tpos, de, gr["temb"], gr["seg"], B, Tm, Tp, d, c.vocab, c.seg_table,
                              math.sqrt(d))
         de0 = ws.get("tmp.de0", (B * Tm, d))
-        self._ln_bwd("emb.ln", de, "emb.ln", None, de0)
-        cmp = self._cmp(c.idim, d)
-        ops.linear_bwd_weight(de0, xm, gr["emb.w"], compute=cmp)
+        de16 = ws.get("tmp.de016", (B * Tm, d), torch.bfloat16) if self.bf16 else None
+        self._ln_bwd("emb.ln", de, "emb.ln", None, de0, de16)
+        dea = de16 if self.bf16 else de0
+        ops.linear_bwd_weight(dea, xm, gr["emb.w"], compute=cmp)
         self._bias_grad(de0, gr["emb.b"])
         dxm = ws.get("tmp.dxm", (B * Tm, c.idim))
-        ops.linear_bwd_data(de0, p["emb.w"], dxm, compute=cmp)
+        ops.linear_bwd_data(dea, self.W("emb.w"), dxm, compute=cmp)
         s64 = self.scratch64[:c.idim]
         s64.zero_()
         ops.col_reduce(dxm, s64, rowmask=masked.view(-1), mode=0)

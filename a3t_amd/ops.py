@@ -21,6 +21,8 @@ def _kernel_name(compute, a_cs, b_cs, A, B):
     ak, bk = "true" if a_cs == 1 else "false", "true" if b_cs == 1 else "false"
     if compute == F32:
         return f"gemm_f32_kernel<{ak}, {bk}, *>"
+    if A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16:
+        return f"gemm_bf16_glds_kernel<{0 if (a_cs == 1 and b_cs == 1) else (1 if a_cs == 1 else 2)}>"
     return f"gemm_bf16_kernel<{tn[A.dtype]}, {tn[B.dtype]}, {ak}, {bk}>"
 
 
@@ -61,6 +63,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.taps, d.pad, d.dil, d.Tseq, d.kshift = taps, pad, dil, Tseq, kshift
     d.alpha, d.act, d.accumulate, d.splitk = alpha, act, acc, splitk
     d.a_dtype, d.b_dtype, d.c_dtype, d.compute = _dt(A), _dt(B), _dt(C), compute
+    d.s_dtype = _dt(S) if S is not None else F32
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -134,21 +137,25 @@ def conv_bwd_weight(dy, x, dWk, Tseq, pad, dil=1, alpha=1.0, compute=F32):
 
 
 # ---- row / column kernels --------------------------------------------------------------------
+def _dto(t):
+    return _dt(t) if t is not None else F32
+
+
 def layernorm_fwd(x, g, b, y, mean, rstd, eps):
     M, D = x.shape
-    L.check(L.load().a3t_layernorm_fwd(_ptr(x), _ptr(g), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), M, D, eps,
+    L.check(L.load().a3t_layernorm_fwd(_ptr(x), _ptr(g), _ptr(b), _ptr(y), _dt(y), _ptr(mean), _ptr(rstd), M, D, eps,
                                        _stream()), "ln_fwd")
 
 
-def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db):
+def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, dx16=None):
     M, D = x.shape
-    L.check(L.load().a3t_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres), _ptr(dx),
-                                       _ptr(dg), _ptr(db), M, D, _stream()), "ln_bwd")
+    L.check(L.load().a3t_layernorm_bwd(_ptr(dy), _dt(dy), _ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres),
+                                       _ptr(dx), _ptr(dx16), _ptr(dg), _ptr(db), M, D, _stream()), "ln_bwd")
 
 
 def col_reduce(x, out0, out1=None, y=None, rowmask=None, mode=0, ld=None):
     M, C = x.shape
-    L.check(L.load().a3t_col_reduce(_ptr(x), _ptr(y), _ptr(rowmask), _ptr(out0), _ptr(out1), M, C,
+    L.check(L.load().a3t_col_reduce(_ptr(x), _dt(x), _ptr(y), _ptr(rowmask), _ptr(out0), _ptr(out1), M, C,
                                     ld if ld is not None else x.stride(0), mode, _stream()), "col_reduce")
 
 
@@ -168,56 +175,60 @@ def bias_grad(dy, dbias, scratch64, scale=1.0):
 def bn_act_fwd(z, stats, g, b, rmean, rvar, mean_out, rstd_out, y, eps, momentum, training, act):
     M, C = z.shape
     L.check(L.load().a3t_bn_act_fwd(_ptr(z), _ptr(stats), _ptr(g), _ptr(b), _ptr(rmean), _ptr(rvar), _ptr(mean_out),
-                                    _ptr(rstd_out), _ptr(y), M, C, eps, momentum, int(training), act, _stream()),
-            "bn_act_fwd")
+                                    _ptr(rstd_out), _ptr(y), _dt(y), M, C, eps, momentum, int(training), act,
+                                    _stream()), "bn_act_fwd")
 
 
 def bn_act_bwd(dy, z, mean, rstd, g, b, dbn, sums, dz, dg, db, training, act):
     M, C = z.shape
     lib = L.load()
     sums.zero_()
-    L.check(lib.a3t_bn_act_bwd_a(_ptr(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(dbn), _ptr(sums),
-                                 M, C, act, _stream()), "bn_bwd_a")
+    L.check(lib.a3t_bn_act_bwd_a(_ptr(dy), _dt(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(dbn),
+                                 _ptr(sums), M, C, act, _stream()), "bn_bwd_a")
     L.check(lib.a3t_bn_act_bwd_b(_ptr(dbn), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(sums), _ptr(dz), _ptr(dg),
                                  _ptr(db), M, C, int(training), _stream()), "bn_bwd_b")
 
 
 def glu_dwconv_fwd(g, wdw, bdw, glu, z, Tseq):
     M, C = glu.shape
-    L.check(L.load().a3t_glu_dwconv_fwd(_ptr(g), _ptr(wdw), _ptr(bdw), _ptr(glu), _ptr(z), M, C, wdw.shape[1], Tseq,
-                                        _stream()), "glu_dwconv_fwd")
+    L.check(L.load().a3t_glu_dwconv_fwd(_ptr(g), _dt(g), _ptr(wdw), _ptr(bdw), _ptr(glu), _dt(glu), _ptr(z), M, C,
+                                        wdw.shape[1], Tseq, _stream()), "glu_dwconv_fwd")
 
 
 def glu_dwconv_bwd(dz, g, glu, wdw, dg, dwdw, dbdw, Tseq):
     M, C = glu.shape
-    L.check(L.load().a3t_glu_dwconv_bwd(_ptr(dz), _ptr(g), _ptr(glu), _ptr(wdw), _ptr(dg), _ptr(dwdw), _ptr(dbdw), M,
-                                        C, wdw.shape[1], Tseq, _stream()), "glu_dwconv_bwd")
+    L.check(L.load().a3t_glu_dwconv_bwd(_ptr(dz), _ptr(g), _dt(g), _ptr(glu), _dt(glu), _ptr(wdw), _ptr(dg), _dt(dg),
+                                        _ptr(dwdw), _ptr(dbdw), M, C, wdw.shape[1], Tseq, _stream()),
+            "glu_dwconv_bwd")
 
 
 def add_pos_bias(qkv, u, v, qu, qv):
     M, d = qu.shape
-    L.check(L.load().a3t_add_pos_bias(_ptr(qkv), _ptr(u), _ptr(v), _ptr(qu), _ptr(qv), M, d, _stream()), "pos_bias")
+    L.check(L.load().a3t_add_pos_bias(_ptr(qkv), _ptr(u), _ptr(v), _ptr(qu), _ptr(qv), _dt(qkv), M, d, _stream()),
+            "pos_bias")
 
 
 def add_pos_bias_bwd(dqu, dqv, dqkv):
     M, d = dqu.shape
-    L.check(L.load().a3t_add_pos_bias_bwd(_ptr(dqu), _ptr(dqv), _ptr(dqkv), M, d, _stream()), "pos_bias_bwd")
+    L.check(L.load().a3t_add_pos_bias_bwd(_ptr(dqu), _ptr(dqv), _ptr(dqkv), _dt(dqu), M, d, _stream()),
+            "pos_bias_bwd")
 
 
 def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale):
-    L.check(L.load().a3t_relpos_softmax_fwd(_ptr(ac), _ptr(bd), _ptr(keymask), _ptr(probs), B, H, T, T * T, T * T,
-                                            T * T, scale, _stream()), "softmax_fwd")
+    L.check(L.load().a3t_relpos_softmax_fwd(_ptr(ac), _ptr(bd), _ptr(keymask), _ptr(probs), _dt(probs), B, H, T,
+                                            T * T, T * T, T * T, scale, _stream()), "softmax_fwd")
 
 
-def relpos_softmax_bwd(probs, dprobs, dbd, B, H, T, scale):
-    L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _ptr(dprobs), _ptr(dbd), B, H, T, T * T, T * T, T * T, scale,
-                                            _stream()), "softmax_bwd")
+def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale):
+    """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place)."""
+    L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _dt(probs), _ptr(dprobs), _ptr(ds), _ptr(dbd), _dt(dbd), B, H,
+                                            T, T * T, T * T, T * T, scale, _stream()), "softmax_bwd")
 
 
 def mask_fill(speech, masked, mask_feature, out):
     M, C = out.shape
-    L.check(L.load().a3t_mask_fill(_ptr(speech), _ptr(masked), _ptr(mask_feature), _ptr(out), M, C, _stream()),
-            "mask_fill")
+    L.check(L.load().a3t_mask_fill(_ptr(speech), _ptr(masked), _ptr(mask_feature), _ptr(out), _dt(out), M, C,
+                                   _stream()), "mask_fill")
 
 
 def embed_finish_fwd(e, emb, seg, text, spos, tpos, xs, B, Tm, Tp, D, xscale):
@@ -239,8 +250,12 @@ def axpy(x, y, a=1.0):
     L.check(L.load().a3t_axpy(_ptr(x), _ptr(y), x.numel(), a, _stream()), "axpy")
 
 
+def cast_bf16(x, y):
+    L.check(L.load().a3t_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "cast_bf16")
+
+
 def slice_rows(x, y, B, T, Tm, D, reverse_add=False):
-    L.check(L.load().a3t_slice_rows(_ptr(x), _ptr(y), B, T, Tm, D, int(reverse_add), _stream()), "slice_rows")
+    L.check(L.load().a3t_slice_rows(_ptr(x), _ptr(y), _dt(y), B, T, Tm, D, int(reverse_add), _stream()), "slice_rows")
 
 
 def mlm_loss(before, after, target, masked, loss_out, d_before, d_after, scratch, l2=False, gscale=1.0):

@@ -76,26 +76,29 @@ typedef struct a3t_gemm_desc {
     int32_t a_dtype, b_dtype, c_dtype; /* A3T_F32 | A3T_BF16 (storage) */
     int32_t compute;                   /* A3T_F32: v_mfma_f32_32x32x2_f32 (exact f32);
                                           A3T_BF16: v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+    int32_t s_dtype;                   /* storage type of S (A3T_F32 | A3T_BF16) */
+    int32_t reserved;
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
 
 /* LayerNorm over the last dim (transformer/layer_norm.py:12-42 eps=1e-12; torch.nn.LayerNorm
  * eps=1e-5 in the speech embed, conformer/encoder.py:404).  mean/rstd: [M] saved for backward. */
-int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                      float* rstd, int M, int D, float eps, void* stream);
-/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta are ACCUMULATED (atomicAdd). */
-int a3t_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                      const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                      int M, int D, void* stream);
+int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
+                      float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* dx = (dres ? dres : 0) + LN'(dy) (dx may alias dres); dx_bf16: optional bf16 copy of dx for the
+ * GEMMs that consume it; dgamma/dbeta are ACCUMULATED (atomicAdd). */
+int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
+                      const float* rstd, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                      float* dbeta, int M, int D, void* stream);
 
 /* Column reductions over rows of x[M][C] (row stride ld), accumulated with atomics:
  *   mode 0: out0[c] += sum x            (bias gradients)
  *   mode 1: out0 += sum x, out1 += sum x*x      (BatchNorm batch statistics)
  *   mode 2: out0 += sum x, out1 += sum x*y      (BatchNorm backward)
  * rowmask (optional, uint8 [M]): only rows with rowmask!=0 contribute. out are double[C]. */
-int a3t_col_reduce(const float* x, const float* y, const uint8_t* rowmask, double* out0, double* out1,
-                   int M, int C, int64_t ld, int mode, void* stream);
+int a3t_col_reduce(const void* x, int x_dtype, const float* y, const uint8_t* rowmask, double* out0,
+                   double* out1, int M, int C, int64_t ld, int mode, void* stream);
 int a3t_f64_to_f32_add(const double* src, float* dst, int n, float scale, void* stream);
 
 /* BatchNorm1d(+activation) over channels-last [M][C] (conformer/convolution.py:74,
@@ -103,10 +106,10 @@ int a3t_f64_to_f32_add(const double* src, float* dst, int n, float scale, void* 
  * training; running_mean/var updated in place when momentum > 0 (unbiased var).
  * saves mean/rstd (float[C]) for backward. */
 int a3t_bn_act_fwd(const float* z, const double* stats, const float* gamma, const float* beta,
-                   float* running_mean, float* running_var, float* mean_out, float* rstd_out, float* y,
-                   int M, int C, float eps, float momentum, int training, int act, void* stream);
+                   float* running_mean, float* running_var, float* mean_out, float* rstd_out, void* y,
+                   int y_dtype, int M, int C, float eps, float momentum, int training, int act, void* stream);
 /* step A: dbn = dy * act'(bn) written to dbn; sums += (sum dbn, sum dbn*zhat) (double[2][C]) */
-int a3t_bn_act_bwd_a(const float* dy, const float* z, const float* mean, const float* rstd,
+int a3t_bn_act_bwd_a(const void* dy, int dy_dtype, const float* z, const float* mean, const float* rstd,
                      const float* gamma, const float* beta, float* dbn, double* sums, int M, int C, int act,
                      void* stream);
 /* step B: dz = gamma*rstd*(dbn - sum0/M - zhat*sum1/M) (training) or gamma*rstd*dbn (eval);
@@ -117,34 +120,37 @@ int a3t_bn_act_bwd_b(const float* dbn, const float* z, const float* mean, const 
 
 /* GLU + depthwise Conv1d (conformer/convolution.py:66-72): g[M][2C] -> glu[M][C] (saved) and
  * z[m][c] = bdw[c] + sum_k wdw[c][k] * glu[m+k-(K-1)/2][c], zero padded per utterance (Tseq). */
-int a3t_glu_dwconv_fwd(const float* g, const float* wdw, const float* bdw, float* glu, float* z, int M,
-                       int C, int K, int Tseq, void* stream);
+int a3t_glu_dwconv_fwd(const void* g, int g_dtype, const float* wdw, const float* bdw, void* glu,
+                       int glu_dtype, float* z, int M, int C, int K, int Tseq, void* stream);
 /* dz -> dg[M][2C]; dwdw[C][K], dbdw[C] accumulated (atomics) */
-int a3t_glu_dwconv_bwd(const float* dz, const float* g, const float* glu, const float* wdw, float* dg,
-                       float* dwdw, float* dbdw, int M, int C, int K, int Tseq, void* stream);
+int a3t_glu_dwconv_bwd(const float* dz, const void* g, int g_dtype, const void* glu, int glu_dtype,
+                       const float* wdw, void* dg, int dg_dtype, float* dwdw, float* dbdw, int M, int C,
+                       int K, int Tseq, void* stream);
 
 /* Attention helpers around the batched GEMMs (transformer/attention.py:167-209).
  * qkv [M][3d] (q|k|v); qu/qv [M][d] = q + pos_bias_{u,v}. */
-int a3t_add_pos_bias(const float* qkv, const float* bias_u, const float* bias_v, float* qu, float* qv, int M,
-                     int d, void* stream);
+int a3t_add_pos_bias(const void* qkv, const float* bias_u, const float* bias_v, void* qu, void* qv, int dtype,
+                     int M, int d, void* stream);
 /* dq = dqu + dqv written into dqkv[:, 0:d] (row stride 3d) */
-int a3t_add_pos_bias_bwd(const float* dqu, const float* dqv, float* dqkv, int M, int d, void* stream);
+int a3t_add_pos_bias_bwd(const void* dqu, const void* dqv, void* dqkv, int dtype, int M, int d, void* stream);
 /* probs[z][i][j] = softmax_j( (ac[z][i][j] + shift(bd)[z][i][j]) * scale ) with key mask
  * (masked_fill(min) -> softmax -> masked_fill(0), attention.py:78-86).  bd is the COMPACT
  * (q+v)P^T matrix; the legacy rel_shift (attention.py:145-165) is applied on the fly in closed
  * form: j<=i -> bd[i][T-1-i+j], j==i+1 -> 0, j>i+1 -> bd[i+1][j-i-2].
  * z = b*H + h; keymask uint8 [B][T]; *_bs = per-z strides (elements). */
-int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, float* probs, int B,
-                           int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs, float scale,
-                           void* stream);
-/* ds = probs * (dprobs - sum_j dprobs*probs) * scale, written in place of dprobs (= gradient of
- * ac) and scattered un-shifted into dbd (= gradient of the compact bd; fully overwritten). */
-int a3t_relpos_softmax_bwd(const float* probs, float* dprobs, float* dbd, int B, int H, int T,
-                           int64_t p_bs, int64_t dp_bs, int64_t dbd_bs, float scale, void* stream);
+int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, void* probs,
+                           int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs,
+                           float scale, void* stream);
+/* ds = probs * (dprobs - sum_j dprobs*probs) * scale (= gradient of ac; may alias dprobs when fp32)
+ * and the same values scattered un-shifted into dbd (= gradient of the compact bd; fully
+ * overwritten).  ds and dbd share out_dtype and the per-z stride o_bs. */
+int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const float* dprobs, void* ds, void* dbd,
+                           int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
+                           float scale, void* stream);
 
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
-int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, float* out, int M,
-                  int C, void* stream);
+int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,
+                  int out_dtype, int M, int C, void* stream);
 /* xs[b][t] (t<Tm): relu(e[b*Tm+t]) * xscale + seg[spos];  (t>=Tm): emb[text]*xscale + seg[tpos] */
 int a3t_embed_finish_fwd(const float* e, const float* emb, const float* seg, const int64_t* text,
                          const int64_t* spos, const int64_t* tpos, float* xs, int B, int Tm, int Tp, int D,
@@ -156,7 +162,10 @@ int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, 
 int a3t_scale(const float* x, float* y, int64_t n, float s, void* stream);
 int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stream); /* y += a*x */
 /* copy rows [b][0:Tm] of x[B][T][D] into y[B][Tm][D] (sedit_model.py:363) and the reverse scatter-add */
-int a3t_slice_rows(const float* x, float* y, int B, int T, int Tm, int D, int reverse_add, void* stream);
+int a3t_slice_rows(const float* x, void* y, int y_dtype, int B, int T, int Tm, int D, int reverse_add,
+                   void* stream);
+/* fp32 -> bf16 (round to nearest even); n % 4 == 0 (the flat parameter buffer once per step) */
+int a3t_cast_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* Masked L1/L2 loss (sedit_model.py:320-340).  scratch: float[2 + nblk*2].
  * loss_out[0] = sum_masked(|before-y|+|after-y|)/(n_masked+1e-10); d_before/d_after = gradients

@@ -191,7 +191,7 @@ def test_relpos_softmax(B, H, T):
     _close(probs, pr, atol=1e-6, rtol=1e-4)
     ds = dp.to(DEV).clone()
     dbd = torch.full((B, H, T, T), 7.0, device=DEV)
-    ops.relpos_softmax_bwd(probs, ds, dbd, B, H, T, scale)
+    ops.relpos_softmax_bwd(probs, ds, ds, dbd, B, H, T, scale)
     _close(ds, ac.grad, atol=1e-6, rtol=1e-3)
     _close(dbd, bd.grad, atol=1e-6, rtol=1e-3)
 
