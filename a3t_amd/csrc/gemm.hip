@@ -430,8 +430,9 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.A = d->A, p.B = d->B, p.C = d->C, p.bias = d->bias, p.R = d->R, p.S = d->S;
     p.M = d->M, p.N = d->N, p.K = d->K;
     p.taps = d->taps < 1 ? 1 : d->taps;
-    if (p.K % p.taps) return A3T_EINVAL;
-    p.Kc = p.K / p.taps;
+    const bool wgrad_fused = (d->taps > 1 && d->a_cs != 1);   // TN conv weight gradient, columns = (tap, c)
+    if (!wgrad_fused && (p.K % p.taps)) return A3T_EINVAL;
+    p.Kc = wgrad_fused ? p.K : p.K / p.taps;
     p.a_rs = d->a_rs, p.a_cs = d->a_cs, p.b_rs = d->b_rs, p.b_cs = d->b_cs, p.b_ts = d->b_ts, p.c_rs = d->c_rs;
     int batch = d->batch < 1 ? 1 : d->batch;
     p.batch_inner = d->batch_inner < 1 ? 1 : d->batch_inner;
@@ -449,7 +450,12 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     const bool AK = (d->a_cs == 1), BKC = (d->b_cs == 1);
     if (!AK && d->a_rs != 1) return A3T_EINVAL;
     if (!BKC && d->b_rs != 1) return A3T_EINVAL;
-    if (p.taps > 1 && !AK) return A3T_EINVAL;  // im2col row shift needs the k-contiguous A loader
+    if (p.taps > 1 && !AK) {  // fused conv weight gradient: only the direct-to-LDS bf16 kernel implements it
+        if (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16 || d->b_cs == 1) return A3T_EINVAL;
+        p.tiles_n = (p.N + 127) / 128;
+        int rc = a3t_gemm_bf16_glds(p, batch, false, false, stream);
+        return rc >= 0 ? rc : A3T_EINVAL;
+    }
     if (!AK && BKC) return A3T_EINVAL;         // (TT layout is never needed on this path)
     p.tiles_n = (p.N + 127) / 128;
     const int tiles_m = (p.M + 127) / 128;

@@ -59,6 +59,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
     const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
     if (kt0 >= kt1) return;
 
+    const bool WG = (LAYOUT == L_TN) && (p.taps > 1);
+    const int wg_cin = WG ? p.N / p.taps : 1;
+    const int wg_tap = WG ? (tn * BN) / wg_cin : 0;
+    const int kshift = WG ? (wg_tap - p.pad) * p.dil : p.kshift;
+
     // ---- per-lane source bookkeeping (4 DMA instructions per operand per tile) ---------------
     // k-contiguous image: instr q of wave w covers tile rows (w*4+q)*8 + (lane>>3), 16-B chunk
     //   position c = lane&7 holds source chunk c ^ (row&7).
@@ -111,7 +116,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
             // running decomposition of this lane's reduction index: (tap, channel) for W^T of a conv,
             // position inside the utterance for the token-shifted weight-gradient operand
             int kg = kt0 * BK + kr;
-            if (p.taps > 1) {
+            if (WG) {
+                // conv weight gradient in ONE launch: output columns are (tap, c); a 128-column tile
+                // lies inside one tap (Cin % 128 == 0), which fixes this block's token shift
+                b_row[q] = B + (col - wg_tap * wg_cin);
+                b_cc[q] = kg % p.Tseq;
+            } else if (p.taps > 1) {
                 b_tap[q] = kg / p.Kc;
                 b_cc[q] = kg - b_tap[q] * p.Kc;
             } else if (p.kshift_mode) {
@@ -157,13 +167,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
                     }
                     src = b_row[q] + koff;
                 }
-            } else if (p.taps > 1) {
+            } else if (!WG && p.taps > 1) {
                 if (b_ok[q] && kg < p.K) src = b_row[q] + (int64_t)b_tap[q] * p.b_ts + (int64_t)b_cc[q] * p.b_cs;
                 b_cc[q] += BK;
                 while (b_cc[q] >= p.Kc) b_cc[q] -= p.Kc, ++b_tap[q];
-            } else if (p.kshift_mode) {
-                int tt = b_cc[q] + p.kshift;
-                if (b_ok[q] && kg < p.K && tt >= 0 && tt < p.Tseq) src = b_row[q] + (int64_t)(kg + p.kshift) * p.b_cs;
+            } else if (WG || p.kshift_mode) {
+                int tt = b_cc[q] + kshift;
+                if (b_ok[q] && kg < p.K && tt >= 0 && tt < p.Tseq) src = b_row[q] + (int64_t)(kg + kshift) * p.b_cs;
                 b_cc[q] += BK;
                 while (b_cc[q] >= p.Tseq) b_cc[q] -= p.Tseq;
             } else if (b_ok[q] && kg < p.K) {
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
         }
         stage ^= 1;
     }
-    if (!p.epi_vec) {
+    if (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC) {   // coalesced 128-B atomic rows straight from the accumulators
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -326,6 +336,7 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
         ok = ok && m8(p.b_rs) && m8(p.K) && m8(p.b_ts);
     else
         ok = ok && m8(p.b_cs) && m8(p.b_ts) && m8(p.N);
+    if (!AK && p.taps > 1) ok = ok && ((p.N / p.taps) % 128 == 0) && (p.N % p.taps == 0) && p.Tseq > 0;
     if (!ok) return -1;
     GP pv = p;
     // vector epilogue contract: 4-column groups never straddle N and every C/R/S/bias access is aligned

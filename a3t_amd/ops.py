@@ -74,7 +74,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
 
 
-def _splitk_for(n_tiles, K, target=1024, ktile=32):
+def _splitk_for(n_tiles, K, target=512, ktile=64):
     """Token-reduction GEMMs (weight gradients) have few output tiles: split K over workgroups
     until the grid covers the 256 CUs a few times."""
     s = max(1, target // max(n_tiles, 1))
@@ -128,6 +128,13 @@ def conv_bwd_weight(dy, x, dWk, Tseq, pad, dil=1, alpha=1.0, compute=F32):
     M, N = dy.shape
     Cin = x.shape[1]
     taps = dWk.shape[1]
+    if compute == BF16 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and Cin % 128 == 0 \
+            and N % 8 == 0 and taps > 1:
+        # one launch: output columns (tap, c); every 128-column tile carries its own token shift
+        tiles = ((N + 127) // 128) * (taps * Cin // 128)
+        gemm(dy, x, dWk, N, taps * Cin, M, 1, N, 1, Cin, taps * Cin, taps=taps, pad=pad, dil=dil, Tseq=Tseq,
+             alpha=alpha, acc=ACC_ATOMIC, splitk=_splitk_for(tiles, M), compute=compute)
+        return
     tiles = ((N + 127) // 128) * ((Cin + 127) // 128)
     sk = _splitk_for(tiles, M)
     flat = dWk.view(-1)
