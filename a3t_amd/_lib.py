@@ -32,6 +32,7 @@ class GemmDesc(ctypes.Structure):
         ("act", c_int32), ("accumulate", c_int32), ("splitk", c_int32),
         ("a_dtype", c_int32), ("b_dtype", c_int32), ("c_dtype", c_int32), ("compute", c_int32),
         ("s_dtype", c_int32), ("reserved", c_int32),
+        ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("reserved2", c_int32),
     ]
 
 
@@ -39,14 +40,14 @@ _P = c_void_p
 _SIGS = {
     "a3t_gemm": [POINTER(GemmDesc), _P],
     "a3t_layernorm_fwd": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_float, _P],
-    "a3t_layernorm_bwd": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
+    "a3t_layernorm_bwd": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P],
     "a3t_col_reduce": [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
     "a3t_f64_to_f32_add": [_P, _P, c_int, c_float, _P],
     "a3t_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P],
     "a3t_bn_act_bwd_a": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_bn_act_bwd_b": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_glu_dwconv_fwd": [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P],
-    "a3t_glu_dwconv_bwd": [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "a3t_glu_dwconv_bwd": [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_add_pos_bias": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_add_pos_bias_bwd": [_P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_relpos_softmax_fwd": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P],

@@ -75,80 +75,106 @@ extern "C" int a3t_glu_dwconv_fwd(const void* g, int g_dtype, const float* wdw, 
     return (int)hipGetLastError();
 }
 
+// One block = 64 channels x `tiles_per_block` consecutive time tiles of one utterance: the weight
+// gradient partials stay in registers across the tiles, so the LDS reduction + atomics happen once.
 __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __restrict__ dz, const void* __restrict__ g,
                                                              int g_dt, const void* __restrict__ glu, int glu_dt,
                                                              const float* __restrict__ wdw, void* __restrict__ dg,
-                                                             int dg_dt, float* dwdw, float* dbdw, int C, int K,
-                                                             int Tseq, int tiles_t) {
+                                                             int dg_dt, float* dwdw, float* dbdw, float* dgsum, int C,
+                                                             int K, int Tseq, int tiles_t, int tiles_per_block,
+                                                             int chunks) {
     __shared__ float wdz[DW_TT + DW_KMAX - 1][64];   // dz window  (rows t0-pad .. t0+TT+pad)
     __shared__ float wgl[DW_TT + DW_KMAX - 1][64];   // glu window
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
-    const int b = blockIdx.y / tiles_t, t0 = (blockIdx.y % tiles_t) * DW_TT;
+    const int b = blockIdx.y / chunks, tile0 = (blockIdx.y % chunks) * tiles_per_block;
     const int pad = (K - 1) / 2;
     const int64_t mbase = (int64_t)b * Tseq;
     const int rows = DW_TT + K - 1;
-    for (int r = ty; r < rows; r += 4) {
-        int t = t0 - pad + r;
-        float a = 0.f, q = 0.f;
-        if (c < C && t >= 0 && t < Tseq) {
-            a = dz[(mbase + t) * (int64_t)C + c];
-            q = ldx(glu, glu_dt, (mbase + t) * (int64_t)C + c);
-        }
-        wdz[r][tx] = a;
-        wgl[r][tx] = q;
-    }
-    __syncthreads();
     float w[DW_KMAX], dw[DW_KMAX];
 #pragma unroll
     for (int k = 0; k < DW_KMAX; ++k) {
         w[k] = (k < K && c < C) ? wdw[(int64_t)c * K + k] : 0.f;
         dw[k] = 0.f;
     }
-    float db = 0.f;
-    if (c < C) {
-        for (int r = ty; r < DW_TT; r += 4) {
-            int t = t0 + r;
-            if (t >= Tseq) break;
-            // data gradient: dglu[t] = sum_k w[k] * dz[t + pad - k]  (window row r + 2*pad - k)
-            float acc = 0.f;
+    float db = 0.f, sga = 0.f, sgb = 0.f;
+    for (int tile = tile0; tile < min(tiles_t, tile0 + tiles_per_block); ++tile) {
+        const int t0 = tile * DW_TT;
+        __syncthreads();
+        for (int r = ty; r < rows; r += 4) {
+            int t = t0 - pad + r;
+            float a = 0.f, q = 0.f;
+            if (c < C && t >= 0 && t < Tseq) {
+                a = dz[(mbase + t) * (int64_t)C + c];
+                q = ldx(glu, glu_dt, (mbase + t) * (int64_t)C + c);
+            }
+            wdz[r][tx] = a;
+            wgl[r][tx] = q;
+        }
+        __syncthreads();
+        if (c < C) {
+            for (int r = ty; r < DW_TT; r += 4) {
+                int t = t0 + r;
+                if (t >= Tseq) break;
+                // data gradient: dglu[t] = sum_k w[k] * dz[t + pad - k]  (window row r + 2*pad - k)
+                float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < DW_KMAX; ++k)
-                if (k < K) acc += w[k] * wdz[r + 2 * pad - k][tx];
-            const int64_t gi = (mbase + t) * (int64_t)(2 * C);
-            float ga = ldx(g, g_dt, gi + c), sb = sigm(ldx(g, g_dt, gi + C + c));
-            stx(dg, dg_dt, gi + c, acc * sb);
-            stx(dg, dg_dt, gi + C + c, acc * ga * sb * (1.f - sb));
-            // weight gradient: dw[k] += dz[t] * glu[t + k - pad]
-            float dzt = wdz[r + pad][tx];
-            db += dzt;
+                for (int k = 0; k < DW_KMAX; ++k)
+                    if (k < K) acc += w[k] * wdz[r + 2 * pad - k][tx];
+                const int64_t gi = (mbase + t) * (int64_t)(2 * C);
+                float ga = ldx(g, g_dt, gi + c), sb = sigm(ldx(g, g_dt, gi + C + c));
+                const float da = acc * sb, dbb = acc * ga * sb * (1.f - sb);
+                stx(dg, dg_dt, gi + c, da);
+                stx(dg, dg_dt, gi + C + c, dbb);
+                sga += da, sgb += dbb;
+                // weight gradient: dw[k] += dz[t] * glu[t + k - pad]
+                float dzt = wdz[r + pad][tx];
+                db += dzt;
 #pragma unroll
-            for (int k = 0; k < DW_KMAX; ++k)
-                if (k < K) dw[k] += dzt * wgl[r + k][tx];
+                for (int k = 0; k < DW_KMAX; ++k)
+                    if (k < K) dw[k] += dzt * wgl[r + k][tx];
+            }
         }
     }
 #pragma unroll
     for (int k = 0; k < DW_KMAX; ++k) {
         if (k >= K) break;
+        __syncthreads();
         red[ty][tx] = dw[k];
         __syncthreads();
         if (ty == 0 && c < C) atomicAdd(&dwdw[(int64_t)c * K + k], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
-        __syncthreads();
     }
+    __syncthreads();
     red[ty][tx] = db;
     __syncthreads();
     if (ty == 0 && c < C) atomicAdd(&dbdw[c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+    if (dgsum) {
+        __syncthreads();
+        red[ty][tx] = sga;
+        __syncthreads();
+        if (ty == 0 && c < C) atomicAdd(&dgsum[c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+        __syncthreads();
+        red[ty][tx] = sgb;
+        __syncthreads();
+        if (ty == 0 && c < C) atomicAdd(&dgsum[C + c], red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+    }
 }
 
 extern "C" int a3t_glu_dwconv_bwd(const float* dz, const void* g, int g_dtype, const void* glu, int glu_dtype,
-                                  const float* wdw, void* dg, int dg_dtype, float* dwdw, float* dbdw, int M, int C,
-                                  int K, int Tseq, void* stream) {
+                                  const float* wdw, void* dg, int dg_dtype, float* dwdw, float* dbdw, float* dg_colsum,
+                                  int M, int C, int K, int Tseq, void* stream) {
     if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
     int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
-    dim3 grid((C + 63) / 64, B * tiles_t);
+    // enough blocks to fill 256 CUs a few times, as few weight-gradient reductions as possible
+    int cb = (C + 63) / 64;
+    int chunks = 1;
+    while (cb * B * chunks < 1024 && chunks < tiles_t) ++chunks;
+    int tpb = (tiles_t + chunks - 1) / chunks;
+    chunks = (tiles_t + tpb - 1) / tpb;
+    dim3 grid(cb, B * chunks);
     hipLaunchKernelGGL(glu_dwconv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, g, g_dtype, glu, glu_dtype,
-                       wdw, dg, dg_dtype, dwdw, dbdw, C, K, Tseq, tiles_t);
+                       wdw, dg, dg_dtype, dwdw, dbdw, dg_colsum, C, K, Tseq, tiles_t, tpb, chunks);
     return (int)hipGetLastError();
 }
 
@@ -202,7 +228,9 @@ __device__ __forceinline__ float bd_shift(const float* __restrict__ BDz, int T, 
     return BDz[(int64_t)(i + 1) * T + (j - i - 2)];
 }
 
-// one wave per (z, i) row; three coalesced passes over the row (L1/L2 resident after pass 1)
+// one wave per (z, i) row.  NV > 0: the row is read ONCE and kept in NV registers per lane
+// (T <= 64*NV); NV == 0: generic three-pass fallback for very long rows.
+template <int NV>
 __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __restrict__ ac,
                                                                  const float* __restrict__ bd,
                                                                  const uint8_t* __restrict__ keymask,
@@ -219,7 +247,34 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     const float* bz = bd + zz * bd_bs;
     const uint8_t* mk = keymask + (int64_t)b * T;
     const int64_t po = zz * p_bs + (int64_t)i * T;
-    float mx = -3.4028235e38f;
+    const float NEG = -3.4028235e38f;
+    if (NV > 0) {
+        float v[NV > 0 ? NV : 1];
+        float mx = NEG;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            int j = lane + q * 64;
+            v[q] = NEG;
+            if (j < T && mk[j]) v[q] = (ar[j] + bd_shift(bz, T, i, j)) * scale;
+            mx = fmaxf(mx, v[q]);
+        }
+        mx = wmax(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            v[q] = (v[q] > NEG) ? expf(v[q] - mx) : 0.f;   // masked keys and the all-masked row -> 0
+            s += v[q];
+        }
+        s = wsum(s);
+        const float inv = s > 0.f ? 1.f / s : 0.f;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            int j = lane + q * 64;
+            if (j < T) stx(probs, p_dt, po + j, v[q] * inv);
+        }
+        return;
+    }
+    float mx = NEG;
     int any = 0;
     for (int j = lane; j < T; j += 64)
         if (mk[j]) {
@@ -241,17 +296,31 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
         stx(probs, p_dt, po + j, mk[j] ? expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx) * inv : 0.f);
 }
 
+#define SM_DISPATCH(T, CALL)               \
+    do {                                   \
+        if ((T) <= 128) { CALL(2); }       \
+        else if ((T) <= 256) { CALL(4); }  \
+        else if ((T) <= 512) { CALL(8); }  \
+        else if ((T) <= 1152) { CALL(18); } \
+        else if ((T) <= 2048) { CALL(32); } \
+        else { CALL(0); }                  \
+    } while (0)
+
 extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, void* probs,
                                       int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs,
                                       int64_t p_bs, float scale, void* stream) {
     int64_t nrows = (int64_t)B * H * T;
-    hipLaunchKernelGGL(relpos_softmax_fwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       ac, bd, keymask, probs, probs_dtype, H, T, ac_bs, bd_bs, p_bs, scale, nrows);
+#define CALL(NV)                                                                                                 \
+    hipLaunchKernelGGL(relpos_softmax_fwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
+                       (hipStream_t)stream, ac, bd, keymask, probs, probs_dtype, H, T, ac_bs, bd_bs, p_bs, scale, nrows)
+    SM_DISPATCH(T, CALL);
+#undef CALL
     return (int)hipGetLastError();
 }
 
 // ds = probs*(dprobs - sum_j dprobs*probs)*scale: written to ds (same dtype as dbd; may alias dprobs
 // when fp32) and scattered un-shifted into the compact dBD (every dBD element written exactly once).
+template <int NV>
 __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __restrict__ probs, int p_dt,
                                                                  const float* dprobs, void* ds, void* __restrict__ dbd,
                                                                  int o_dt, int T, int64_t p_bs, int64_t dp_bs,
@@ -264,16 +333,35 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
     const int64_t po = zz * p_bs + (int64_t)i * T;
     const float* dr = dprobs + zz * dp_bs + (int64_t)i * T;
     const int64_t oz = zz * o_bs;
+    float pv[NV > 0 ? NV : 1], dv[NV > 0 ? NV : 1];
     float s = 0.f;
-    for (int j = lane; j < T; j += 64) s += ldx(probs, p_dt, po + j) * dr[j];
+    if (NV > 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            int j = lane + q * 64;
+            pv[q] = (j < T) ? ldx(probs, p_dt, po + j) : 0.f;
+            dv[q] = (j < T) ? dr[j] : 0.f;
+            s += pv[q] * dv[q];
+        }
+    } else {
+        for (int j = lane; j < T; j += 64) s += ldx(probs, p_dt, po + j) * dr[j];
+    }
     s = wsum(s);
-    for (int j = lane; j < T; j += 64) {
-        float v = ldx(probs, p_dt, po + j) * (dr[j] - s) * scale;
+    auto emit = [&](int j, float v) {
         stx(ds, o_dt, oz + (int64_t)i * T + j, v);
         if (j <= i)
             stx(dbd, o_dt, oz + (int64_t)i * T + (T - 1 - i + j), v);
         else if (j > i + 1)
             stx(dbd, o_dt, oz + (int64_t)(i + 1) * T + (j - i - 2), v);
+    };
+    if (NV > 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            int j = lane + q * 64;
+            if (j < T) emit(j, pv[q] * (dv[q] - s) * scale);
+        }
+    } else {
+        for (int j = lane; j < T; j += 64) emit(j, ldx(probs, p_dt, po + j) * (dr[j] - s) * scale);
     }
     if (i == 0)  // BD[0][0..T-2] never reaches the scores
         for (int j = lane; j < T - 1; j += 64) stx(dbd, o_dt, oz + j, 0.f);
@@ -283,7 +371,10 @@ extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const 
                                       int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
                                       float scale, void* stream) {
     int64_t nrows = (int64_t)B * H * T;
-    hipLaunchKernelGGL(relpos_softmax_bwd_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       probs, probs_dtype, dprobs, ds, dbd, out_dtype, T, p_bs, dp_bs, o_bs, scale, nrows);
+#define CALL(NV)                                                                                                 \
+    hipLaunchKernelGGL(relpos_softmax_bwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
+                       (hipStream_t)stream, probs, probs_dtype, dprobs, ds, dbd, out_dtype, T, p_bs, dp_bs, o_bs, scale, nrows)
+    SM_DISPATCH(T, CALL);
+#undef CALL
     return (int)hipGetLastError();
 }

@@ -446,6 +446,8 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     if (p.splitk > 1 && p.accumulate != A3T_ACC_ATOMIC) return A3T_EINVAL;
     p.c_dtype = d->c_dtype;
     p.s_dtype = d->s_dtype;
+    p.epi_vec = 0;
+    p.colsum = d->colsum, p.colsum_bs1 = d->colsum_bs1, p.colsum_scale = d->colsum_scale;
     if (p.c_dtype == A3T_BF16 && p.accumulate != A3T_ACC_STORE) return A3T_EINVAL;
     const bool AK = (d->a_cs == 1), BKC = (d->b_cs == 1);
     if (!AK && d->a_rs != 1) return A3T_EINVAL;
@@ -462,7 +464,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk)), block(256);
 
     if (d->compute == A3T_F32) {
-        if (d->a_dtype != A3T_F32 || d->b_dtype != A3T_F32) return A3T_EINVAL;
+        if (d->a_dtype != A3T_F32 || d->b_dtype != A3T_F32 || d->colsum) return A3T_EINVAL;
         bool vec = al(p.A, 16) && al(p.B, 16) && m4(p.a_bs0, 4) && m4(p.a_bs1, 4) && m4(p.b_bs0, 4) && m4(p.b_bs1, 4);
         if (AK)
             vec = vec && m4(p.a_rs, 4) && m4(p.K, 4) && m4(p.Kc, 4);
@@ -493,6 +495,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         int rc = a3t_gemm_bf16_glds(p, batch, AK, BKC, stream);   // direct-to-LDS production kernel
         if (rc >= 0) return rc;                                   // -1: alignment contract not met
     }
+    if (d->colsum) return A3T_EINVAL;   // fused column sums live in the direct-to-LDS kernel's epilogue
     {
         const int ea = d->a_dtype == A3T_BF16 ? 2 : 4, eb = d->b_dtype == A3T_BF16 ? 2 : 4;
         bool ok = al(p.A, 16) && al(p.B, 16);

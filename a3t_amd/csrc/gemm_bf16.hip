@@ -271,14 +271,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
     // (only this wave reads its region back; a wave is lock-step, LDS ops are issued in order)
     const int c4 = (lane & 15) * 4, r4 = lane >> 4;
     const int col = tn * BN + wn + c4;
-    if (col >= p.N) return;
+    const bool col_ok = col < p.N;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && ks == 0) bias4 = *(const float4*)(p.bias + col);
+    if (p.bias && ks == 0 && col_ok) bias4 = *(const float4*)(p.bias + col);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
         const int lrow = it * 4 + r4;
         const int row = tm * BM + wm + lrow;
-        if (row >= p.M) continue;
+        if (row >= p.M || !col_ok) continue;
         float4 v = *(const float4*)(ct + lrow * 64 + c4);
         const int64_t idx = zoff + (int64_t)row * p.c_rs + col;
         v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
             float4 rv = *(const float4*)(p.R + idx);
             v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
         }
+        cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
         if (p.c_dtype == A3T_BF16) {
             uint2 o;
             o.x = f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
@@ -318,6 +320,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
             } else {
                 atomicAdd(C + 0, v.x), atomicAdd(C + 1, v.y), atomicAdd(C + 2, v.z), atomicAdd(C + 3, v.w);
             }
+        }
+    }
+    if (p.colsum) {   // lanes l, l+16, l+32, l+48 hold the same 4 columns (different rows)
+        cs.x += __shfl_xor(cs.x, 16, 64), cs.y += __shfl_xor(cs.y, 16, 64);
+        cs.z += __shfl_xor(cs.z, 16, 64), cs.w += __shfl_xor(cs.w, 16, 64);
+        cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64);
+        cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
+        if (lane < 16 && col_ok) {
+            float* o = p.colsum + z1 * p.colsum_bs1 + col;
+            atomicAdd(o + 0, p.colsum_scale * cs.x), atomicAdd(o + 1, p.colsum_scale * cs.y);
+            atomicAdd(o + 2, p.colsum_scale * cs.z), atomicAdd(o + 3, p.colsum_scale * cs.w);
         }
     }
 }
@@ -339,9 +352,11 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     if (!AK && p.taps > 1) ok = ok && ((p.N / p.taps) % 128 == 0) && (p.N % p.taps == 0) && p.Tseq > 0;
     if (!ok) return -1;
     GP pv = p;
+    if (p.colsum && (p.accumulate == A3T_ACC_ATOMIC)) return -1;
     // vector epilogue contract: 4-column groups never straddle N and every C/R/S/bias access is aligned
     pv.epi_vec = (p.N % 4 == 0) && (p.c_rs % 4 == 0) && (p.c_bs0 % 4 == 0) && (p.c_bs1 % 4 == 0) &&
                  al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
+    if (p.colsum && !pv.epi_vec) return -1;
     const int tiles_m = (p.M + 127) / 128;
     dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk)), block(256);
     const size_t lds = 4 * 128 * 64 * 2;

@@ -18,6 +18,9 @@ struct GP {
     int taps, pad, dil, Tseq, kshift, kshift_mode;
     float alpha;
     int act, accumulate, splitk, c_dtype, tiles_n, s_dtype, epi_vec;
+    float* colsum;
+    int64_t colsum_bs1;
+    float colsum_scale;
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) {

@@ -15,10 +15,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm: rows of D <= 64*MAXV floats, one wave per row, values kept in registers.
+// LayerNorm: one wave64 per row, the row lives in V registers per lane (V = ceil(D/64), chosen at
+// launch so the d=384 rows of the Conformer use exactly 6), __shfl_xor butterflies for the stats.
 // ------------------------------------------------------------------------------------------
 #define LN_MAXV 24  // D <= 1536
 
+template <int V>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                      const float* __restrict__ b, void* __restrict__ y, int y_dt,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M,
@@ -27,10 +29,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int row = blockIdx.x * 4 + wv;
     if (row >= M) return;
     const float* xr = x + (int64_t)row * D;
-    float v[LN_MAXV];
+    float v[V];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         int c = lane + i * 64;
         v[i] = (c < D) ? xr[c] : 0.f;
         s += v[i];
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float mu = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         int c = lane + i * 64;
         float dlt = (c < D) ? (v[i] - mu) : 0.f;
         q += dlt * dlt;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const float var = wave_sum(q) / (float)D;
     const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         int c = lane + i * 64;
         if (c < D) stx(y, y_dt, (int64_t)row * D + c, (v[i] - mu) * rs * g[c] + b[c]);
     }
@@ -56,32 +58,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// dx = dres + LN'(dy); optional bf16 copy; column sums of dy*xhat, dy (and optionally of dx, the
+// bias gradient of whatever produced the residual-stream gradient) reduced per block, then atomics.
+template <int V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
                                                      const float* __restrict__ g, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* dres,
-                                                     float* dx, unsigned short* __restrict__ dx16,
-                                                     float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int D) {
-    __shared__ float red[2][4][64];
+                                                     const float* __restrict__ rstd, const float* dres, float* dx,
+                                                     unsigned short* __restrict__ dx16, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                                     float dxsum_scale, int M, int D) {
+    __shared__ float red[3][4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float gam[LN_MAXV], ag[LN_MAXV], ab[LN_MAXV];
+    float gam[V], ag[V], ab[V], ax[V];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         int c = lane + i * 64;
         gam[i] = (c < D) ? g[c] : 0.f;
-        ag[i] = 0.f;
-        ab[i] = 0.f;
+        ag[i] = ab[i] = ax[i] = 0.f;
     }
     for (int row = blockIdx.x * 4 + wv; row < M; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        const float* xr = x + (int64_t)row * D;
-        float xh[LN_MAXV], dg[LN_MAXV];
+        const int64_t ro = (int64_t)row * D;
+        float xh[V], dg[V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < V; ++i) {
             int c = lane + i * 64;
-            float d = (c < D) ? ldx(dy, dy_dt, (int64_t)row * D + c) : 0.f;
-            xh[i] = (c < D) ? (xr[c] - mu) * rs : 0.f;
+            float d = (c < D) ? ldx(dy, dy_dt, ro + c) : 0.f;
+            xh[i] = (c < D) ? (x[ro + c] - mu) * rs : 0.f;
             dg[i] = d * gam[i];
             s1 += dg[i];
             s2 += dg[i] * xh[i];
@@ -90,53 +94,71 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
         s1 = wave_sum(s1) / (float)D;
         s2 = wave_sum(s2) / (float)D;
-        float* dxr = dx + (int64_t)row * D;
-        const float* rr = dres ? dres + (int64_t)row * D : nullptr;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < V; ++i) {
             int c = lane + i * 64;
             if (c < D) {
                 float o = rs * (dg[i] - s1 - xh[i] * s2);
-                if (rr) o += rr[c];
-                dxr[c] = o;
-                if (dx16) dx16[(int64_t)row * D + c] = io_f2bf(o);
+                if (dres) o += dres[ro + c];
+                dx[ro + c] = o;
+                if (dx16) dx16[ro + c] = io_f2bf(o);
+                ax[i] += o;
             }
         }
     }
-    // reduce the 4 waves' column partials, one atomic per column per block
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         if (i * 64 >= D) break;
         red[0][wv][lane] = ag[i];
         red[1][wv][lane] = ab[i];
+        red[2][wv][lane] = ax[i];
         __syncthreads();
         if (wv == 0) {
             int c = lane + i * 64;
             if (c < D) {
                 atomicAdd(&dgamma[c], red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]);
                 atomicAdd(&dbeta[c], red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]);
+                if (dxsum)
+                    atomicAdd(&dxsum[c], dxsum_scale * (red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]));
             }
         }
         __syncthreads();
     }
 }
 
+#define LN_DISPATCH(D, CALL)              \
+    do {                                  \
+        if ((D) <= 64) { CALL(1); }       \
+        else if ((D) <= 128) { CALL(2); } \
+        else if ((D) <= 256) { CALL(4); } \
+        else if ((D) <= 384) { CALL(6); } \
+        else if ((D) <= 512) { CALL(8); } \
+        else { CALL(LN_MAXV); }           \
+    } while (0)
+
 extern "C" int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                                  float* mean, float* rstd, int M, int D, float eps, void* stream) {
     if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, y_dtype,
-                       mean, rstd, M, D, eps);
+#define CALL(V)                                                                                                  \
+    hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, \
+                       y_dtype, mean, rstd, M, D, eps)
+    LN_DISPATCH(D, CALL);
+#undef CALL
     return (int)hipGetLastError();
 }
 
 extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, const float* dres, float* dx, void* dx_bf16,
-                                 float* dgamma, float* dbeta, int M, int D, void* stream) {
+                                 float* dgamma, float* dbeta, float* dx_colsum, float dx_colsum_scale, int M, int D,
+                                 void* stream) {
     if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
     int blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean,
-                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, M, D);
+    if (blocks > 512) blocks = 512;
+#define CALL(V)                                                                                                   \
+    hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
+                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D)
+    LN_DISPATCH(D, CALL);
+#undef CALL
     return (int)hipGetLastError();
 }
 

@@ -103,10 +103,16 @@ class MLMEngine:
         self.sv[tag] = (x, y, mean, rstd)
         return y
 
-    def _ln_bwd(self, tag, dy, pre, dres, dx, dx16=None):
+    def _ln_bwd(self, tag, dy, pre, dres, dx, dx16=None, nb=None):
+        """nb = (bias-gradient view, scale) of the layer that produced the residual stream this LN read:
+        its bias gradient is the column sum of dx; fused into the kernel on the bf16 path."""
         p, g = self.store.p, self.store.g
         x, _, mean, rstd = self.sv[tag]
-        ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=dx16)
+        fuse = self.bf16 and nb is not None
+        ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=dx16,
+                          dxsum=nb[0] if fuse else None, dxsum_scale=nb[1] if fuse else 1.0)
+        if nb is not None and not fuse:
+            self._bias_grad(dx, nb[0], nb[1])
 
     def _bias_grad(self, dy, gb, scale=1.0):
         ops.bias_grad(dy, gb, self.scratch64, scale)
@@ -128,7 +134,7 @@ class MLMEngine:
         self.sv[tag] = (y, h)
         return xo
 
-    def _ffn_bwd(self, tag, pre, g, T):
+    def _ffn_bwd(self, tag, pre, g, T, nb=None):
         """g = grad wrt the sub-layer output (fp32 residual stream, updated in place to the grad wrt
         the sub-layer input); in bf16 mode grad.x16 holds the same values in bf16 on entry and exit."""
         p, gr, c = self.store.p, self.store.g, self.c
@@ -138,14 +144,16 @@ class MLMEngine:
         g16 = self._g16(g)
         ga = g16 if self.bf16 else g
         dh = self._act("tmp.dh", (M, c.ff))
-        ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=0.5, compute=self.cmp)
+        # (b2's gradient = 0.5*colsum(g) was accumulated by the LayerNorm backward that produced g)
+        ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=0.5, compute=self.cmp,
+                          colsum=gr[pre + ".b1"] if self.bf16 else None)
         ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp)
-        self._bias_grad(g, gr[pre + ".b2"], 0.5)
         dy = self._act("tmp.dy", (M, c.adim))
         ops.conv_bwd_data(dh, self.W(pre + ".w1"), dy, T, pad, compute=self.cmp)
         ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp)
-        self._bias_grad(dh, gr[pre + ".b1"])
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16)
+        if not self.bf16:
+            self._bias_grad(dh, gr[pre + ".b1"])
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
         return g
 
     # ------------------------------------------------------------------ rel-pos self-attention
@@ -182,7 +190,7 @@ class MLMEngine:
         self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos)
         return xo
 
-    def _mha_bwd(self, tag, pre, g, B, T):
+    def _mha_bwd(self, tag, pre, g, B, T, nb=None):
         p, gr, c = self.store.p, self.store.g, self.c
         d, H, dk = c.adim, c.heads, c.dk
         M = B * T
@@ -194,7 +202,6 @@ class MLMEngine:
         dctx = self._act("tmp.dctx", (M, d))
         ops.linear_bwd_data(ga, self.W(pre + ".wo"), dctx, compute=cmp)
         ops.linear_bwd_weight(ga, ctx, gr[pre + ".wo"], compute=cmp)
-        self._bias_grad(g, gr[pre + ".bo"])
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
         dqkv = self._act("tmp.dqkv", (M, 3 * d))
@@ -206,8 +213,11 @@ class MLMEngine:
         ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
                  b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
+        fz = self.bf16   # bias / pos-bias gradients ride on the GEMM epilogues as column sums
+        gbq = gr[pre + ".bqkv"]
         ops.gemm(probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp)
+                 b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp, colsum=gbq[2 * d:] if fz else None,
+                 colsum_bs1=dk)
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
             dbd = self.ws.get("tmp.dbd16", (B, H, T, T), torch.bfloat16)
@@ -219,12 +229,13 @@ class MLMEngine:
         dqv = self._act("tmp.dqv", (M, d))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
         ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp)
+                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=gr[pre + ".u"] if fz else None,
+                 colsum_bs1=dk)
         ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                 c_bs=(T * 3 * d, dk), compute=cmp)
+                 c_bs=(T * 3 * d, dk), compute=cmp, colsum=gbq[d:] if fz else None, colsum_bs1=dk)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
-                 c_bs=(T * d, dk), compute=cmp)
+                 c_bs=(T * d, dk), compute=cmp, colsum=gr[pre + ".v"] if fz else None, colsum_bs1=dk)
         dP = self.ws.get("tmp.dP", (T, d), zero=True)
         ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
                  c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
@@ -234,13 +245,17 @@ class MLMEngine:
             dP = dP16
         ops.linear_bwd_weight(dP, pos, gr[pre + ".wpos"], compute=cmp)
         ops.add_pos_bias_bwd(dqu, dqv, dqkv)
-        self._bias_grad(dqu, gr[pre + ".u"])
-        self._bias_grad(dqv, gr[pre + ".v"])
+        if fz:   # d b_q = colsum(dq_u + dq_v) = d u + d v (this layer's u/v gradients are complete here)
+            ops.axpy(gr[pre + ".u"], gbq[:d], 1.0)
+            ops.axpy(gr[pre + ".v"], gbq[:d], 1.0)
+        else:
+            self._bias_grad(dqu, gr[pre + ".u"])
+            self._bias_grad(dqv, gr[pre + ".v"])
+            self._bias_grad(dqkv, gbq)
         dy = self._act("tmp.dy", (M, d))
         ops.linear_bwd_data(dqkv, self.W(pre + ".wqkv"), dy, compute=cmp)
         ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp)
-        self._bias_grad(dqkv, gr[pre + ".bqkv"])
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
         return g
 
     # ------------------------------------------------------------------ convolution module
@@ -285,7 +300,7 @@ class MLMEngine:
         self.sv[tag] = (y, g2, glu, s)
         return xo
 
-    def _conv_bwd(self, tag, pre, g, T):
+    def _conv_bwd(self, tag, pre, g, T, nb=None):
         p, gr, c = self.store.p, self.store.g, self.c
         M, d = g.shape
         cmp = self.cmp
@@ -295,16 +310,15 @@ class MLMEngine:
         ds = self.ws.get("tmp.ds", (M, d))
         ops.linear_bwd_data(ga, self.W(pre + ".pw2"), ds, compute=cmp)
         ops.linear_bwd_weight(ga, s, gr[pre + ".pw2"], compute=cmp)
-        self._bias_grad(g, gr[pre + ".pb2"])
         dz = self.ws.get("tmp.dz", (M, d))
         self._bn_bwd(tag, ds, pre + ".bn", ACT_SWISH, dz)
         dg = self._act("tmp.dg", (M, 2 * d))
-        ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T)
+        ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T,
+                           dgsum=gr[pre + ".pb1"])
         dy = self._act("tmp.dy", (M, d))
         ops.linear_bwd_data(dg, self.W(pre + ".pw1"), dy, compute=cmp)
         ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp)
-        self._bias_grad(dg, gr[pre + ".pb1"])
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
         return g
 
     # ------------------------------------------------------------------ one Conformer block
@@ -316,11 +330,13 @@ class MLMEngine:
         return self._ln_fwd(pre + ".fin", x, pre + ".fin.ln", out_dtype=torch.float32)
 
     def block_bwd(self, pre, g, B, T):
-        self._ln_bwd(pre + ".fin", g, pre + ".fin.ln", None, g, self._g16(g))
-        self._ffn_bwd(pre + ".ff", pre + ".ff", g, T)
-        self._conv_bwd(pre + ".cnv", pre + ".cnv", g, T)
-        self._mha_bwd(pre + ".mha", pre + ".mha", g, B, T)
-        self._ffn_bwd(pre + ".ffm", pre + ".ffm", g, T)
+        gr = self.store.g
+        # every LayerNorm backward also delivers the bias gradient of the layer whose output it read
+        self._ln_bwd(pre + ".fin", g, pre + ".fin.ln", None, g, self._g16(g), (gr[pre + ".ff.b2"], 0.5))
+        self._ffn_bwd(pre + ".ff", pre + ".ff", g, T, (gr[pre + ".cnv.pb2"], 1.0))
+        self._conv_bwd(pre + ".cnv", pre + ".cnv", g, T, (gr[pre + ".mha.bo"], 1.0))
+        self._mha_bwd(pre + ".mha", pre + ".mha", g, B, T, (gr[pre + ".ffm.b2"], 0.5))
+        self._ffn_bwd(pre + ".ffm", pre + ".ffm", g, T, None)
         return g
 
     # ------------------------------------------------------------------ whole model
@@ -456,10 +472,9 @@ class MLMEngine:
                              math.sqrt(d))
         de0 = ws.get("tmp.de0", (B * Tm, d))
         de16 = ws.get("tmp.de016", (B * Tm, d), torch.bfloat16) if self.bf16 else None
-        self._ln_bwd("emb.ln", de, "emb.ln", None, de0, de16)
+        self._ln_bwd("emb.ln", de, "emb.ln", None, de0, de16, (gr["emb.b"], 1.0))
         dea = de16 if self.bf16 else de0
         ops.linear_bwd_weight(dea, xm, gr["emb.w"], compute=cmp)
-        self._bias_grad(de0, gr["emb.b"])
         dxm = ws.get("tmp.dxm", (B * Tm, c.idim))
         ops.linear_bwd_data(dea, self.W("emb.w"), dxm, compute=cmp)
         s64 = self.scratch64[:c.idim]

@@ -46,7 +46,7 @@ def _dt(t):
 
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
-         act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32):
+         act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -64,6 +64,8 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.alpha, d.act, d.accumulate, d.splitk = alpha, act, acc, splitk
     d.a_dtype, d.b_dtype, d.c_dtype, d.compute = _dt(A), _dt(B), _dt(C), compute
     d.s_dtype = _dt(S) if S is not None else F32
+    d.colsum = colsum.data_ptr() if colsum is not None else None
+    d.colsum_bs1, d.colsum_scale = colsum_bs1, colsum_scale
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -89,11 +91,11 @@ def linear_fwd(x, W, out, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F3
     gemm(x, W, out, M, N, K, K, 1, K, 1, N, bias=bias, R=R, alpha=alpha, act=act, compute=compute)
 
 
-def linear_bwd_data(dy, W, dx, S=None, alpha=1.0, acc=ACC_STORE, compute=F32):
-    """dx[M,K] = alpha * relu_mask_S(dy[M,N] @ W[N,K])"""
+def linear_bwd_data(dy, W, dx, S=None, alpha=1.0, acc=ACC_STORE, compute=F32, colsum=None):
+    """dx[M,K] = alpha * relu_mask_S(dy[M,N] @ W[N,K]);  colsum += column sums of dx"""
     M, N = dy.shape
     K = W.shape[1]
-    gemm(dy, W, dx, M, K, N, N, 1, 1, K, K, S=S, alpha=alpha, acc=acc, compute=compute)
+    gemm(dy, W, dx, M, K, N, N, 1, 1, K, K, S=S, alpha=alpha, acc=acc, compute=compute, colsum=colsum)
 
 
 def linear_bwd_weight(dy, x, dW, alpha=1.0, compute=F32):
@@ -113,14 +115,14 @@ def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT
          dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute)
 
 
-def conv_bwd_data(dy, Wk, dx, Tseq, pad, dil=1, S=None, alpha=1.0, compute=F32):
+def conv_bwd_data(dy, Wk, dx, Tseq, pad, dil=1, S=None, alpha=1.0, compute=F32, colsum=None):
     """dx[m][c] = sum_tap sum_n dy[m-(tap-pad)*dil][n] Wk[n][tap][c]: the same im2col loader on dy
     with the taps read back to front (pad' = taps-1-pad) and B addressed as W^T via strides."""
     M, N = dy.shape
     _, taps, Cin = Wk.shape
     Wv = Wk.view(-1)[(taps - 1) * Cin:]
     gemm(dy, Wv, dx, M, Cin, taps * N, N, 1, 1, taps * Cin, Cin, b_ts=-Cin, S=S, taps=taps, pad=taps - 1 - pad,
-         dil=dil, Tseq=Tseq, alpha=alpha, compute=compute)
+         dil=dil, Tseq=Tseq, alpha=alpha, compute=compute, colsum=colsum)
 
 
 def conv_bwd_weight(dy, x, dWk, Tseq, pad, dil=1, alpha=1.0, compute=F32):
@@ -154,10 +156,11 @@ def layernorm_fwd(x, g, b, y, mean, rstd, eps):
                                        _stream()), "ln_fwd")
 
 
-def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, dx16=None):
+def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, dx16=None, dxsum=None, dxsum_scale=1.0):
     M, D = x.shape
     L.check(L.load().a3t_layernorm_bwd(_ptr(dy), _dt(dy), _ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres),
-                                       _ptr(dx), _ptr(dx16), _ptr(dg), _ptr(db), M, D, _stream()), "ln_bwd")
+                                       _ptr(dx), _ptr(dx16), _ptr(dg), _ptr(db), _ptr(dxsum), dxsum_scale, M, D,
+                                       _stream()), "ln_bwd")
 
 
 def col_reduce(x, out0, out1=None, y=None, rowmask=None, mode=0, ld=None):
@@ -202,10 +205,10 @@ def glu_dwconv_fwd(g, wdw, bdw, glu, z, Tseq):
                                         wdw.shape[1], Tseq, _stream()), "glu_dwconv_fwd")
 
 
-def glu_dwconv_bwd(dz, g, glu, wdw, dg, dwdw, dbdw, Tseq):
+def glu_dwconv_bwd(dz, g, glu, wdw, dg, dwdw, dbdw, Tseq, dgsum=None):
     M, C = glu.shape
     L.check(L.load().a3t_glu_dwconv_bwd(_ptr(dz), _ptr(g), _dt(g), _ptr(glu), _dt(glu), _ptr(wdw), _ptr(dg), _dt(dg),
-                                        _ptr(dwdw), _ptr(dbdw), M, C, wdw.shape[1], Tseq, _stream()),
+                                        _ptr(dwdw), _ptr(dbdw), _ptr(dgsum), M, C, wdw.shape[1], Tseq, _stream()),
             "glu_dwconv_bwd")
 
 

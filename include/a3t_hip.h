@@ -78,6 +78,11 @@ typedef struct a3t_gemm_desc {
                                           A3T_BF16: v_mfma_f32_32x32x16_bf16, fp32 accumulate */
     int32_t s_dtype;                   /* storage type of S (A3T_F32 | A3T_BF16) */
     int32_t reserved;
+    float* colsum;                     /* optional: colsum[z1*colsum_bs1 + n] += colsum_scale * sum_m C[m][n]
+                                          (bias gradients fused into the data-gradient GEMM; bf16 path only) */
+    int64_t colsum_bs1;
+    float colsum_scale;
+    int32_t reserved2;
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
@@ -90,7 +95,9 @@ int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
  * GEMMs that consume it; dgamma/dbeta are ACCUMULATED (atomicAdd). */
 int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx, void* dx_bf16, float* dgamma,
-                      float* dbeta, int M, int D, void* stream);
+                      float* dbeta, float* dx_colsum, float dx_colsum_scale, int M, int D, void* stream);
+/* dx_colsum (optional): += dx_colsum_scale * column sums of dx = the bias gradient of the layer whose
+ * output gradient dx is. */
 
 /* Column reductions over rows of x[M][C] (row stride ld), accumulated with atomics:
  *   mode 0: out0[c] += sum x            (bias gradients)
@@ -124,8 +131,9 @@ int a3t_glu_dwconv_fwd(const void* g, int g_dtype, const float* wdw, const float
                        int glu_dtype, float* z, int M, int C, int K, int Tseq, void* stream);
 /* dz -> dg[M][2C]; dwdw[C][K], dbdw[C] accumulated (atomics) */
 int a3t_glu_dwconv_bwd(const float* dz, const void* g, int g_dtype, const void* glu, int glu_dtype,
-                       const float* wdw, void* dg, int dg_dtype, float* dwdw, float* dbdw, int M, int C,
-                       int K, int Tseq, void* stream);
+                       const float* wdw, void* dg, int dg_dtype, float* dwdw, float* dbdw, float* dg_colsum,
+                       int M, int C, int K, int Tseq, void* stream);
+/* dg_colsum (optional, [2C]): += column sums of dg (bias gradient of pointwise_conv1) */
 
 /* Attention helpers around the batched GEMMs (transformer/attention.py:167-209).
  * qkv [M][3d] (q|k|v); qu/qv [M][d] = q + pos_bias_{u,v}. */

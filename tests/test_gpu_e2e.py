@@ -103,3 +103,20 @@ def test_e2e_bf16_compute_within_1e2():
     store.zero_grad()
     eng.backward()
     assert torch.isfinite(store.grad).all()
+    # every parameter gradient of the bf16 path (fused bias sums, bf16 operands) against the fp32 path
+    eng32, store32 = _engine(oc, 7, compute="f32")
+    eng32.forward(_to_dev(batch))
+    store32.zero_grad()
+    eng32.backward()
+    g16, g32 = store.state_dict(grads=True), store32.state_dict(grads=True)
+    bad = []
+    for k in g32:
+        a, b = g16[k].double().flatten(), g32[k].double().flatten()
+        nb = float(b.norm())
+        if nb < 1e-6 or k.endswith("depthwise_conv.bias"):   # a bias in front of BatchNorm: gradient is analytically 0
+            continue
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        ratio = float(a.norm()) / nb
+        if cos < 0.97 or not (0.9 < ratio < 1.1):
+            bad.append((k, round(cos, 4), round(ratio, 4)))
+    assert not bad, bad[:10]
