@@ -26,6 +26,7 @@ __device__ __forceinline__ float wmax(float v) {
 #define DW_TT 64
 #define DW_KMAX 31
 
+template <int KT>
 __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const void* __restrict__ g, int g_dt,
                                                              const float* __restrict__ wdw,
                                                              const float* __restrict__ bdw, void* __restrict__ glu,
@@ -50,16 +51,16 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const void* __restr
     }
     __syncthreads();
     if (c >= C) return;
-    float w[DW_KMAX];
+    float w[KT];
 #pragma unroll
-    for (int k = 0; k < DW_KMAX; ++k) w[k] = (k < K) ? wdw[(int64_t)c * K + k] : 0.f;
+    for (int k = 0; k < KT; ++k) w[k] = (k < K) ? wdw[(int64_t)c * K + k] : 0.f;
     const float bias = bdw[c];
     for (int r = ty; r < DW_TT; r += 4) {
         int t = t0 + r;
         if (t >= Tseq) break;
         float acc = bias;
 #pragma unroll
-        for (int k = 0; k < DW_KMAX; ++k)
+        for (int k = 0; k < KT; ++k)
             if (k < K) acc += w[k] * win[r + k][tx];
         z[(mbase + t) * (int64_t)C + c] = acc;
     }
@@ -70,13 +71,21 @@ extern "C" int a3t_glu_dwconv_fwd(const void* g, int g_dtype, const float* wdw, 
     if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
     int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
     dim3 grid((C + 63) / 64, B * tiles_t);
-    hipLaunchKernelGGL(glu_dwconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, g_dtype, wdw, bdw, glu,
-                       glu_dtype, z, C, K, Tseq, tiles_t);
+    if (K <= 7)
+        hipLaunchKernelGGL(glu_dwconv_fwd_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, g, g_dtype, wdw, bdw, glu,
+                           glu_dtype, z, C, K, Tseq, tiles_t);
+    else if (K <= 15)
+        hipLaunchKernelGGL(glu_dwconv_fwd_kernel<15>, grid, dim3(256), 0, (hipStream_t)stream, g, g_dtype, wdw, bdw, glu,
+                           glu_dtype, z, C, K, Tseq, tiles_t);
+    else
+        hipLaunchKernelGGL(glu_dwconv_fwd_kernel<DW_KMAX>, grid, dim3(256), 0, (hipStream_t)stream, g, g_dtype, wdw, bdw,
+                           glu, glu_dtype, z, C, K, Tseq, tiles_t);
     return (int)hipGetLastError();
 }
 
 // One block = 64 channels x `tiles_per_block` consecutive time tiles of one utterance: the weight
 // gradient partials stay in registers across the tiles, so the LDS reduction + atomics happen once.
+template <int KT>
 __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __restrict__ dz, const void* __restrict__ g,
                                                              int g_dt, const void* __restrict__ glu, int glu_dt,
                                                              const float* __restrict__ wdw, void* __restrict__ dg,
@@ -92,9 +101,9 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
     const int pad = (K - 1) / 2;
     const int64_t mbase = (int64_t)b * Tseq;
     const int rows = DW_TT + K - 1;
-    float w[DW_KMAX], dw[DW_KMAX];
+    float w[KT], dw[KT];
 #pragma unroll
-    for (int k = 0; k < DW_KMAX; ++k) {
+    for (int k = 0; k < KT; ++k) {
         w[k] = (k < K && c < C) ? wdw[(int64_t)c * K + k] : 0.f;
         dw[k] = 0.f;
     }
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
                 // data gradient: dglu[t] = sum_k w[k] * dz[t + pad - k]  (window row r + 2*pad - k)
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < DW_KMAX; ++k)
+                for (int k = 0; k < KT; ++k)
                     if (k < K) acc += w[k] * wdz[r + 2 * pad - k][tx];
                 const int64_t gi = (mbase + t) * (int64_t)(2 * C);
                 float ga = ldx(g, g_dt, gi + c), sb = sigm(ldx(g, g_dt, gi + C + c));
@@ -132,13 +141,13 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
                 float dzt = wdz[r + pad][tx];
                 db += dzt;
 #pragma unroll
-                for (int k = 0; k < DW_KMAX; ++k)
+                for (int k = 0; k < KT; ++k)
                     if (k < K) dw[k] += dzt * wgl[r + k][tx];
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < DW_KMAX; ++k) {
+    for (int k = 0; k < KT; ++k) {
         if (k >= K) break;
         __syncthreads();
         red[ty][tx] = dw[k];
@@ -173,8 +182,16 @@ extern "C" int a3t_glu_dwconv_bwd(const float* dz, const void* g, int g_dtype, c
     int tpb = (tiles_t + chunks - 1) / chunks;
     chunks = (tiles_t + tpb - 1) / tpb;
     dim3 grid(cb, B * chunks);
-    hipLaunchKernelGGL(glu_dwconv_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, g, g_dtype, glu, glu_dtype,
-                       wdw, dg, dg_dtype, dwdw, dbdw, dg_colsum, C, K, Tseq, tiles_t, tpb, chunks);
+#define DWB(KT)                                                                                                       \
+    hipLaunchKernelGGL(glu_dwconv_bwd_kernel<KT>, grid, dim3(256), 0, (hipStream_t)stream, dz, g, g_dtype, glu, glu_dtype, \
+                       wdw, dg, dg_dtype, dwdw, dbdw, dg_colsum, C, K, Tseq, tiles_t, tpb, chunks)
+    if (K <= 7)
+        DWB(7);
+    else if (K <= 15)
+        DWB(15);
+    else
+        DWB(DW_KMAX);
+#undef DWB
     return (int)hipGetLastError();
 }
 

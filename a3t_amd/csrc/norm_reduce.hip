@@ -153,7 +153,7 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
                                  void* stream) {
     if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
     int blocks = (M + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 2048) blocks = 2048;   // 8 blocks/CU: the kernel is latency-bound on its row loads
 #define CALL(V)                                                                                                   \
     hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
                        rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D)

@@ -212,7 +212,7 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
-        for name, flops, e0, e1 in prof:
+        for name, flops, e0, e1, _shape in prof:
             t = e0.elapsed_time(e1) * 1e-3
             s = agg.setdefault(name, [0.0, 0.0, 0])
             s[0] += flops
