@@ -57,8 +57,12 @@ _SIGS = {
     "a3t_embed_finish_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "a3t_scale": [_P, _P, c_int64, c_float, _P],
     "a3t_axpy": [_P, _P, c_int64, c_float, _P],
+    "a3t_scale_dev": [_P, _P, c_int64, _P, _P],
     "a3t_slice_rows": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "a3t_cast_bf16": [_P, _P, c_int64, _P],
+    "a3t_reflect_pad": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "a3t_stft_amp": [_P, _P, c_int64, c_int, c_int, _P],
+    "a3t_logmel_finish": [_P, _P, c_int, c_int, c_int, _P],
     "a3t_mlm_loss": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
     "a3t_mlm_loss_scratch_floats": [c_int],
     "a3t_sumsq": [_P, c_int64, _P, _P],

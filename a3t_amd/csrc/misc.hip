@@ -101,6 +101,14 @@ extern "C" int a3t_scale(const float* x, float* y, int64_t n, float s, void* str
     hipLaunchKernelGGL(scale_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, s);
     return (int)hipGetLastError();
 }
+__global__ void scale_dev_kernel(const float* x, float* y, int64_t n, const float* s) {
+    const float k = s[0];
+    GRID_STRIDE(i, n) y[i] = x[i] * k;
+}
+extern "C" int a3t_scale_dev(const float* x, float* y, int64_t n, const float* s, void* stream) {
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, s);
+    return (int)hipGetLastError();
+}
 __global__ void axpy_kernel(const float* x, float* y, int64_t n, float a) {
     GRID_STRIDE(i, n) y[i] += a * x[i];
 }

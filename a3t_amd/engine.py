@@ -419,8 +419,11 @@ class MLMEngine:
         self.sv["head"] = (hs, before, after, db, da)
         return dict(loss=loss, before=before.view(B, Tm, c.odim), after=after.view(B, Tm, c.odim))
 
-    def backward(self):
-        """Accumulates d loss / d param (times the gscale given to forward) into store.grad."""
+    def backward(self, on_group_done=None):
+        """Accumulates d loss / d param (times the gscale given to forward) into store.grad.
+        on_group_done(first_param_name) is called each time every parameter at or above that flat
+        offset has its final gradient (hook for overlapping the gradient all-reduce)."""
+        done = on_group_done or (lambda name: None)
         c, p, gr, ws = self.c, self.store.p, self.store.g, self.ws
         B, Tm, Tp, T = self.dims
         d = c.adim
@@ -455,16 +458,19 @@ class MLMEngine:
         ops.linear_bwd_data(dba, self.W("sfc.w"), dhs, compute=cmp)
         ops.linear_bwd_weight(dba, hs, gr["sfc.w"], compute=cmp)
         self._bias_grad(db, gr["sfc.b"])
+        done("sfc.w")
         g = ws.get("grad.x", (B * T, d), zero=True)
         g16 = self._g16(g)
         ops.slice_rows(g, dhs, B, T, Tm, d, reverse_add=True)
         self._ln_bwd("dec.after", g, "dec.after", None, g, g16)
         for i in reversed(range(c.dec_blocks)):
             self.block_bwd(f"dec.{i}", g, B, T)
+            done(f"dec.{i}.ffm.ln.g")
         ops.scale(g, g, math.sqrt(d))
         self._ln_bwd("enc.after", g, "enc.after", None, g, g16)
         for i in reversed(range(c.enc_blocks)):
             self.block_bwd(f"enc.{i}", g, B, T)
+            done(f"enc.{i}.ffm.ln.g")
         # --- prologue backward
         xm, e, text, spos, tpos, masked, speech2 = self.sv["embed"]
         de = ws.get("tmp.de", (B * Tm, d))
@@ -481,3 +487,4 @@ class MLMEngine:
         s64.zero_()
         ops.col_reduce(dxm, s64, rowmask=masked.view(-1), mode=0)
         ops.f64_to_f32_add(s64, gr["mask_feature"], 1.0)
+        done("seg")

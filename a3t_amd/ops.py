@@ -257,6 +257,10 @@ def scale(x, y, s):
     L.check(L.load().a3t_scale(_ptr(x), _ptr(y), x.numel(), s, _stream()), "scale")
 
 
+def scale_dev(x, y, s):
+    L.check(L.load().a3t_scale_dev(_ptr(x), _ptr(y), x.numel(), _ptr(s), _stream()), "scale_dev")
+
+
 def axpy(x, y, a=1.0):
     L.check(L.load().a3t_axpy(_ptr(x), _ptr(y), x.numel(), a, _stream()), "axpy")
 
@@ -267,6 +271,19 @@ def cast_bf16(x, y):
 
 def slice_rows(x, y, B, T, Tm, D, reverse_add=False):
     L.check(L.load().a3t_slice_rows(_ptr(x), _ptr(y), _dt(y), B, T, Tm, D, int(reverse_add), _stream()), "slice_rows")
+
+
+def reflect_pad(x, out, pad):
+    B, N = x.shape
+    L.check(L.load().a3t_reflect_pad(_ptr(x), _ptr(out), B, N, pad, out.shape[1], _stream()), "reflect_pad")
+
+
+def stft_amp(S, amp, nbins):
+    L.check(L.load().a3t_stft_amp(_ptr(S), _ptr(amp), amp.shape[0], nbins, amp.shape[1], _stream()), "stft_amp")
+
+
+def logmel_finish(mel, olens, B, F, C):
+    L.check(L.load().a3t_logmel_finish(_ptr(mel), _ptr(olens), B, F, C, _stream()), "logmel_finish")
 
 
 def mlm_loss(before, after, target, masked, loss_out, d_before, d_after, scratch, l2=False, gscale=1.0):

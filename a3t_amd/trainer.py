@@ -1,0 +1,190 @@
+"""Training-step runtime for the MI355X path: the slice of ``Trainer.train_one_epoch``
+(espnet2/train/trainer.py:528-703) that sits on the hot path, re-designed around one flat
+gradient buffer per rank.
+
+Data parallelism = the reference's: one process per GPU, every global batch strided over ranks
+(``batch[rank::world]``, espnet2/tasks/abs_task.py:1504-1513), one gradient all-reduce per step
+(C1), scalar all-reduces for the iterator-stop flag (C3) and the reported statistics (C4).  On
+MI355X ``backend="nccl"`` is RCCL over xGMI.  Instead of DDP's 25 MB buckets fired from autograd
+hooks, the flat fp32 gradient buffer is reduced in a few large contiguous buckets on a side HIP
+stream as soon as the backward schedule has finished the parameter range each one covers
+(decoder blocks first), so the xGMI transfer overlaps the rest of the backward pass.
+"""
+import math
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .config import A3TConfig
+
+
+# ----------------------------------------------------------------------------------------------
+# pure helpers (CPU-testable with gloo)
+# ----------------------------------------------------------------------------------------------
+def shard_batches(batches: Sequence[Sequence[str]], rank: int, world: int) -> List[List[str]]:
+    """abs_task.py:1504-1513: every mini-batch (list of utterance keys) is strided over ranks;
+    the sampler guarantees len(batch) >= world (abs_task.py:1485-1487)."""
+    for b in batches:
+        if len(b) < world:
+            raise RuntimeError(f"The batch-size must be equal or more than world_size: {len(b)} < {world}")
+    return [list(b[rank::world]) for b in batches]
+
+
+def noam_lr(step: int, base_lr: float, model_size: int, warmup: int) -> float:
+    """NoamLR.get_lr (espnet2/schedulers/noam_lr.py:58-65); step = number of optimizer steps taken + 1."""
+    return base_lr * model_size ** -0.5 * min(step ** -0.5, step * warmup ** -1.5)
+
+
+def iterator_stop(local_done: bool, device="cpu") -> bool:
+    """C3: stop the epoch on every rank as soon as any rank ran out of batches (trainer.py:533-536)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_done
+    t = torch.tensor([1 if local_done else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return bool(t.item() > 0)
+
+
+def average_stats(stats: Dict[str, torch.Tensor], weight: torch.Tensor):
+    """C4: recursive_average (espnet2/torch_utils/recursive_op.py:17-44): weighted mean of every
+    statistic over ranks; returns (stats, total_weight)."""
+    w = weight.to(torch.float32).sum()
+    out = {k: (v.to(torch.float32) * w) for k, v in stats.items() if v is not None}
+    if dist.is_available() and dist.is_initialized():
+        for v in out.values():
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+    return {k: v / w for k, v in out.items()}, w
+
+
+def grad_scale(local_weight: float, total_weight: float, world: int) -> float:
+    """Loss scaling contract of trainer.py:583-595: loss_r * w_r / sum(w) * world, and the SUM
+    all-reduce is later divided by world (DDP semantics) -> net factor w_r / sum(w) per rank."""
+    return local_weight / total_weight * world
+
+
+def bucket_ranges(total: int, boundaries: Sequence[int], min_elems: int) -> List[tuple]:
+    """Contiguous [lo, hi) ranges of the flat buffer, cut at parameter-group boundaries so that a
+    bucket becomes reducible as soon as backward has passed its lowest offset; merged until each
+    holds >= min_elems (few, large collectives: xGMI rings are per-link bound)."""
+    cuts = sorted(set([0, total] + [b for b in boundaries if 0 < b < total]))
+    ranges, hi = [], total
+    for lo in reversed(cuts[:-1]):
+        if hi - lo >= min_elems or lo == 0:
+            ranges.append((lo, hi))
+            hi = lo
+    return ranges            # ordered as backward completes them: highest offsets first
+
+
+class FlatAllReduce:
+    """Bucketed all-reduce of one flat gradient buffer on a side stream."""
+
+    def __init__(self, flat_grad: torch.Tensor, ranges: List[tuple]):
+        self.g = flat_grad
+        self.ranges = ranges
+        self.cuda = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.works = []
+
+    def reduce_range(self, i: int):
+        """Call when backward has finished writing range i (on the current stream)."""
+        lo, hi = self.ranges[i]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+# ----------------------------------------------------------------------------------------------
+# the training step on the HIP engine
+# ----------------------------------------------------------------------------------------------
+class A3TTrainer:
+    """forward + loss + backward + gradient all-reduce + clip + Adam + NoamLR on flat buffers
+    (trainer.py:545,610,631-679; optimizer/scheduler of egs2/vctk/sedit/conf/fsp2_conformer.yaml:77-83)."""
+
+    def __init__(self, cfg: A3TConfig, store, compute="bf16", lr=1.0, warmup_steps=4000, grad_clip=1.0,
+                 betas=(0.9, 0.999), eps=1e-8, overlap=True):
+        from .engine import MLMEngine
+        self.cfg, self.store = cfg, store
+        self.engine = MLMEngine(cfg, store, compute=compute, training=True)
+        dev = store.device
+        self.m = torch.zeros_like(store.flat)
+        self.v = torch.zeros_like(store.flat)
+        self.partial = torch.zeros(1024, dtype=torch.float64, device=dev)
+        self.norm = torch.zeros(1, device=dev)
+        self.step_no = 0
+        self.lr, self.warmup, self.clip, self.betas, self.eps = lr, warmup_steps, grad_clip, betas, eps
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.reducer = None
+        if self.world > 1:
+            dist.broadcast(store.flat, 0)                      # C5
+            for b in store.buf.values():                       # C2 (once: BN statistics then stay rank-local)
+                dist.broadcast(b, 0)
+            bounds = [store.offsets[f"enc.{i}.ffm.ln.g"][0] for i in range(cfg.enc_blocks)]
+            bounds += [store.offsets[f"dec.{i}.ffm.ln.g"][0] for i in range(cfg.dec_blocks)]
+            bounds += [store.offsets["sfc.w"][0]]
+            self.ranges = bucket_ranges(store.total, bounds, 16 * 1024 * 1024)   # >= 64 MB fp32 per collective
+            if overlap:
+                self.reducer = FlatAllReduce(store.grad, self.ranges)
+
+    def step(self, batch: Dict[str, torch.Tensor], weight_scale: float = 1.0) -> torch.Tensor:
+        from . import ops
+        self.step_no += 1
+        st = self.store
+        st.zero_grad()
+        out = self.engine.forward(batch, gscale=weight_scale)
+        if self.reducer is not None:
+            self._backward_overlapped()
+        else:
+            self.engine.backward()
+            if self.world > 1:
+                dist.all_reduce(st.grad)
+        lr = noam_lr(self.step_no, self.lr, self.cfg.adim, self.warmup)
+        ops.sumsq(st.grad, self.partial)
+        ops.clip_adam(st.flat, st.grad, self.m, self.v, self.partial, self.norm, lr, self.step_no, clip=self.clip,
+                      gscale=1.0 / self.world, betas=self.betas, eps=self.eps)
+        return out["loss"]
+
+    def _backward_overlapped(self):
+        """Backward with per-range all-reduce hooks: a range is reduced once the schedule has moved
+        below its lowest parameter offset (ranges are ordered decoder -> encoder -> embedding)."""
+        eng, red = self.engine, self.reducer
+        state = {"next": 0}
+        lows = [lo for lo, _ in red.ranges]
+        offs = self.store.offsets
+
+        def after(name):          # called after the backward of the parameter group starting at `name`
+            lo = offs[name][0]
+            while state["next"] < len(lows) and lows[state["next"]] >= lo:
+                red.reduce_range(state["next"])
+                state["next"] += 1
+
+        eng.backward(on_group_done=after)
+        while state["next"] < len(lows):
+            red.reduce_range(state["next"])
+            state["next"] += 1
+        red.wait()
+
+    # ---- checkpoint (trainer.py:366-388: checkpoint.pth = {model, optimizers, schedulers, ...}) ----
+    def state(self):
+        return dict(model=self.store.state_dict(), optimizers=[dict(m=self.m.cpu(), v=self.v.cpu(), step=self.step_no)],
+                    schedulers=[dict(step=self.step_no, warmup_steps=self.warmup)], reporter=None, scaler=None)
+
+    def load_state(self, st):
+        self.store.load_state_dict(st["model"])
+        o = st["optimizers"][0]
+        self.m.copy_(o["m"])
+        self.v.copy_(o["v"])
+        self.step_no = int(o["step"])

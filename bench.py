@@ -42,41 +42,15 @@ def fwd_flops_per_step(c, B, Tm, Tp):
     return blocks + head
 
 
-class Trainer:
-    """Minimal mirror of Trainer.train_one_epoch's step body (espnet2/train/trainer.py:528-703)."""
-
-    def __init__(self, cfg, device, compute, world, lr=1.0, warmup=4000, clip=1.0):
-        from a3t_amd.engine import MLMEngine
-        from a3t_amd.params import ParamStore
-        from a3t_amd.init import xavier_init_
-        self.cfg, self.world = cfg, world
-        self.store = ParamStore(cfg, device)
-        xavier_init_(self.store, seed=0, bn_gamma=1.0)  # non-degenerate BN so no GEMM sees zeros
-        if world > 1:
-            dist.broadcast(self.store.flat, 0)     # C5: parameters start identical on every rank
-        self.engine = MLMEngine(cfg, self.store, compute=compute, training=True)
-        self.m = torch.zeros_like(self.store.flat)
-        self.v = torch.zeros_like(self.store.flat)
-        self.partial = torch.zeros(1024, dtype=torch.float64, device=device)
-        self.norm = torch.zeros(1, device=device)
-        self.step_no = 0
-        self.lr, self.warm, self.clip = lr, warmup, clip
-
-    def step(self, batch):
-        from a3t_amd import ops
-        self.step_no += 1
-        self.store.zero_grad()
-        out = self.engine.forward(batch)
-        self.engine.backward()
-        gscale = 1.0
-        if self.world > 1:
-            dist.all_reduce(self.store.grad)       # C1: one flat fp32 bucket over RCCL/xGMI
-            gscale = 1.0 / self.world
-        lr = self.lr * self.cfg.adim ** -0.5 * min(self.step_no ** -0.5, self.step_no * self.warm ** -1.5)
-        ops.sumsq(self.store.grad, self.partial)
-        ops.clip_adam(self.store.flat, self.store.grad, self.m, self.v, self.partial, self.norm, lr, self.step_no,
-                      clip=self.clip, gscale=gscale)
-        return out["loss"]
+def build_trainer(cfg, device, compute, world):
+    """A3TTrainer = the step body of Trainer.train_one_epoch (espnet2/train/trainer.py:528-703) on flat
+    buffers; recipe init except BatchNorm gamma = 1 so that no GEMM runs on an all-zero operand."""
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    from a3t_amd.trainer import A3TTrainer
+    store = ParamStore(cfg, device)
+    xavier_init_(store, seed=0, bn_gamma=1.0)
+    return A3TTrainer(cfg, store, compute=compute, lr=1.0, warmup_steps=4000, grad_clip=1.0)
 
 
 def cpu_baseline_worker(blocks, Tm, Tp, threads, budget_s):
@@ -175,7 +149,7 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     log("building trainer")
-    tr = Trainer(cfg, dev, a.compute, world)
+    tr = build_trainer(cfg, dev, a.compute, world)
     batch = synthetic_batch(cfg, B, Tm, Tp, seed=1234 + rank, device=dev)
     log(f"params {tr.store.n_params}; warm-up")
 

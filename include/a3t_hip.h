@@ -169,11 +169,19 @@ int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, 
 /* y = x * s (decoder entry xscale, conformer/encoder.py:585-588) */
 int a3t_scale(const float* x, float* y, int64_t n, float s, void* stream);
 int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stream); /* y += a*x */
+int a3t_scale_dev(const float* x, float* y, int64_t n, const float* s, void* stream); /* y = x * s[0], s on device */
 /* copy rows [b][0:Tm] of x[B][T][D] into y[B][Tm][D] (sedit_model.py:363) and the reverse scatter-add */
 int a3t_slice_rows(const float* x, void* y, int y_dtype, int B, int T, int Tm, int D, int reverse_add,
                    void* stream);
 /* fp32 -> bf16 (round to nearest even); n % 4 == 0 (the flat parameter buffer once per step) */
 int a3t_cast_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* Log-mel front end on the device (espnet2/layers/stft.py:56-124, log_mel.py:56-83,
+ * tts/feats_extract/log_mel_fbank.py:88-106).  The STFT is a GEMM of overlapping frames
+ * (A row stride = hop) with the windowed DFT basis; these are the element-wise stages around it. */
+int a3t_reflect_pad(const float* x, float* out, int B, int N, int pad, int ld, void* stream);
+int a3t_stft_amp(const float* S, float* amp, int64_t rows, int nbins, int ld, void* stream);
+int a3t_logmel_finish(float* mel, const int64_t* olens, int B, int F, int C, void* stream);
 
 /* Masked L1/L2 loss (sedit_model.py:320-340).  scratch: float[2 + nblk*2].
  * loss_out[0] = sum_masked(|before-y|+|after-y|)/(n_masked+1e-10); d_before/d_after = gradients

@@ -1,0 +1,66 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel path: sharding, loss-scaling contract,
+bucketed flat all-reduce, C3/C4 scalar collectives."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from a3t_amd import trainer as T
+
+
+def test_shard_batches_and_buckets():
+    batches = [["a", "b", "c", "d", "e"], ["f", "g"]]
+    assert T.shard_batches(batches, 0, 2) == [["a", "c", "e"], ["f"]]
+    assert T.shard_batches(batches, 1, 2) == [["b", "d"], ["g"]]
+    with pytest.raises(RuntimeError):
+        T.shard_batches([["a"]], 0, 2)
+    r = T.bucket_ranges(1000, [100, 300, 350, 900], 200)
+    assert r[0][1] == 1000 and r[-1][0] == 0
+    assert all(a[0] == b[1] for a, b in zip(r[:-1], r[1:]))            # contiguous, descending
+    assert all(hi - lo >= 200 for lo, hi in r[:-1])
+    assert abs(T.noam_lr(1, 1.0, 384, 4000) - 384 ** -0.5 * 4000 ** -1.5) < 1e-15
+    assert abs(T.noam_lr(4000, 1.0, 384, 4000) - 384 ** -0.5 * 4000 ** -0.5) < 1e-15
+
+
+def _worker(rank, world, init_file, out_file):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    # global batch of 5 utterances, strided over ranks; per-utterance "gradient" = f(utt)
+    keys = list(range(5))
+    mine = T.shard_batches([keys], rank, world)[0]
+    n = 1000
+    per_utt = {k: torch.from_numpy(np.random.RandomState(k).standard_normal(n).astype(np.float32)) for k in keys}
+    # rank-local mean loss gradient and weight (= local batch size)
+    g_local = torch.stack([per_utt[k] for k in mine]).mean(0)
+    w_local = torch.tensor([len(mine)])
+    stats, w_tot = T.average_stats({"loss": torch.tensor([float(sum(mine)) / len(mine)])}, w_local)
+    scale = T.grad_scale(float(w_local), float(w_tot), world)
+    flat = g_local * scale
+    ranges = T.bucket_ranges(n, [100, 400, 700], 250)
+    red = T.FlatAllReduce(flat, ranges)
+    for i in range(len(ranges)):
+        red.reduce_range(i)
+    red.wait()
+    flat /= world                                  # the DDP division (folded into clip_adam's gscale on the GPU)
+    stop = T.iterator_stop(rank == 1)
+    if rank == 0:
+        torch.save(dict(flat=flat, loss=stats["loss"], w=w_tot, stop=stop), out_file)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_equals_global_batch_mean():
+    with tempfile.TemporaryDirectory() as d:
+        init, out = os.path.join(d, "init"), os.path.join(d, "out.pt")
+        mp.spawn(_worker, args=(2, init, out), nprocs=2, join=True)
+        r = torch.load(out)
+    keys = list(range(5))
+    ref = torch.stack([torch.from_numpy(np.random.RandomState(k).standard_normal(1000).astype(np.float32))
+                       for k in keys]).mean(0)
+    np.testing.assert_allclose(r["flat"].numpy(), ref.numpy(), atol=1e-6)
+    assert abs(float(r["loss"]) - sum(keys) / 5) < 1e-6 and float(r["w"]) == 5.0
+    assert r["stop"] is True

@@ -120,3 +120,70 @@ def test_e2e_bf16_compute_within_1e2():
         if cos < 0.97 or not (0.9 < ratio < 1.1):
             bad.append((k, round(cos, 4), round(ratio, 4)))
     assert not bad, bad[:10]
+
+
+def _task_args(oc):
+    import argparse
+    enc = dict(input_layer="sega_mlm", cnn_module_kernel=oc.enc_kernel, attention_dim=oc.adim, attention_heads=oc.heads,
+               linear_units=oc.ff, num_blocks=oc.enc_blocks, macaron_style=True, use_cnn_module=True,
+               selfattention_layer_type="rel_selfattn", pos_enc_layer_type="rel_pos", positionwise_layer_type="conv1d",
+               positionwise_conv_kernel_size=3)
+    dec = dict(cnn_module_kernel=oc.dec_kernel, attention_dim=oc.adim, attention_heads=oc.heads, linear_units=oc.ff,
+               num_blocks=oc.dec_blocks, selfattention_layer_type="rel_selfattn", pos_enc_layer_type="rel_pos")
+    mc = dict(lsm_weight=0.1, mean_phn_span=8, mlm_prob=0.8, postnet_layers=oc.postnet_layers, postnet_filts=5,
+              postnet_chans=oc.postnet_chans)
+    return argparse.Namespace(token_list=[f"t{i}" for i in range(oc.vocab)], odim=80, input_size=80,
+                              feats_extract="fbank", feats_extract_conf=dict(n_fft=2048, hop_length=300,
+                                                                             win_length=1200, fs=24000, fmin=80,
+                                                                             fmax=7600, n_mels=80),
+                              normalize=None, normalize_conf={}, encoder="conformer", encoder_conf=enc,
+                              decoder="conformer", decoder_conf=dec, model_conf=mc, init=None)
+
+
+def test_plugin_model_loss_backward_and_inference():
+    """The ESPnet2 model surface: forward(**batch) -> (loss, stats, weight); loss.backward() fills p.grad."""
+    from a3t_amd.task import MLMTask
+    g = np.load(os.path.join(G, "e2e_tiny.npz"))
+    oc = O.tiny_config()
+    model = MLMTask.build_model(_task_args(oc), device=DEV)
+    state = O.procedural_state(O.param_shapes(oc), 1)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+    batch = O.synthetic_batch(oc, B=2, T_mel=48, T_phn=8, seed=11, lengths=[48, 37], text_lengths=[8, 6])
+    model.train()
+    loss, stats, weight = model(**batch)
+    assert loss.shape == (1,) and weight.tolist() == [2] and set(stats) == {"loss", "loss_mlm", "loss_copy"}
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    (loss * 2.0).backward()                       # the trainer rescales the loss (world_size / accum_grad)
+    grads = model.store.state_dict(grads=True)    # flat buffer == what autograd accumulated into p.grad
+    name = "encoder.encoders.0.feed_forward.w_1.weight"
+    np.testing.assert_allclose(grads[name].cpu().numpy(), 2.0 * g["grad." + name], atol=2e-3, rtol=1e-2)
+    pgrad = dict(model.named_parameters())["enc__0__ff__w1"].grad        # kernel layout [ff][tap][d]
+    np.testing.assert_allclose(pgrad.permute(0, 2, 1).cpu().numpy(), 2.0 * g["grad." + name], atol=2e-3, rtol=1e-2)
+    # teacher-forced infill (sedit_model.py:274-284), eval-mode BN
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+    model.eval()
+    b1 = {k: v[:1] for k, v in batch.items()}
+    with torch.no_grad():
+        out = model.inference(**b1, span_boundary=[10, 30], use_teacher_forcing=True)
+    sp = torch.cat([out["feat_gen"][0][0], out["feat_gen"][1], out["feat_gen"][2][0]], dim=0)
+    np.testing.assert_allclose(sp.cpu().numpy(), g["infer_splice"], atol=2e-4, rtol=1e-3)
+
+
+def test_logmel_and_collate_on_device():
+    from a3t_amd.collate import MLMCollateFn
+    from a3t_amd.features import LogMelFbank
+    g = np.load(os.path.join(G, "logmel.npz"))
+    fe = LogMelFbank(fs=24000, n_fft=2048, win_length=1200, hop_length=300, n_mels=80, fmin=80, fmax=7600, device=DEV)
+    feats, flen = fe(torch.from_numpy(g["wav"]), torch.from_numpy(g["lens"]))
+    assert np.array_equal(flen.cpu().numpy(), g["feats_lengths"])
+    np.testing.assert_allclose(feats.cpu().numpy(), g["feats"], atol=2e-4, rtol=0)
+    c = np.load(os.path.join(G, "collate.npz"))
+    data = [(f"utt{i}", {k: c[f"in{i}.{k}"] for k in ("speech", "text", "align_start", "align_end")}) for i in range(2)]
+    coll = MLMCollateFn(fe, float_pad_value=0.0, int_pad_value=0, mlm_prob=0.8, mean_phn_span=8, sega_emb=True)
+    np.random.seed(77)
+    uids, b = coll(data)
+    assert uids == ["utt0", "utt1"]
+    for k in ("text", "masked_position", "speech_mask", "text_mask", "speech_segment_pos", "text_segment_pos",
+              "speech_lengths", "text_lengths"):
+        assert np.array_equal(b[k].numpy(), c["out." + k]), k
+    np.testing.assert_allclose(b["speech"].numpy(), c["out.speech"], atol=2e-4)

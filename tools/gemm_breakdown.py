@@ -8,7 +8,7 @@ from a3t_amd.collate import synthetic_batch
 from a3t_amd.config import config_c2
 dev = torch.device("cuda", 0)
 cfg = config_c2()
-tr = bench.Trainer(cfg, dev, "bf16", 1)
+tr = bench.build_trainer(cfg, dev, "bf16", 1)
 batch = synthetic_batch(cfg, 32, 1000, 120, seed=1234, device=dev)
 for _ in range(2):
     tr.step(batch)
