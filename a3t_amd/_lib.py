@@ -32,7 +32,8 @@ class GemmDesc(ctypes.Structure):
         ("act", c_int32), ("accumulate", c_int32), ("splitk", c_int32),
         ("a_dtype", c_int32), ("b_dtype", c_int32), ("c_dtype", c_int32), ("compute", c_int32),
         ("s_dtype", c_int32), ("reserved", c_int32),
-        ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("reserved2", c_int32),
+        ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("drop_key", ctypes.c_uint32),
+        ("drop_p", c_float), ("reserved3", c_int32),
     ]
 
 
@@ -50,11 +51,15 @@ _SIGS = {
     "a3t_glu_dwconv_bwd": [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_add_pos_bias": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_add_pos_bias_bwd": [_P, _P, _P, c_int, c_int, c_int, _P],
-    "a3t_relpos_softmax_fwd": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P],
-    "a3t_relpos_softmax_bwd": [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P],
+    "a3t_relpos_softmax_fwd": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
+                               c_float, ctypes.c_uint32, _P],
+    "a3t_relpos_softmax_bwd": [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
+                               c_float, _P],
     "a3t_mask_fill": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
-    "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P],
-    "a3t_embed_finish_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint32,
+                             _P],
+    "a3t_embed_finish_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                             ctypes.c_uint32, _P],
     "a3t_scale": [_P, _P, c_int64, c_float, _P],
     "a3t_axpy": [_P, _P, c_int64, c_float, _P],
     "a3t_scale_dev": [_P, _P, c_int64, _P, _P],
@@ -73,7 +78,8 @@ _SIGS = {
     "a3t_pwg_upsample": [_P, _P, _P, c_int64, c_int, c_int, _P],
     "a3t_replicate_pad": [_P, _P, c_int64, c_int, c_int, _P],
     "a3t_bias_act": [_P, _P, c_int64, c_int, c_int, c_float, _P],
-    "a3t_dropout": [_P, _P, c_int64, c_float, c_uint64, c_uint64, _P],
+    "a3t_dropout": [_P, c_int, _P, c_int, c_int64, c_float, ctypes.c_uint32, c_float, _P],
+    "a3t_dropout_bwd_cast": [_P, _P, c_int, _P, c_float, c_int, c_int, c_float, ctypes.c_uint32, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["a3t_version"])
 

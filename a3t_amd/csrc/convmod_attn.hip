@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
                                                                  const uint8_t* __restrict__ keymask,
                                                                  void* __restrict__ probs, int p_dt, int H, int T,
                                                                  int64_t ac_bs, int64_t bd_bs, int64_t p_bs,
-                                                                 float scale, int64_t nrows) {
+                                                                 float scale, int64_t nrows, void* __restrict__ pdrop,
+                                                                 unsigned int thr, float inv, unsigned int key) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -283,11 +284,15 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
             s += v[q];
         }
         s = wsum(s);
-        const float inv = s > 0.f ? 1.f / s : 0.f;
+        const float inv_s = s > 0.f ? 1.f / s : 0.f;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             int j = lane + q * 64;
-            if (j < T) stx(probs, p_dt, po + j, v[q] * inv);
+            if (j < T) {
+                const float pj = v[q] * inv_s;
+                stx(probs, p_dt, po + j, pj);
+                if (pdrop) stx(pdrop, p_dt, po + j, rng_keep(key, (unsigned int)(po + j), thr) ? pj * inv : 0.f);
+            }
         }
         return;
     }
@@ -301,16 +306,22 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     mx = wmax(mx);
     any = __any(any);
     if (!any) {  // every key padded: softmax over equal fills then masked_fill(0) -> zeros
-        for (int j = lane; j < T; j += 64) stx(probs, p_dt, po + j, 0.f);
+        for (int j = lane; j < T; j += 64) {
+            stx(probs, p_dt, po + j, 0.f);
+            if (pdrop) stx(pdrop, p_dt, po + j, 0.f);
+        }
         return;
     }
     float s = 0.f;
     for (int j = lane; j < T; j += 64)
         if (mk[j]) s += expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx);
     s = wsum(s);
-    const float inv = 1.f / s;
-    for (int j = lane; j < T; j += 64)
-        stx(probs, p_dt, po + j, mk[j] ? expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx) * inv : 0.f);
+    const float inv_s = 1.f / s;
+    for (int j = lane; j < T; j += 64) {
+        const float pj = mk[j] ? expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx) * inv_s : 0.f;
+        stx(probs, p_dt, po + j, pj);
+        if (pdrop) stx(pdrop, p_dt, po + j, rng_keep(key, (unsigned int)(po + j), thr) ? pj * inv : 0.f);
+    }
 }
 
 #define SM_DISPATCH(T, CALL)               \
@@ -325,11 +336,17 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
 
 extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, void* probs,
                                       int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs,
-                                      int64_t p_bs, float scale, void* stream) {
+                                      int64_t p_bs, float scale, void* probs_drop, float drop_p, uint32_t drop_key,
+                                      void* stream) {
     int64_t nrows = (int64_t)B * H * T;
+    if (drop_p < 0.f || drop_p >= 1.f) return A3T_EINVAL;
+    if (drop_p == 0.f) probs_drop = nullptr;
+    const unsigned int thr = (unsigned int)((double)drop_p * 4294967296.0);
+    const float dinv = 1.f / (1.f - drop_p);
 #define CALL(NV)                                                                                                 \
     hipLaunchKernelGGL(relpos_softmax_fwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
-                       (hipStream_t)stream, ac, bd, keymask, probs, probs_dtype, H, T, ac_bs, bd_bs, p_bs, scale, nrows)
+                       (hipStream_t)stream, ac, bd, keymask, probs, probs_dtype, H, T, ac_bs, bd_bs, p_bs, scale, nrows, \
+                       probs_drop, thr, dinv, drop_key)
     SM_DISPATCH(T, CALL);
 #undef CALL
     return (int)hipGetLastError();
@@ -341,7 +358,14 @@ template <int NV>
 __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __restrict__ probs, int p_dt,
                                                                  const float* dprobs, void* ds, void* __restrict__ dbd,
                                                                  int o_dt, int T, int64_t p_bs, int64_t dp_bs,
-                                                                 int64_t o_bs, float scale, int64_t nrows) {
+                                                                 int64_t o_bs, float scale, int64_t nrows,
+                                                                 const void* __restrict__ pdrop, float dinv) {
+    // attention dropout: dprobs is the gradient of the DROPPED probabilities; the mask is read off the
+    // saved dropped tensor (pdrop != 0), so no RNG replay is needed: dP = dPd * mask/(1-p)
+    auto dpv = [&](int64_t pidx, float d) -> float {
+        if (!pdrop) return d;
+        return (ldx(pdrop, p_dt, pidx) != 0.f) ? d * dinv : 0.f;
+    };
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -357,11 +381,11 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
         for (int q = 0; q < NV; ++q) {
             int j = lane + q * 64;
             pv[q] = (j < T) ? ldx(probs, p_dt, po + j) : 0.f;
-            dv[q] = (j < T) ? dr[j] : 0.f;
+            dv[q] = (j < T) ? dpv(po + j, dr[j]) : 0.f;
             s += pv[q] * dv[q];
         }
     } else {
-        for (int j = lane; j < T; j += 64) s += ldx(probs, p_dt, po + j) * dr[j];
+        for (int j = lane; j < T; j += 64) s += ldx(probs, p_dt, po + j) * dpv(po + j, dr[j]);
     }
     s = wsum(s);
     auto emit = [&](int j, float v) {
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
             if (j < T) emit(j, pv[q] * (dv[q] - s) * scale);
         }
     } else {
-        for (int j = lane; j < T; j += 64) emit(j, ldx(probs, p_dt, po + j) * (dr[j] - s) * scale);
+        for (int j = lane; j < T; j += 64) emit(j, ldx(probs, p_dt, po + j) * (dpv(po + j, dr[j]) - s) * scale);
     }
     if (i == 0)  // BD[0][0..T-2] never reaches the scores
         for (int j = lane; j < T - 1; j += 64) stx(dbd, o_dt, oz + j, 0.f);
@@ -386,11 +410,14 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
 
 extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const float* dprobs, void* ds, void* dbd,
                                       int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
-                                      float scale, void* stream) {
+                                      float scale, const void* probs_drop, float drop_p, void* stream) {
+    const float dinv = 1.f / (1.f - drop_p);
+    if (drop_p == 0.f) probs_drop = nullptr;
     int64_t nrows = (int64_t)B * H * T;
 #define CALL(NV)                                                                                                 \
     hipLaunchKernelGGL(relpos_softmax_bwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
-                       (hipStream_t)stream, probs, probs_dtype, dprobs, ds, dbd, out_dtype, T, p_bs, dp_bs, o_bs, scale, nrows)
+                       (hipStream_t)stream, probs, probs_dtype, dprobs, ds, dbd, out_dtype, T, p_bs, dp_bs, o_bs, scale, nrows, \
+                       probs_drop, dinv)
     SM_DISPATCH(T, CALL);
 #undef CALL
     return (int)hipGetLastError();

@@ -11,6 +11,21 @@ __device__ __forceinline__ unsigned short io_f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float io_bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+// Counter-based dropout RNG: keep(key, idx) is a pure function, so forward and backward kernels
+// (and GEMM epilogues) regenerate the same mask from (key, element index) with no stored state.
+__device__ __forceinline__ unsigned int rng_fmix32(unsigned int h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ bool rng_keep(unsigned int key, unsigned int idx, unsigned int thr) {
+    return rng_fmix32(rng_fmix32(idx * 0x9E3779B1u + key) ^ key) >= thr;
+}
+__device__ __forceinline__ unsigned int rng_thr(float p) { return (unsigned int)((double)p * 4294967296.0); }
+
 __device__ __forceinline__ float ldx(const void* p, int dt, int64_t i) {
     return dt == A3T_BF16 ? io_bf2f(((const unsigned short*)p)[i]) : ((const float*)p)[i];
 }

@@ -448,6 +448,10 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.s_dtype = d->s_dtype;
     p.epi_vec = 0;
     p.colsum = d->colsum, p.colsum_bs1 = d->colsum_bs1, p.colsum_scale = d->colsum_scale;
+    if (d->drop_p < 0.f || d->drop_p >= 1.f) return A3T_EINVAL;
+    p.drop_key = d->drop_key;
+    p.drop_thr = (unsigned int)((double)d->drop_p * 4294967296.0);
+    p.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 0.f;
     if (p.c_dtype == A3T_BF16 && p.accumulate != A3T_ACC_STORE) return A3T_EINVAL;
     const bool AK = (d->a_cs == 1), BKC = (d->b_cs == 1);
     if (!AK && d->a_rs != 1) return A3T_EINVAL;

@@ -298,6 +298,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
             v.x = sv.x > 0.f ? v.x : 0.f, v.y = sv.y > 0.f ? v.y : 0.f;
             v.z = sv.z > 0.f ? v.z : 0.f, v.w = sv.w > 0.f ? v.w : 0.f;
         }
+        if (p.drop_inv > 0.f) {
+            const unsigned int i0 = (unsigned int)idx;
+            v.x = rng_keep(p.drop_key, i0 + 0, p.drop_thr) ? v.x * p.drop_inv : 0.f;
+            v.y = rng_keep(p.drop_key, i0 + 1, p.drop_thr) ? v.y * p.drop_inv : 0.f;
+            v.z = rng_keep(p.drop_key, i0 + 2, p.drop_thr) ? v.z * p.drop_inv : 0.f;
+            v.w = rng_keep(p.drop_key, i0 + 3, p.drop_thr) ? v.w * p.drop_inv : 0.f;
+        }
         v.x *= p.alpha, v.y *= p.alpha, v.z *= p.alpha, v.w *= p.alpha;
         if (p.R && ks == 0) {
             float4 rv = *(const float4*)(p.R + idx);

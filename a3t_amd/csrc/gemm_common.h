@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/a3t_hip.h"
+#include "dtype_io.h"
 
 struct GP {
     const void* A;
@@ -21,6 +22,8 @@ struct GP {
     float* colsum;
     int64_t colsum_bs1;
     float colsum_scale;
+    unsigned int drop_key, drop_thr;
+    float drop_inv;   // 1/(1-p), 0 when dropout is off
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -88,6 +91,7 @@ __device__ __forceinline__ void epilogue_store(const GP& p, int64_t zoff, int ro
         float sv = (p.s_dtype == A3T_BF16) ? bf2f(((const unsigned short*)p.S)[idx]) : p.S[idx];
         v = (sv > 0.f) ? v : 0.f;
     }
+    if (p.drop_inv > 0.f) v = rng_keep(p.drop_key, (unsigned int)idx, p.drop_thr) ? v * p.drop_inv : 0.f;
     v *= p.alpha;
     if (p.R && ks == 0) v += p.R[idx];
     if (p.c_dtype == A3T_BF16) {

@@ -33,37 +33,43 @@ extern "C" int a3t_mask_fill(const float* speech, const uint8_t* masked, const f
 __global__ void embed_finish_fwd_kernel(const float* __restrict__ e, const float* __restrict__ emb,
                                         const float* __restrict__ seg, const int64_t* __restrict__ text,
                                         const int64_t* __restrict__ spos, const int64_t* __restrict__ tpos,
-                                        float* __restrict__ xs, int B, int Tm, int Tp, int D, float xscale) {
+                                        float* __restrict__ xs, int B, int Tm, int Tp, int D, float xscale,
+                                        unsigned int thr, float inv, unsigned int key) {
     const int T = Tm + Tp;
     const int64_t n = (int64_t)B * T * D;
     GRID_STRIDE(i, n) {
         int64_t row = i / D;
         int c = (int)(i - row * D);
         int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
-        float v;
+        float v, sg;
         if (t < Tm) {
             int64_t r = (int64_t)b * Tm + t;
-            v = fmaxf(e[r * D + c], 0.f) * xscale + seg[spos[r] * D + c];
+            v = fmaxf(e[r * D + c], 0.f) * xscale;
+            sg = seg[spos[r] * D + c];
         } else {
             int64_t r = (int64_t)b * Tp + (t - Tm);
-            v = emb[text[r] * D + c] * xscale + seg[tpos[r] * D + c];
+            v = emb[text[r] * D + c] * xscale;
+            sg = seg[tpos[r] * D + c];
         }
-        xs[i] = v;
+        if (inv > 0.f) v = rng_keep(key, (unsigned int)i, thr) ? v * inv : 0.f;   // positional dropout, before + seg
+        xs[i] = v + sg;
     }
 }
 extern "C" int a3t_embed_finish_fwd(const float* e, const float* emb, const float* seg, const int64_t* text,
                                     const int64_t* spos, const int64_t* tpos, float* xs, int B, int Tm, int Tp, int D,
-                                    float xscale, void* stream) {
+                                    float xscale, float drop_p, uint32_t drop_key, void* stream) {
     int64_t n = (int64_t)B * (Tm + Tp) * D;
     hipLaunchKernelGGL(embed_finish_fwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, e, emb, seg, text,
-                       spos, tpos, xs, B, Tm, Tp, D, xscale);
+                       spos, tpos, xs, B, Tm, Tp, D, xscale, (unsigned int)((double)drop_p * 4294967296.0),
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f, drop_key);
     return (int)hipGetLastError();
 }
 
 __global__ void embed_finish_bwd_kernel(const float* __restrict__ dxs, const float* __restrict__ e,
                                         const int64_t* __restrict__ text, const int64_t* __restrict__ spos,
                                         const int64_t* __restrict__ tpos, float* __restrict__ de, float* demb,
-                                        float* dseg, int B, int Tm, int Tp, int D, int V, int nseg, float xscale) {
+                                        float* dseg, int B, int Tm, int Tp, int D, int V, int nseg, float xscale,
+                                        unsigned int thr, float inv, unsigned int key) {
     const int T = Tm + Tp;
     const int64_t n = (int64_t)B * T * D;
     GRID_STRIDE(i, n) {
@@ -71,15 +77,17 @@ __global__ void embed_finish_bwd_kernel(const float* __restrict__ dxs, const flo
         int c = (int)(i - row * D);
         int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
         float g = dxs[i];
+        float gd = g;                                            // gradient through the positional dropout
+        if (inv > 0.f) gd = rng_keep(key, (unsigned int)i, thr) ? g * inv : 0.f;
         if (t < Tm) {
             int64_t r = (int64_t)b * Tm + t;
-            de[r * D + c] = (e[r * D + c] > 0.f) ? g * xscale : 0.f;
+            de[r * D + c] = (e[r * D + c] > 0.f) ? gd * xscale : 0.f;
             int64_t s = spos[r];
             if (s != nseg - 1) atomicAdd(&dseg[s * D + c], g);  // padding_idx=-1 -> last row gets no grad
         } else {
             int64_t r = (int64_t)b * Tp + (t - Tm);
             int64_t tok = text[r];
-            if (tok != V - 1) atomicAdd(&demb[tok * D + c], g * xscale);
+            if (tok != V - 1) atomicAdd(&demb[tok * D + c], gd * xscale);
             int64_t s = tpos[r];
             if (s != nseg - 1) atomicAdd(&dseg[s * D + c], g);
         }
@@ -87,10 +95,13 @@ __global__ void embed_finish_bwd_kernel(const float* __restrict__ dxs, const flo
 }
 extern "C" int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, const int64_t* spos,
                                     const int64_t* tpos, float* de, float* demb, float* dseg, int B, int Tm, int Tp,
-                                    int D, int V, int nseg, float xscale, void* stream) {
+                                    int D, int V, int nseg, float xscale, float drop_p, uint32_t drop_key,
+                                    void* stream) {
     int64_t n = (int64_t)B * (Tm + Tp) * D;
     hipLaunchKernelGGL(embed_finish_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, dxs, e, text, spos,
-                       tpos, de, demb, dseg, B, Tm, Tp, D, V, nseg, xscale);
+                       tpos, de, demb, dseg, B, Tm, Tp, D, V, nseg, xscale,
+                       (unsigned int)((double)drop_p * 4294967296.0), drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f,
+                       drop_key);
     return (int)hipGetLastError();
 }
 
@@ -406,25 +417,51 @@ extern "C" int a3t_bias_act(float* x, const float* bias, int64_t M, int C, int a
     return (int)hipGetLastError();
 }
 
-// ---------------------------------------------------------------- dropout (splitmix64 counter RNG)
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__global__ void dropout_kernel(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset) {
-    const float inv = 1.f / (1.f - p);
-    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+// ---------------------------------------------------------------- dropout (counter RNG, dtype_io.h)
+__global__ void dropout_kernel(const void* x, int x_dt, void* y, int y_dt, int64_t n, unsigned int thr, float inv,
+                               unsigned int key, float scale) {
     GRID_STRIDE(i, n) {
-        uint64_t r = mix64(seed ^ mix64(offset + (uint64_t)i));
-        y[i] = ((uint32_t)r >= thr) ? x[i] * inv : 0.f;
+        float v = ldx(x, x_dt, i) * scale;
+        stx(y, y_dt, i, rng_keep(key, (unsigned int)i, thr) ? v * inv : 0.f);
     }
 }
-extern "C" int a3t_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset,
-                           void* stream) {
+extern "C" int a3t_dropout(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, float p, uint32_t key,
+                           float scale, void* stream) {
     if (p < 0.f || p >= 1.f) return A3T_EINVAL;
-    hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, seed, offset);
+    hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, y_dtype, n,
+                       (unsigned int)((double)p * 4294967296.0), 1.f / (1.f - p), key, scale);
+    return (int)hipGetLastError();
+}
+// backward of "x + alpha*dropout(branch)": gm = g * mask/(1-p) (operand of the branch's GEMMs, fp32 or bf16)
+// and colsum[c] += colsum_scale * sum_m gm[m][c] (the branch's bias gradient)
+__global__ __launch_bounds__(256) void dropout_bwd_cast_kernel(const float* __restrict__ g, void* __restrict__ gm,
+                                                               int gm_dt, float* colsum, float colsum_scale, int M,
+                                                               int C, unsigned int thr, float inv, unsigned int key,
+                                                               int rows_per_block) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + ty; r < r1; r += 4) {
+            int64_t i = (int64_t)r * C + c;
+            float v = rng_keep(key, (unsigned int)i, thr) ? g[i] * inv : 0.f;
+            stx(gm, gm_dt, i, v);
+            s += v;
+        }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (colsum && ty == 0 && c < C)
+        atomicAdd(&colsum[c], colsum_scale * (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]));
+}
+extern "C" int a3t_dropout_bwd_cast(const float* g, void* gm, int gm_dtype, float* colsum, float colsum_scale, int M,
+                                    int C, float p, uint32_t key, void* stream) {
+    if (p < 0.f || p >= 1.f) return A3T_EINVAL;
+    int rpb = 128;
+    dim3 grid((C + 63) / 64, (M + rpb - 1) / rpb);
+    hipLaunchKernelGGL(dropout_bwd_cast_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, gm, gm_dtype, colsum,
+                       colsum_scale, M, C, (unsigned int)((double)p * 4294967296.0), 1.f / (1.f - p), key, rpb);
     return (int)hipGetLastError();
 }
 

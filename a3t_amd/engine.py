@@ -15,6 +15,7 @@ Two numeric modes:
                    optimizer stay fp32  (throughput path, 1e-2)
 """
 import math
+import zlib
 from typing import Dict
 
 import torch
@@ -59,8 +60,14 @@ class Workspace:
 
 
 class MLMEngine:
-    def __init__(self, cfg: A3TConfig, store: ParamStore, compute: str = "f32", training: bool = True):
+    def __init__(self, cfg: A3TConfig, store: ParamStore, compute: str = "f32", training: bool = True,
+                 dropout: bool = False):
+        """dropout=True enables the recipe's Dropout sites (dropout_rate / positional / attention rates of
+        the config, 0.5 in the postnet) in training mode; masks come from a counter RNG keyed by
+        (step seed, site), regenerated in the backward pass."""
         self.c = cfg
+        self.dropping = bool(dropout and training)
+        self.step_seed = 0
         self.store = store
         self.dev = store.device
         self.ws = Workspace(self.dev)
@@ -82,6 +89,25 @@ class MLMEngine:
             self.p16 = {k: self.flat16[o:o + math.prod(s)].view(s) for k, (o, s) in store.offsets.items()}
 
     # ------------------------------------------------------------------ helpers
+    def _drop(self, p, tag):
+        """(p, key) of one dropout site for the current step, or None when dropout is off."""
+        if not self.dropping or p <= 0.0:
+            return None
+        h = (zlib.crc32(tag.encode()) ^ ((self.step_seed * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        h = ((h ^ (h >> 16)) * 0x85EBCA6B) & 0xFFFFFFFF
+        h = ((h ^ (h >> 13)) * 0xC2B2AE35) & 0xFFFFFFFF
+        return (float(p), (h ^ (h >> 16)) & 0xFFFFFFFF)
+
+    def _gm(self, g, tag, p, bias_grad, bias_scale):
+        """Gradient entering a "residual + a*dropout(branch)" sub-layer: the GEMM operand (bf16 on the
+        bf16 path) and, with dropout on, the masked gradient + the branch's output-bias gradient."""
+        dr = self._drop(p, tag)
+        if dr is None:
+            return (self._g16(g) if self.bf16 else g)
+        gm = self.ws.get("tmp.gm", tuple(g.shape), self.adt)
+        ops.dropout_bwd_cast(g, gm, dr[0], dr[1], colsum=bias_grad, colsum_scale=bias_scale)
+        return gm
+
     def W(self, name):
         """GEMM-operand view of a parameter (bf16 shadow in bf16 mode)."""
         return self.p16[name] if self.bf16 else self.store.p[name]
@@ -108,6 +134,8 @@ class MLMEngine:
         its bias gradient is the column sum of dx; fused into the kernel on the bf16 path."""
         p, g = self.store.p, self.store.g
         x, _, mean, rstd = self.sv[tag]
+        if self.dropping and self.c.dropout_rate > 0:
+            nb = None          # with dropout the bias gradients come from the masked gradient (_gm)
         fuse = self.bf16 and nb is not None
         ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=dx16,
                           dxsum=nb[0] if fuse else None, dxsum_scale=nb[1] if fuse else 1.0)
@@ -128,9 +156,11 @@ class MLMEngine:
         pad = (c.ff_kernel - 1) // 2
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
         h = self._act(tag + ".h", (M, c.ff))
-        ops.conv_fwd(y, self.W(pre + ".w1"), h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=self.cmp)
+        ops.conv_fwd(y, self.W(pre + ".w1"), h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=self.cmp,
+                     drop=self._drop(c.dropout_rate, tag + ".h"))
         xo = self.ws.get(tag + ".xo", (M, c.adim))
-        ops.conv_fwd(h, self.W(pre + ".w2"), xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=self.cmp)
+        ops.conv_fwd(h, self.W(pre + ".w2"), xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=self.cmp,
+                     drop=self._drop(c.dropout_rate, tag + ".o"))
         self.sv[tag] = (y, h)
         return xo
 
@@ -142,11 +172,13 @@ class MLMEngine:
         M = g.shape[0]
         pad = (c.ff_kernel - 1) // 2
         g16 = self._g16(g)
-        ga = g16 if self.bf16 else g
+        ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".b2"], 0.5)
         dh = self._act("tmp.dh", (M, c.ff))
-        # (b2's gradient = 0.5*colsum(g) was accumulated by the LayerNorm backward that produced g)
-        ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=0.5, compute=self.cmp,
-                          colsum=gr[pre + ".b1"] if self.bf16 else None)
+        # (without dropout b2's gradient = 0.5*colsum(g) was accumulated by the LayerNorm backward that
+        #  produced g; the dropout on h folds into the relu mask S=h>0 and the 1/(1-p) factor)
+        hd = self._drop(c.dropout_rate, tag + ".h")
+        ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=0.5 / (1.0 - hd[0]) if hd else 0.5,
+                          compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
         ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp)
         dy = self._act("tmp.dy", (M, c.adim))
         ops.conv_bwd_data(dh, self.W(pre + ".w1"), dy, T, pad, compute=self.cmp)
@@ -180,14 +212,18 @@ class MLMEngine:
         ops.gemm(qv, P, bd, T, T, dk, d, 1, d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(0, dk),
                  c_bs=(H * T * T, T * T), compute=cmp)
         probs = self._act(tag + ".probs", (B, H, T, T))
-        ops.relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, 1.0 / math.sqrt(dk))
+        adr = self._drop(c.attention_dropout_rate, tag + ".att")
+        pdrop = self._act(tag + ".pdrop", (B, H, T, T)) if adr else None
+        ops.relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, 1.0 / math.sqrt(dk), probs_drop=pdrop,
+                               drop=adr or (0.0, 0))
         ctx = self._act(tag + ".ctx", (M, d))
-        # ctx[b,:,h,:] = probs[b,h] V[b,h]
-        ops.gemm(probs, vv, ctx, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=(H * T * T, T * T),
-                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp)
+        # ctx[b,:,h,:] = dropout(probs[b,h]) V[b,h]
+        ops.gemm(pdrop if adr else probs, vv, ctx, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H,
+                 a_bs=(H * T * T, T * T), b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp)
         xo = self.ws.get(tag + ".xo", (M, d))
-        ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp)
-        self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos)
+        ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
+                       drop=self._drop(c.dropout_rate, tag + ".o"))
+        self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos, pdrop)
         return xo
 
     def _mha_bwd(self, tag, pre, g, B, T, nb=None):
@@ -195,10 +231,10 @@ class MLMEngine:
         d, H, dk = c.adim, c.heads, c.dk
         M = B * T
         cmp = self.cmp
-        y, qkv, qu, qv, P, probs, ctx, pos = self.sv[tag]
+        y, qkv, qu, qv, P, probs, ctx, pos, pdrop = self.sv[tag]
         scale = 1.0 / math.sqrt(dk)
         g16 = self._g16(g)
-        ga = g16 if self.bf16 else g
+        ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".bo"], 1.0)
         dctx = self._act("tmp.dctx", (M, d))
         ops.linear_bwd_data(ga, self.W(pre + ".wo"), dctx, compute=cmp)
         ops.linear_bwd_weight(ga, ctx, gr[pre + ".wo"], compute=cmp)
@@ -215,7 +251,8 @@ class MLMEngine:
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
         fz = self.bf16   # bias / pos-bias gradients ride on the GEMM epilogues as column sums
         gbq = gr[pre + ".bqkv"]
-        ops.gemm(probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb,
+        ops.gemm(pdrop if pdrop is not None else probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H,
+                 batch_inner=H, a_bs=zb,
                  b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp, colsum=gbq[2 * d:] if fz else None,
                  colsum_bs1=dk)
         if self.bf16:
@@ -224,7 +261,8 @@ class MLMEngine:
         else:
             ds = dpr
             dbd = self.ws.get("tmp.bd", (B, H, T, T))
-        ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale)
+        ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=pdrop,
+                               drop_p=c.attention_dropout_rate if pdrop is not None else 0.0)
         dqu = self._act("tmp.dqu", (M, d))
         dqv = self._act("tmp.dqv", (M, d))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
@@ -296,7 +334,8 @@ class MLMEngine:
         s = self._act(tag + ".s", (M, d))
         self._bn_fwd(tag, z, pre + ".bn", pre + ".bn", ACT_SWISH, s)
         xo = self.ws.get(tag + ".xo", (M, d))
-        ops.linear_fwd(s, self.W(pre + ".pw2"), xo, bias=p[pre + ".pb2"], R=x, compute=cmp)
+        ops.linear_fwd(s, self.W(pre + ".pw2"), xo, bias=p[pre + ".pb2"], R=x, compute=cmp,
+                       drop=self._drop(c.dropout_rate, tag + ".o"))
         self.sv[tag] = (y, g2, glu, s)
         return xo
 
@@ -306,7 +345,7 @@ class MLMEngine:
         cmp = self.cmp
         y, g2, glu, s = self.sv[tag]
         g16 = self._g16(g)
-        ga = g16 if self.bf16 else g
+        ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".pb2"], 1.0)
         ds = self.ws.get("tmp.ds", (M, d))
         ops.linear_bwd_data(ga, self.W(pre + ".pw2"), ds, compute=cmp)
         ops.linear_bwd_weight(ga, s, gr[pre + ".pw2"], compute=cmp)
@@ -351,7 +390,9 @@ class MLMEngine:
         if self.bf16 and (T % 8 or Tm % 8):
             raise ValueError(f"compute='bf16' needs T_mel and T_mel+T_phn to be multiples of 8, got {Tm}, {T}")
         self.dims = (B, Tm, Tp, T)
+        self.step_seed += 1
         self.refresh_weights()
+        pp = c.positional_dropout_rate
         masked = batch["masked_position"].contiguous().view(torch.uint8)
         keymask = ws.get("keymask", (B, T), torch.uint8)
         keymask[:, :Tm].copy_(batch["speech_mask"].reshape(B, Tm).view(torch.uint8))
@@ -367,12 +408,21 @@ class MLMEngine:
         e = self._ln_fwd("emb.ln", e0, "emb.ln", eps=1e-5, out_dtype=torch.float32)
         xs = ws.get("emb.xs", (B * T, d))
         xscale = math.sqrt(d)
-        ops.embed_finish_fwd(e, p["temb"], p["seg"], text, spos, tpos, xs, B, Tm, Tp, d, xscale)
+        ops.embed_finish_fwd(e, p["temb"], p["seg"], text, spos, tpos, xs, B, Tm, Tp, d, xscale,
+                             drop=self._drop(pp, "emb.x") or (0.0, 0))
         pos_e = self._act("pos.enc", (T, d))
-        pos_e[:Tm].copy_(self.pe[:Tm])
-        pos_e[Tm:].copy_(self.pe[:Tp])
         pos_d = self._act("pos.dec", (T, d))
-        pos_d.copy_(self.pe[:T])
+        if self._drop(pp, "pos.enc"):      # dropout(pos_emb) (embedding.py:170)
+            pf = ws.get("pos.f32", (T, d))
+            pf[:Tm].copy_(self.pe[:Tm])
+            pf[Tm:].copy_(self.pe[:Tp])
+            ops.dropout(pf, pos_e, *self._drop(pp, "pos.enc"))
+            pf.copy_(self.pe[:T])
+            ops.dropout(pf, pos_d, *self._drop(pp, "pos.dec"))
+        else:
+            pos_e[:Tm].copy_(self.pe[:Tm])
+            pos_e[Tm:].copy_(self.pe[:Tp])
+            pos_d.copy_(self.pe[:T])
         self.sv["embed"] = (xm, e, text, spos, tpos, masked, speech2)
         x = xs
         for i in range(c.enc_blocks):
@@ -380,7 +430,11 @@ class MLMEngine:
         x = self._ln_fwd("enc.after", x, "enc.after", out_dtype=torch.float32)
         # --- decoder (conformer/encoder.py:568-614): x*sqrt(d), contiguous rel-pos table
         xd = ws.get("dec.in", (B * T, d))
-        ops.scale(x, xd, xscale)
+        dd = self._drop(pp, "dec.x")
+        if dd:
+            ops.dropout(x, xd, dd[0], dd[1], scale=xscale)
+        else:
+            ops.scale(x, xd, xscale)
         x = xd
         for i in range(c.dec_blocks):
             x = self.block_fwd(f"dec.{i}", x, pos_d, keymask, B, T)
@@ -403,6 +457,9 @@ class MLMEngine:
             ops.conv_fwd(y, W, z, Tm, pad, compute=self.cmp)
             o = ws.get(f"post.{l}.o", (B * Tm, oc), torch.float32 if last else self.adt)
             self._bn_fwd(f"post.{l}", z, f"post.{l}.bn", f"post.{l}.bn", ACT_NONE if last else ACT_TANH, o)
+            pdr = self._drop(c.postnet_dropout_rate, f"post.{l}")
+            if pdr:
+                ops.dropout(o, o, *pdr)
             self.sv[f"post.{l}"] = y
             y = o
         if c.postnet_layers > 0:
@@ -437,6 +494,11 @@ class MLMEngine:
                 oc = W.shape[0]
                 last = (l == c.postnet_layers - 1)
                 dz = ws.get(f"tmp.post.dz{oc}", (B * Tm, oc))
+                pdr = self._drop(c.postnet_dropout_rate, f"post.{l}")
+                if pdr:
+                    gd = ws.get(f"tmp.post.gd{oc}", (B * Tm, oc))
+                    ops.dropout(g, gd, *pdr)
+                    g = gd
                 self._bn_bwd(f"post.{l}", g, f"post.{l}.bn", ACT_NONE if last else ACT_TANH, dz)
                 if self.bf16:
                     dz16 = ws.get(f"tmp.post.dz16.{oc}", (B * Tm, oc), torch.bfloat16)
@@ -466,7 +528,11 @@ class MLMEngine:
         for i in reversed(range(c.dec_blocks)):
             self.block_bwd(f"dec.{i}", g, B, T)
             done(f"dec.{i}.ffm.ln.g")
-        ops.scale(g, g, math.sqrt(d))
+        dd = self._drop(c.positional_dropout_rate, "dec.x")
+        if dd:
+            ops.dropout(g, g, dd[0], dd[1], scale=math.sqrt(d))
+        else:
+            ops.scale(g, g, math.sqrt(d))
         self._ln_bwd("enc.after", g, "enc.after", None, g, g16)
         for i in reversed(range(c.enc_blocks)):
             self.block_bwd(f"enc.{i}", g, B, T)
@@ -475,7 +541,7 @@ class MLMEngine:
         xm, e, text, spos, tpos, masked, speech2 = self.sv["embed"]
         de = ws.get("tmp.de", (B * Tm, d))
         ops.embed_finish_bwd(g, e, text, spos, tpos, de, gr["temb"], gr["seg"], B, Tm, Tp, d, c.vocab, c.seg_table,
-                             math.sqrt(d))
+                             math.sqrt(d), drop=self._drop(c.positional_dropout_rate, "emb.x") or (0.0, 0))
         de0 = ws.get("tmp.de0", (B * Tm, d))
         de16 = ws.get("tmp.de016", (B * Tm, d), torch.bfloat16) if self.bf16 else None
         self._ln_bwd("emb.ln", de, "emb.ln", None, de0, de16, (gr["emb.b"], 1.0))

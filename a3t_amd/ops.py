@@ -46,7 +46,8 @@ def _dt(t):
 
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
-         act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0):
+         act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
+         drop=None):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -66,6 +67,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.s_dtype = _dt(S) if S is not None else F32
     d.colsum = colsum.data_ptr() if colsum is not None else None
     d.colsum_bs1, d.colsum_scale = colsum_bs1, colsum_scale
+    d.drop_p, d.drop_key = (drop if drop is not None else (0.0, 0))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -86,10 +88,10 @@ def _splitk_for(n_tiles, K, target=512, ktile=64):
 
 
 # ---- y = x W^T (+bias): torch.nn.Linear / 1x1 Conv1d -----------------------------------------
-def linear_fwd(x, W, out, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32):
+def linear_fwd(x, W, out, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None):
     M, K = x.shape
     N = W.shape[0]
-    gemm(x, W, out, M, N, K, K, 1, K, 1, N, bias=bias, R=R, alpha=alpha, act=act, compute=compute)
+    gemm(x, W, out, M, N, K, K, 1, K, 1, N, bias=bias, R=R, alpha=alpha, act=act, compute=compute, drop=drop)
 
 
 def linear_bwd_data(dy, W, dx, S=None, alpha=1.0, acc=ACC_STORE, compute=F32, colsum=None):
@@ -109,11 +111,11 @@ def linear_bwd_weight(dy, x, dW, alpha=1.0, compute=F32):
 
 
 # ---- Conv1d over time as implicit-im2col GEMM; weights kept as Wk[N][taps][Cin] --------------
-def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32):
+def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None):
     M, Cin = x.shape
     N, taps, _ = Wk.shape
     gemm(x, Wk, out, M, N, taps * Cin, Cin, 1, taps * Cin, 1, N, b_ts=Cin, bias=bias, R=R, taps=taps, pad=pad,
-         dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute)
+         dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute, drop=drop)
 
 
 def conv_bwd_data(dy, Wk, dx, Tseq, pad, dil=1, S=None, alpha=1.0, compute=F32, colsum=None):
@@ -225,15 +227,17 @@ def add_pos_bias_bwd(dqu, dqv, dqkv):
             "pos_bias_bwd")
 
 
-def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale):
+def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale, probs_drop=None, drop=(0.0, 0)):
     L.check(L.load().a3t_relpos_softmax_fwd(_ptr(ac), _ptr(bd), _ptr(keymask), _ptr(probs), _dt(probs), B, H, T,
-                                            T * T, T * T, T * T, scale, _stream()), "softmax_fwd")
+                                            T * T, T * T, T * T, scale, _ptr(probs_drop), drop[0], drop[1],
+                                            _stream()), "softmax_fwd")
 
 
-def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale):
+def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, drop_p=0.0):
     """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place)."""
     L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _dt(probs), _ptr(dprobs), _ptr(ds), _ptr(dbd), _dt(dbd), B, H,
-                                            T, T * T, T * T, T * T, scale, _stream()), "softmax_bwd")
+                                            T, T * T, T * T, T * T, scale, _ptr(probs_drop), drop_p, _stream()),
+            "softmax_bwd")
 
 
 def mask_fill(speech, masked, mask_feature, out):
@@ -242,15 +246,15 @@ def mask_fill(speech, masked, mask_feature, out):
                                    _stream()), "mask_fill")
 
 
-def embed_finish_fwd(e, emb, seg, text, spos, tpos, xs, B, Tm, Tp, D, xscale):
+def embed_finish_fwd(e, emb, seg, text, spos, tpos, xs, B, Tm, Tp, D, xscale, drop=(0.0, 0)):
     L.check(L.load().a3t_embed_finish_fwd(_ptr(e), _ptr(emb), _ptr(seg), _ptr(text), _ptr(spos), _ptr(tpos), _ptr(xs),
-                                          B, Tm, Tp, D, xscale, _stream()), "embed_fwd")
+                                          B, Tm, Tp, D, xscale, drop[0], drop[1], _stream()), "embed_fwd")
 
 
-def embed_finish_bwd(dxs, e, text, spos, tpos, de, demb, dseg, B, Tm, Tp, D, V, nseg, xscale):
+def embed_finish_bwd(dxs, e, text, spos, tpos, de, demb, dseg, B, Tm, Tp, D, V, nseg, xscale, drop=(0.0, 0)):
     L.check(L.load().a3t_embed_finish_bwd(_ptr(dxs), _ptr(e), _ptr(text), _ptr(spos), _ptr(tpos), _ptr(de),
-                                          _ptr(demb), _ptr(dseg), B, Tm, Tp, D, V, nseg, xscale, _stream()),
-            "embed_bwd")
+                                          _ptr(demb), _ptr(dseg), B, Tm, Tp, D, V, nseg, xscale, drop[0], drop[1],
+                                          _stream()), "embed_bwd")
 
 
 def scale(x, y, s):
@@ -331,5 +335,11 @@ def bias_act(x, bias, act, scale_=1.0):
     L.check(L.load().a3t_bias_act(_ptr(x), _ptr(bias), M, C, act, scale_, _stream()), "bias_act")
 
 
-def dropout(x, y, p, seed, offset):
-    L.check(L.load().a3t_dropout(_ptr(x), _ptr(y), x.numel(), p, seed, offset, _stream()), "dropout")
+def dropout(x, y, p, key, scale=1.0):
+    L.check(L.load().a3t_dropout(_ptr(x), _dt(x), _ptr(y), _dt(y), x.numel(), p, key, scale, _stream()), "dropout")
+
+
+def dropout_bwd_cast(g, gm, p, key, colsum=None, colsum_scale=1.0):
+    M, C = g.shape
+    L.check(L.load().a3t_dropout_bwd_cast(_ptr(g), _ptr(gm), _dt(gm), _ptr(colsum), colsum_scale, M, C, p, key,
+                                          _stream()), "dropout_bwd_cast")

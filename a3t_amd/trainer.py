@@ -115,10 +115,10 @@ class A3TTrainer:
     (trainer.py:545,610,631-679; optimizer/scheduler of egs2/vctk/sedit/conf/fsp2_conformer.yaml:77-83)."""
 
     def __init__(self, cfg: A3TConfig, store, compute="bf16", lr=1.0, warmup_steps=4000, grad_clip=1.0,
-                 betas=(0.9, 0.999), eps=1e-8, overlap=True):
+                 betas=(0.9, 0.999), eps=1e-8, overlap=True, dropout=True):
         from .engine import MLMEngine
         self.cfg, self.store = cfg, store
-        self.engine = MLMEngine(cfg, store, compute=compute, training=True)
+        self.engine = MLMEngine(cfg, store, compute=compute, training=True, dropout=dropout)
         dev = store.device
         self.m = torch.zeros_like(store.flat)
         self.v = torch.zeros_like(store.flat)

@@ -42,7 +42,7 @@ def fwd_flops_per_step(c, B, Tm, Tp):
     return blocks + head
 
 
-def build_trainer(cfg, device, compute, world):
+def build_trainer(cfg, device, compute, world, dropout=True):
     """A3TTrainer = the step body of Trainer.train_one_epoch (espnet2/train/trainer.py:528-703) on flat
     buffers; recipe init except BatchNorm gamma = 1 so that no GEMM runs on an all-zero operand."""
     from a3t_amd.init import xavier_init_
@@ -50,7 +50,7 @@ def build_trainer(cfg, device, compute, world):
     from a3t_amd.trainer import A3TTrainer
     store = ParamStore(cfg, device)
     xavier_init_(store, seed=0, bn_gamma=1.0)
-    return A3TTrainer(cfg, store, compute=compute, lr=1.0, warmup_steps=4000, grad_clip=1.0)
+    return A3TTrainer(cfg, store, compute=compute, lr=1.0, warmup_steps=4000, grad_clip=1.0, dropout=dropout)
 
 
 def cpu_baseline_worker(blocks, Tm, Tp, threads, budget_s):
@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=6, help="encoder blocks = decoder blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true", help="disable the recipe's dropout sites (debug only)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--threads", type=int, default=32)
@@ -149,7 +150,7 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     log("building trainer")
-    tr = build_trainer(cfg, dev, a.compute, world)
+    tr = build_trainer(cfg, dev, a.compute, world, dropout=not a.no_dropout)
     batch = synthetic_batch(cfg, B, Tm, Tp, seed=1234 + rank, device=dev)
     log(f"params {tr.store.n_params}; warm-up")
 
@@ -206,7 +207,7 @@ def main():
             "vs_baseline": None, "dtype": a.compute, "data": "synthetic",
             "config": {"workload": f"VCTK A3T masked-mel train step: {a.blocks}+{a.blocks} Conformer blocks d=384 "
                                    f"H=2 ff=1536(k3), B={B}/GPU, T_mel={Tm}, T_phn={Tp}, postnet 5x256x5, "
-                                   f"fwd+bwd+clip+Adam, dropout=off",
+                                   f"fwd+bwd+clip+Adam, dropout {'off' if a.no_dropout else '0.2/0.2/0.2 + postnet 0.5 (recipe)'}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "params": tr.store.n_params,
                        "masked_fraction": float(batch["masked_position"].float().mean()),
                        "algorithmic_tflop_per_step": step_flops / 1e12, "final_loss": final_loss},

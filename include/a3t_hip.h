@@ -82,7 +82,9 @@ typedef struct a3t_gemm_desc {
                                           (bias gradients fused into the data-gradient GEMM; bf16 path only) */
     int64_t colsum_bs1;
     float colsum_scale;
-    int32_t reserved2;
+    uint32_t drop_key;                 /* dropout fused into the epilogue (after act / mask, before alpha): */
+    float drop_p;                      /*   v = keep(drop_key, linear index in C) ? v/(1-p) : 0 ; p = 0 disables */
+    int32_t reserved3;
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
@@ -148,13 +150,15 @@ int a3t_add_pos_bias_bwd(const void* dqu, const void* dqv, void* dqkv, int dtype
  * z = b*H + h; keymask uint8 [B][T]; *_bs = per-z strides (elements). */
 int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, void* probs,
                            int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs,
-                           float scale, void* stream);
+                           float scale, void* probs_drop, float drop_p, uint32_t drop_key, void* stream);
+/* probs_drop (optional, drop_p > 0): the attention-dropout'ed probabilities fed to probs @ V
+ * (attention.py:88 self.dropout(self.attn)); probs itself stays un-dropped for the backward. */
 /* ds = probs * (dprobs - sum_j dprobs*probs) * scale (= gradient of ac; may alias dprobs when fp32)
  * and the same values scattered un-shifted into dbd (= gradient of the compact bd; fully
  * overwritten).  ds and dbd share out_dtype and the per-z stride o_bs. */
 int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const float* dprobs, void* ds, void* dbd,
                            int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
-                           float scale, void* stream);
+                           float scale, const void* probs_drop, float drop_p, void* stream);
 
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
 int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,
@@ -162,10 +166,10 @@ int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_
 /* xs[b][t] (t<Tm): relu(e[b*Tm+t]) * xscale + seg[spos];  (t>=Tm): emb[text]*xscale + seg[tpos] */
 int a3t_embed_finish_fwd(const float* e, const float* emb, const float* seg, const int64_t* text,
                          const int64_t* spos, const int64_t* tpos, float* xs, int B, int Tm, int Tp, int D,
-                         float xscale, void* stream);
+                         float xscale, float drop_p, uint32_t drop_key, void* stream);
 int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, const int64_t* spos,
                          const int64_t* tpos, float* de, float* demb, float* dseg, int B, int Tm, int Tp,
-                         int D, int V, int nseg, float xscale, void* stream);
+                         int D, int V, int nseg, float xscale, float drop_p, uint32_t drop_key, void* stream);
 /* y = x * s (decoder entry xscale, conformer/encoder.py:585-588) */
 int a3t_scale(const float* x, float* y, int64_t n, float s, void* stream);
 int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stream); /* y += a*x */
@@ -211,9 +215,15 @@ int a3t_pwg_upsample(const float* c, const float* w, float* out, int64_t Tin, in
 int a3t_replicate_pad(const float* x, float* y, int64_t T, int C, int pad, void* stream);
 int a3t_bias_act(float* x, const float* bias, int64_t M, int C, int act, float scale, void* stream);
 
-/* Dropout (counter-based; same (seed, offset) reproduces the mask in backward).
- * y = x * keep/(1-p), in place allowed. */
-int a3t_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+/* Dropout (torch.nn.Dropout sites of the path).  Counter-based: keep = f(key, element index), so the
+ * same key reproduces the mask in the backward pass and inside GEMM epilogues; no mask tensors.
+ * y = scale * x * keep/(1-p); in place allowed; x / y may be fp32 or bf16. */
+int a3t_dropout(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, float p, uint32_t key, float scale,
+                void* stream);
+/* Backward of "residual + alpha*dropout(branch)": gm = g*mask/(1-p) (fp32 or bf16 operand of the branch's
+ * GEMMs) and colsum += colsum_scale * column sums of gm (the branch's output-bias gradient). */
+int a3t_dropout_bwd_cast(const float* g, void* gm, int gm_dtype, float* colsum, float colsum_scale, int M, int C,
+                         float p, uint32_t key, void* stream);
 
 const char* a3t_version(void);
 

@@ -42,4 +42,4 @@ def test_gemm_desc_layout_matches_header():
     assert GemmDesc.a_rs.offset == 64 and GemmDesc.c_rs.offset == 104
     assert GemmDesc.batch.offset == 112 and GemmDesc.a_bs0.offset == 120
     assert GemmDesc.taps.offset == 168 and GemmDesc.alpha.offset == 188
-    assert GemmDesc.s_dtype.offset == 220 and GemmDesc.colsum.offset == 232 and ctypes.sizeof(GemmDesc) == 256
+    assert GemmDesc.s_dtype.offset == 220 and GemmDesc.colsum.offset == 232 and GemmDesc.drop_p.offset == 256 and ctypes.sizeof(GemmDesc) == 264

@@ -187,3 +187,42 @@ def test_logmel_and_collate_on_device():
               "speech_lengths", "text_lengths"):
         assert np.array_equal(b[k].numpy(), c["out." + k]), k
     np.testing.assert_allclose(b["speech"].numpy(), c["out.speech"], atol=2e-4)
+
+
+def test_dropout_backward_matches_finite_differences():
+    """With dropout on (counter RNG, fixed step seed) the loss is a deterministic function of the
+    parameters: the hand-written backward must agree with a central finite difference along the
+    gradient direction.  fp32 engine, reference-architecture tiny config."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.params import ParamStore
+    oc = O.tiny_config()
+    c = A3TConfig(adim=oc.adim, heads=oc.heads, ff=oc.ff, enc_blocks=1, dec_blocks=1, postnet_layers=2,
+                  postnet_chans=16, vocab=oc.vocab, dropout_rate=0.2, positional_dropout_rate=0.2,
+                  attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
+    store = ParamStore(c, DEV)
+    store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in O.procedural_state(O.param_shapes(oc), 1).items()})
+    eng = MLMEngine(c, store, compute="f32", training=True, dropout=True)
+    batch = _to_dev(O.synthetic_batch(oc, B=2, T_mel=48, T_phn=8, seed=11))
+
+    def loss_at(theta):
+        store.flat.copy_(theta)
+        eng.step_seed = 41                      # same masks every evaluation
+        return float(eng.forward(batch, need_grad=False)["loss"])
+
+    theta0 = store.flat.clone()
+    eng.step_seed = 41
+    l0 = float(eng.forward(batch)["loss"])
+    store.zero_grad()
+    eng.backward()
+    g = store.grad.clone()
+    # dropout really is on: a different seed gives a different loss
+    eng.step_seed = 5
+    assert abs(float(eng.forward(batch, need_grad=False)["loss"]) - l0) > 1e-3
+    v = g / g.norm()
+    eps = 2e-3
+    fd = (loss_at(theta0 + eps * v) - loss_at(theta0 - eps * v)) / (2 * eps)
+    an = float((g * v).sum())
+    assert abs(fd - an) < 3e-2 * abs(an), (fd, an)
+    # BatchNorm running stats must not matter for the train-mode loss; restore parameters
+    store.flat.copy_(theta0)

@@ -229,16 +229,39 @@ def test_loss_and_optimizer():
         _close(pd, pr[0], atol=1e-6, rtol=1e-5)
 
 
-def test_dropout_statistics_and_replay():
+def test_dropout_statistics_replay_and_gemm_epilogue():
     ops = _ops()
+    from a3t_amd._lib import F32
     n = 1 << 20
     x = torch.ones(n, device=DEV)
     y1, y2, y3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    ops.dropout(x, y1, 0.2, 1234, 0)
-    ops.dropout(x, y2, 0.2, 1234, 0)
-    ops.dropout(x, y3, 0.2, 1234, n)
+    ops.dropout(x, y1, 0.2, 1234)
+    ops.dropout(x, y2, 0.2, 1234)
+    ops.dropout(x, y3, 0.2, 99)
     assert torch.equal(y1, y2)
     keep = float((y1 > 0).float().mean())
     assert abs(keep - 0.8) < 5e-3
     assert abs(float(y1.mean()) - 1.0) < 1e-2
     assert not torch.equal(y1, y3)
+    # no visible structure along rows / columns of a matrix view
+    m = (y1.view(1024, 1024) > 0).float()
+    assert float(m.mean(0).std()) < 0.03 and float(m.mean(1).std()) < 0.03
+    # the GEMM epilogue regenerates exactly the mask of the stand-alone kernel (same key, same linear index)
+    M, N, K = 300, 256, 64
+    a, W = _rand(M, K, seed=1).to(DEV), _rand(N, K, seed=2).to(DEV)
+    ref = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(a, W, ref, compute=F32)
+    out = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(a, W, out, compute=F32, drop=(0.3, 777))
+    exp = torch.empty(M, N, device=DEV)
+    ops.dropout(ref, exp, 0.3, 777)
+    _close(out, exp, atol=1e-6, rtol=1e-6)
+    # backward companion: gm = g*mask/(1-p) and its column sums
+    g = _rand(M, N, seed=3).to(DEV)
+    gm = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    cs = torch.zeros(N, device=DEV)
+    ops.dropout_bwd_cast(g, gm, 0.3, 777, colsum=cs, colsum_scale=0.5)
+    gexp = torch.empty(M, N, device=DEV)
+    ops.dropout(g, gexp, 0.3, 777)
+    _close(gm, gexp, atol=2e-2, rtol=1e-2)
+    _close(cs, 0.5 * gexp.sum(0), atol=1e-3, rtol=1e-4)
