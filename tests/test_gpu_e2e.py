@@ -226,3 +226,20 @@ def test_dropout_backward_matches_finite_differences():
     assert abs(fd - an) < 3e-2 * abs(an), (fd, an)
     # BatchNorm running stats must not matter for the train-mode loss; restore parameters
     store.flat.copy_(theta0)
+
+
+def test_parallel_wavegan_generator_matches_vendored_reference():
+    from a3t_amd.vocoder import ParallelWaveGANGeneratorHIP
+    g = np.load(os.path.join(G, "pwg.npz"))
+    cfg = O.PWGConfig()
+    state = O.procedural_state(O.pwg_param_shapes(cfg), seed=4)
+    for k in state:
+        if "up_layers" in k:
+            state[k] = np.abs(state[k]) / np.abs(state[k]).sum()
+    voc = ParallelWaveGANGeneratorHIP(state, device=DEV)
+    wav = voc.inference(torch.from_numpy(g["c"]), torch.from_numpy(g["z"]))
+    assert wav.shape == (6000, 1)
+    np.testing.assert_allclose(wav.cpu().numpy(), g["wav"], atol=2e-5, rtol=1e-4)
+    # batched call = independent utterances
+    wb = voc.inference(torch.from_numpy(g["c"])[None].repeat(2, 1, 1), torch.from_numpy(g["z"])[None].repeat(2, 1, 1))
+    np.testing.assert_allclose(wb[1].cpu().numpy(), g["wav"], atol=2e-5, rtol=1e-4)
