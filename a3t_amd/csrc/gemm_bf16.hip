@@ -15,6 +15,7 @@
 // branching around the DMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/a3t_hip.h"
 #include "gemm_common.h"
 
@@ -30,8 +31,10 @@ __device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 
-template <int LAYOUT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
+// STAGES = 2: double-buffered LDS (64 KiB, 2 workgroups/CU, next tile's DMA in flight during the MFMAs)
+// STAGES = 1: single LDS buffer (32 KiB, up to 4 workgroups/CU: latency hidden by the other workgroups)
+template <int LAYOUT, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kernel(GP p) {
     constexpr int BM = 128, BN = 128, BK = 64;
     constexpr bool A_KC = (LAYOUT != L_TN), B_KC = (LAYOUT == L_NT);
     constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
@@ -212,11 +215,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    issue(kt0 * BK, 0);
+    if (STAGES == 2) issue(kt0 * BK, 0);
     int stage = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
+        if (STAGES == 1) {
+            if (kt > kt0) __syncthreads();   // WAR: every wave is done reading the previous tile
+            issue(kt * BK, 0);
+        }
         __syncthreads();  // drains this tile's DMA (vmcnt(0) precedes the barrier) + WAR on the other stage
-        if (kt + 1 < kt1) issue((kt + 1) * BK, stage ^ 1);
+        if (STAGES == 2 && kt + 1 < kt1) issue((kt + 1) * BK, stage ^ 1);
         const unsigned char* sA = smem + stage * 2 * TILE_BYTES;
         const unsigned char* sB = sA + TILE_BYTES;
 #pragma unroll
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        stage ^= 1;
+        if (STAGES == 2) stage ^= 1;
     }
     if (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC) {   // coalesced 128-B atomic rows straight from the accumulators
 #pragma unroll
@@ -260,14 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
     // lane finishes 4 consecutive columns: bias / residual / mask reads and the output stores
     // become 16-byte (8-byte for bf16) accesses, 256 B contiguous per output row segment.
     __syncthreads();
-    float* ct = (float*)smem + w * 4096;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = acc[i][j][r];
+    float* ct = (float*)smem + w * (STAGES == 2 ? 4096 : 2048);
     // (only this wave reads its region back; a wave is lock-step, LDS ops are issued in order)
     const int c4 = (lane & 15) * 4, r4 = lane >> 4;
     const int col = tn * BN + wn + c4;
@@ -275,12 +275,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && ks == 0 && col_ok) bias4 = *(const float4*)(p.bias + col);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    // STAGES==2: the whole 64x64 tile is staged at once; STAGES==1 (32 KiB LDS): 32 rows at a time
+    constexpr int HALVES = (STAGES == 2) ? 1 : 2;
+#pragma unroll
+    for (int hf = 0; hf < HALVES; ++hf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (HALVES == 2 && i != hf) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[((HALVES == 2 ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = acc[i][j][r];
+    }
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int lrow = it * 4 + r4;
+    for (int it = 0; it < 16 / HALVES; ++it) {
+        const int srow = it * 4 + r4;                       // row inside the staged slab
+        const int lrow = srow + (HALVES == 2 ? hf * 32 : 0); // row inside the wave's 64x64 tile
         const int row = tm * BM + wm + lrow;
         if (row >= p.M || !col_ok) continue;
-        float4 v = *(const float4*)(ct + lrow * 64 + c4);
+        float4 v = *(const float4*)(ct + srow * 64 + c4);
         const int64_t idx = zoff + (int64_t)row * p.c_rs + col;
         v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
         if (p.act != A3T_ACT_NONE) {
@@ -329,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(GP p) {
             }
         }
     }
+    }
     if (p.colsum) {   // lanes l, l+16, l+32, l+48 hold the same 4 columns (different rows)
         cs.x += __shfl_xor(cs.x, 16, 64), cs.y += __shfl_xor(cs.y, 16, 64);
         cs.z += __shfl_xor(cs.z, 16, 64), cs.w += __shfl_xor(cs.w, 16, 64);
@@ -366,19 +381,33 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     if (p.colsum && !pv.epi_vec) return -1;
     const int tiles_m = (p.M + 127) / 128;
     dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk)), block(256);
-    const size_t lds = 4 * 128 * 64 * 2;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("A3T_GEMM_STAGES");
+        forced = e ? (e[0] == '1' ? 1 : 2) : 0;
+        const int l2 = 4 * 128 * 64 * 2;
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_TN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
     }
+    // many tiles per CU: single LDS buffer, 3-4 co-resident workgroups hide the DMA latency (measured
+    // +8..18 % on the FFN shapes); few tiles per CU: double buffering inside the workgroup wins.
+    const long total_tiles = (long)p.tiles_n * tiles_m * batch * p.splitk;
+    const int stages = forced ? forced : (total_tiles >= 2048 ? 1 : 2);
+    const size_t lds = (size_t)stages * 2 * 128 * 64 * 2;
+#define LAUNCH(LY)                                                                                  \
+    do {                                                                                            \
+        if (stages == 2)                                                                            \
+            hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 2>), grid, block, lds, stream, pv);       \
+        else                                                                                        \
+            hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 1>), grid, block, lds, stream, pv);       \
+    } while (0)
     if (AK && BKC)
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel<L_NT>, grid, block, lds, stream, pv);
+        LAUNCH(L_NT);
     else if (AK && !BKC)
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel<L_NN>, grid, block, lds, stream, pv);
+        LAUNCH(L_NN);
     else
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel<L_TN>, grid, block, lds, stream, pv);
+        LAUNCH(L_TN);
+#undef LAUNCH
     return (int)hipGetLastError();
 }
