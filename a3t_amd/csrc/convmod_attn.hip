@@ -55,6 +55,22 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const void* __restr
 #pragma unroll
     for (int k = 0; k < KT; ++k) w[k] = (k < K) ? wdw[(int64_t)c * K + k] : 0.f;
     const float bias = bdw[c];
+    if (K == KT) {   // register-blocked: 4 consecutive time steps share one (KT+3)-value window
+        for (int r0 = ty * 4; r0 < DW_TT; r0 += 16) {
+            float v[KT + 3];
+#pragma unroll
+            for (int j = 0; j < KT + 3; ++j) v[j] = win[r0 + j][tx];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                float acc = bias;
+#pragma unroll
+                for (int k = 0; k < KT; ++k) acc += w[k] * v[tt + k];
+                int t = t0 + r0 + tt;
+                if (t < Tseq) z[(mbase + t) * (int64_t)C + c] = acc;
+            }
+        }
+        return;
+    }
     for (int r = ty; r < DW_TT; r += 4) {
         int t = t0 + r;
         if (t >= Tseq) break;
@@ -122,7 +138,35 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
             wgl[r][tx] = q;
         }
         __syncthreads();
-        if (c < C) {
+        if (c < C && K == KT) {   // register-blocked: 4 consecutive time steps per window read
+            for (int r0 = ty * 4; r0 < DW_TT; r0 += 16) {
+                float u[KT + 3], q[KT + 3];
+#pragma unroll
+                for (int j = 0; j < KT + 3; ++j) {
+                    u[j] = wdz[r0 + j][tx];
+                    q[j] = wgl[r0 + j][tx];
+                }
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    float acc = 0.f;   // dglu[t] = sum_k w[k] * dz[t + pad - k]
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) acc += w[k] * u[tt + KT - 1 - k];
+                    const float dzt = u[tt + (KT - 1) / 2];
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) dw[k] += dzt * q[tt + k];
+                    db += dzt;
+                    int t = t0 + r0 + tt;
+                    if (t < Tseq) {
+                        const int64_t gi = (mbase + t) * (int64_t)(2 * C);
+                        float ga = ldx(g, g_dt, gi + c), sb = sigm(ldx(g, g_dt, gi + C + c));
+                        const float da = acc * sb, dbb = acc * ga * sb * (1.f - sb);
+                        stx(dg, dg_dt, gi + c, da);
+                        stx(dg, dg_dt, gi + C + c, dbb);
+                        sga += da, sgb += dbb;
+                    }
+                }
+            }
+        } else if (c < C) {
             for (int r = ty; r < DW_TT; r += 4) {
                 int t = t0 + r;
                 if (t >= Tseq) break;

@@ -265,3 +265,30 @@ def test_dropout_statistics_replay_and_gemm_epilogue():
     ops.dropout(g, gexp, 0.3, 777)
     _close(gm, gexp, atol=2e-2, rtol=1e-2)
     _close(cs, 0.5 * gexp.sum(0), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,D", [(1003, 384), (64, 128), (77, 80)])
+def test_layernorm_bwd_bf16_input_copy_and_fused_column_sum(M, D):
+    ops = _ops()
+    x = _rand(M, D, seed=1, scale=2.0).requires_grad_(True)
+    g = (1 + 0.1 * _rand(D, seed=2)).requires_grad_(True)
+    b = _rand(D, seed=3).requires_grad_(True)
+    y = F.layer_norm(x, (D,), g, b, 1e-12)
+    dy16 = _rand(M, D, seed=4).bfloat16()
+    res = _rand(M, D, seed=5)
+    y.backward(dy16.float())
+    xd = x.detach().to(DEV)
+    yd = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(xd, g.detach().to(DEV), b.detach().to(DEV), yd, mean, rstd, 1e-12)
+    _close(yd, y, atol=3e-2, rtol=1e-2)
+    dx, dx16 = torch.empty(M, D, device=DEV), torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dg, db, cs = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dy16.to(DEV), xd, g.detach().to(DEV), mean, rstd, res.to(DEV), dx, dg, db, dx16=dx16, dxsum=cs,
+                      dxsum_scale=0.5)
+    ref = x.grad + res
+    _close(dx, ref, atol=5e-5, rtol=1e-4)
+    _close(dx16, ref, atol=3e-2, rtol=1e-2)
+    _close(dg, g.grad, atol=1e-4 * math.sqrt(M), rtol=1e-4)
+    _close(db, b.grad, atol=1e-4 * math.sqrt(M), rtol=1e-4)
+    _close(cs, 0.5 * ref.sum(0), atol=2e-4 * math.sqrt(M), rtol=1e-4)
