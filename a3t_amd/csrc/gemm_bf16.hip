@@ -34,7 +34,10 @@ enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 // STAGES = 2: double-buffered LDS (64 KiB, 2 workgroups/CU, next tile's DMA in flight during the MFMAs)
 // STAGES = 1: single LDS buffer (32 KiB, up to 4 workgroups/CU: latency hidden by the other workgroups)
 template <int LAYOUT, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kernel(GP p) {
+// STAGES = 3: three LDS buffers (96 KiB, 1 workgroup/CU), the DMA of tile t+2 is issued while tile t is
+//             computed and the wait is a COUNTED s_waitcnt vmcnt(8) + raw s_barrier, so one tile's DMA
+//             stays in flight across every barrier (a __syncthreads() would drain it with vmcnt(0))
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void gemm_bf16_glds_kernel(GP p) {
     constexpr int BM = 128, BN = 128, BK = 64;
     constexpr bool A_KC = (LAYOUT != L_TN), B_KC = (LAYOUT == L_NT);
     constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
@@ -69,7 +72,9 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
 
     // ---- per-lane source bookkeeping (4 DMA instructions per operand per tile) ---------------
     // k-contiguous image: instr q of wave w covers tile rows (w*4+q)*8 + (lane>>3), 16-B chunk
-    //   position c = lane&7 holds source chunk c ^ (row&7).
+    //   position c = lane&7 holds source chunk c ^ ((row>>1)&7): ds_read_b128 is serviced in the lane
+    //   groups {0-3,12-15,20-27}/{4-11,16-19,28-31}, two 128-B rows share a 256-B bank line, so rows r and r+8
+    //   of one group must land on different 16-B slots (measured: (row&7) left a 2-way conflict).
     // row-contiguous image: instr q covers k-rows (w*4+q)*4 + (lane>>4), chunk position
     //   c = lane&15 holds source chunk c ^ ((krow&3)<<2).
     const u16* a_row[4];   // A_KC: row base pointer (nullptr-equivalent = invalid -> zero page)
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
             a_ok[q] = m < p.M;
             a_tp[q] = (p.taps > 1) ? (m % p.Tseq) : 0;
             a_row[q] = A + (int64_t)m * p.a_rs;
-            a_sw[q] = ((lane & 7) ^ (r & 7)) * 8;
+            a_sw[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
             if (p.taps > 1) {
                 int kg = kt0 * BK + a_sw[q];
                 a_tap[q] = kg / p.Kc;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
             int n = tn * BN + r;
             b_ok[q] = n < p.N;
             b_row[q] = B + (int64_t)n * p.b_rs;
-            b_sw[q] = ((lane & 7) ^ (r & 7)) * 8;
+            b_sw[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         } else {
             int kr = (w * 4 + q) * 4 + (lane >> 4);
             int col = tn * BN + (((lane & 15) ^ ((kr & 3) << 2)) * 8);
@@ -133,56 +138,97 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
         }
     }
 
-    auto issue = [&](int k0, int stage) {
+    // Uniform (scalar) decomposition of the tile's first k into (tap, channel): when the channel count is
+    // a multiple of BK every lane of a tile works on the same tap, so the im2col row shift, its 64-bit
+    // row offset and the validity test reduce to a few VALU ops and one v_cndmask per DMA (no branches).
+    const bool a_fast = A_KC && p.taps > 1 && (p.Kc % BK == 0);
+    const bool b_fast = !B_KC && !WG && p.taps > 1 && (p.Kc % BK == 0);
+    const bool ks_fast = p.Tseq >= BK;
+    int u_tap = 0, u_cc = 0;
+    if (a_fast || b_fast) {
+        u_tap = (kt0 * BK) / p.Kc;
+        u_cc = kt0 * BK - u_tap * p.Kc;
+    }
+    auto issue = [&](int k0, int stage) {   // NOTE: called for consecutive tiles only (running state above)
         unsigned char* sA = smem + stage * 2 * TILE_BYTES;
         unsigned char* sB = sA + TILE_BYTES;
+        if (A_KC && a_fast) {
+            const int off = (u_tap - p.pad) * p.dil;
+            const int64_t roff = (int64_t)off * p.a_rs + u_cc;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u16* src = ZP;
-            if (A_KC) {
-                int kg = k0 + a_sw[q];
-                if (p.taps > 1) {
-                    if (a_ok[q] && kg < p.K) {
-                        int off = (a_tap[q] - p.pad) * p.dil, tt = a_tp[q] + off;
-                        if (tt >= 0 && tt < p.Tseq) src = a_row[q] + (int64_t)off * p.a_rs + a_cc[q];
-                    }
-                    a_cc[q] += BK;                       // tiles are issued in order: advance by one K-tile
-                    while (a_cc[q] >= p.Kc) a_cc[q] -= p.Kc, ++a_tap[q];
-                } else if (a_ok[q] && kg < p.K) {
-                    src = a_row[q] + kg;
-                }
-            } else {
-                int kg = k0 + a_sw[q];
-                if (a_ok[q] && kg < p.K) src = a_row[q] + (int64_t)kg * p.a_cs;
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = a_ok[q] && ((unsigned)(a_tp[q] + off) < (unsigned)p.Tseq);
+                const u16* src = ok ? a_row[q] + roff + a_sw[q] : ZP;
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * 4 + q) * 1024), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * 4 + q) * 1024), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u16* src = ZP;
+                const int kg = k0 + a_sw[q];
+                if (A_KC) {
+                    if (p.taps > 1) {
+                        if (a_ok[q] && kg < p.K) {
+                            int off = (a_tap[q] - p.pad) * p.dil, tt = a_tp[q] + off;
+                            if (tt >= 0 && tt < p.Tseq) src = a_row[q] + (int64_t)off * p.a_rs + a_cc[q];
+                        }
+                        a_cc[q] += BK;
+                        while (a_cc[q] >= p.Kc) a_cc[q] -= p.Kc, ++a_tap[q];
+                    } else {
+                        src = (a_ok[q] && kg < p.K) ? a_row[q] + kg : ZP;
+                    }
+                } else {
+                    src = (a_ok[q] && kg < p.K) ? a_row[q] + (int64_t)kg * p.a_cs : ZP;
+                }
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * 4 + q) * 1024), 16, 0, 0);
+            }
         }
+        if (B_KC) {
+            const bool split = (p.taps > 1 && p.b_ts != p.Kc);   // (weights are [n][tap][c]: b_ts == Kc, no split)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u16* src = ZP;
-            int kg = k0 + b_sw[q];
-            if (B_KC) {
-                if (b_ok[q] && kg < p.K) {
-                    int64_t koff = kg;
-                    if (p.taps > 1 && p.b_ts != p.Kc) {   // (weights are stored [n][tap][c]: b_ts == Kc, no split)
-                        int tap = kg / p.Kc, cc = kg - tap * p.Kc;
-                        koff = (int64_t)tap * p.b_ts + cc;
-                    }
-                    src = b_row[q] + koff;
+            for (int q = 0; q < 4; ++q) {
+                const int kg = k0 + b_sw[q];
+                int64_t koff = kg;
+                if (split) {
+                    int tap = kg / p.Kc, cc = kg - tap * p.Kc;
+                    koff = (int64_t)tap * p.b_ts + cc;
                 }
-            } else if (!WG && p.taps > 1) {
-                if (b_ok[q] && kg < p.K) src = b_row[q] + (int64_t)b_tap[q] * p.b_ts + (int64_t)b_cc[q] * p.b_cs;
-                b_cc[q] += BK;
-                while (b_cc[q] >= p.Kc) b_cc[q] -= p.Kc, ++b_tap[q];
-            } else if (WG || p.kshift_mode) {
-                int tt = b_cc[q] + kshift;
-                if (b_ok[q] && kg < p.K && tt >= 0 && tt < p.Tseq) src = b_row[q] + (int64_t)(kg + kshift) * p.b_cs;
-                b_cc[q] += BK;
-                while (b_cc[q] >= p.Tseq) b_cc[q] -= p.Tseq;
-            } else if (b_ok[q] && kg < p.K) {
-                src = b_row[q] + (int64_t)kg * p.b_cs;
+                const u16* src = (b_ok[q] && kg < p.K) ? b_row[q] + koff : ZP;
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
+        } else if (b_fast) {
+            const int64_t toff = (int64_t)u_tap * p.b_ts + (int64_t)u_cc * p.b_cs;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u16* src = b_ok[q] ? b_row[q] + toff + (int64_t)b_sw[q] * p.b_cs : ZP;
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u16* src = ZP;
+                const int kg = k0 + b_sw[q];
+                if (!WG && p.taps > 1) {
+                    if (b_ok[q] && kg < p.K) src = b_row[q] + (int64_t)b_tap[q] * p.b_ts + (int64_t)b_cc[q] * p.b_cs;
+                    b_cc[q] += BK;
+                    while (b_cc[q] >= p.Kc) b_cc[q] -= p.Kc, ++b_tap[q];
+                } else if (WG || p.kshift_mode) {
+                    const bool ok = b_ok[q] && kg < p.K && ((unsigned)(b_cc[q] + kshift) < (unsigned)p.Tseq);
+                    src = ok ? b_row[q] + (int64_t)(kg + kshift) * p.b_cs : ZP;
+                    b_cc[q] += BK;
+                    if (ks_fast)
+                        b_cc[q] = (b_cc[q] >= p.Tseq) ? b_cc[q] - p.Tseq : b_cc[q];
+                    else
+                        b_cc[q] %= p.Tseq;
+                } else {
+                    src = (b_ok[q] && kg < p.K) ? b_row[q] + (int64_t)kg * p.b_cs : ZP;
+                }
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
+            }
+        }
+        if (a_fast || b_fast) {
+            u_cc += BK;
+            if (u_cc >= p.Kc) u_cc -= p.Kc, ++u_tap;
         }
     };
 
@@ -198,7 +244,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
     // fragment read offsets (bytes inside one operand image), constant over the K loop
     auto frag_kc = [&](const unsigned char* img, int row, int kk) -> bf16x8 {
         int kc = kk * 2 + lk;
-        return *(const bf16x8*)(img + row * 128 + ((kc ^ (row & 7)) << 4));
+        return *(const bf16x8*)(img + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     };
     auto frag_rc = [&](const unsigned char* img, int row0, int kk) -> bf16x8 {
         // 16-lane group g: rows row0 + (g&1)*16 .. +15, k = kk*16 + (g>>1)*8 .. +7 (two 4-k transposed reads)
@@ -215,14 +261,25 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    if (STAGES == 2) issue(kt0 * BK, 0);
+    if (STAGES >= 2) issue(kt0 * BK, 0);
+    if (STAGES == 3 && kt0 + 1 < kt1) issue((kt0 + 1) * BK, 1);
     int stage = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         if (STAGES == 1) {
             if (kt > kt0) __syncthreads();   // WAR: every wave is done reading the previous tile
             issue(kt * BK, 0);
         }
-        __syncthreads();  // drains this tile's DMA (vmcnt(0) precedes the barrier) + WAR on the other stage
+        if (STAGES == 3) {
+            // each wave has 8 DMA ops per tile in flight: keep tile kt+1's, require tile kt's
+            if (kt + 1 < kt1)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();    // all waves' pieces of tile kt landed; buffer (kt+2)%3 is free
+            if (kt + 2 < kt1) issue((kt + 2) * BK, stage == 0 ? 2 : stage - 1);
+        } else {
+            __syncthreads();  // drains this tile's DMA (vmcnt(0) precedes the barrier) + WAR on the other stage
+        }
         if (STAGES == 2 && kt + 1 < kt1) issue((kt + 1) * BK, stage ^ 1);
         const unsigned char* sA = smem + stage * 2 * TILE_BYTES;
         const unsigned char* sB = sA + TILE_BYTES;
@@ -249,6 +306,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (STAGES == 2) stage ^= 1;
+        if (STAGES == 3) stage = (stage == 2) ? 0 : stage + 1;
     }
     if (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC) {   // coalesced 128-B atomic rows straight from the accumulators
 #pragma unroll
@@ -267,7 +325,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
     // lane finishes 4 consecutive columns: bias / residual / mask reads and the output stores
     // become 16-byte (8-byte for bf16) accesses, 256 B contiguous per output row segment.
     __syncthreads();
-    float* ct = (float*)smem + w * (STAGES == 2 ? 4096 : 2048);
+    float* ct = (float*)smem + w * (STAGES >= 2 ? 4096 : 2048);
     // (only this wave reads its region back; a wave is lock-step, LDS ops are issued in order)
     const int c4 = (lane & 15) * 4, r4 = lane >> 4;
     const int col = tn * BN + wn + c4;
@@ -276,7 +334,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16_glds_kerne
     if (p.bias && ks == 0 && col_ok) bias4 = *(const float4*)(p.bias + col);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     // STAGES==2: the whole 64x64 tile is staged at once; STAGES==1 (32 KiB LDS): 32 rows at a time
-    constexpr int HALVES = (STAGES == 2) ? 1 : 2;
+    constexpr int HALVES = (STAGES >= 2) ? 1 : 2;
 #pragma unroll
     for (int hf = 0; hf < HALVES; ++hf) {
 #pragma unroll
@@ -384,8 +442,12 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("A3T_GEMM_STAGES");
-        forced = e ? (e[0] == '1' ? 1 : 2) : 0;
+        forced = e ? (e[0] == '1' ? 1 : (e[0] == '3' ? 3 : 2)) : 0;
         const int l2 = 4 * 128 * 64 * 2;
+        const int l3 = 6 * 128 * 64 * 2;
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, l3);
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, l3);
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_TN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, l3);
         hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
         hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
         hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_TN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
@@ -393,12 +455,14 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     // many tiles per CU: single LDS buffer, 3-4 co-resident workgroups hide the DMA latency (measured
     // +8..18 % on the FFN shapes); few tiles per CU: double buffering inside the workgroup wins.
     const long total_tiles = (long)p.tiles_n * tiles_m * batch * p.splitk;
-    const int stages = forced ? forced : (total_tiles >= 2048 ? 1 : 2);
+    const int stages = forced ? forced : (total_tiles >= 768 ? 1 : 2);
     const size_t lds = (size_t)stages * 2 * 128 * 64 * 2;
 #define LAUNCH(LY)                                                                                  \
     do {                                                                                            \
         if (stages == 2)                                                                            \
             hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 2>), grid, block, lds, stream, pv);       \
+        else if (stages == 3)                                                                       \
+            hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 3>), grid, block, lds, stream, pv);       \
         else                                                                                        \
             hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 1>), grid, block, lds, stream, pv);       \
     } while (0)
