@@ -16,13 +16,14 @@ __all__ = ["gemm", "linear_fwd", "linear_bwd_data", "linear_bwd_weight", "conv_f
 PROFILE = None
 
 
-def _kernel_name(compute, a_cs, b_cs, A, B):
+def _kernel_name(compute, a_cs, b_cs, A, B, tiles=0):
     tn = {torch.float32: "float", torch.bfloat16: "unsigned short"}
     ak, bk = "true" if a_cs == 1 else "false", "true" if b_cs == 1 else "false"
     if compute == F32:
         return f"gemm_f32_kernel<{ak}, {bk}, *>"
     if A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16:
-        return f"gemm_bf16_glds_kernel<{0 if (a_cs == 1 and b_cs == 1) else (1 if a_cs == 1 else 2)}>"
+        lay = 0 if (a_cs == 1 and b_cs == 1) else (1 if a_cs == 1 else 2)
+        return f"gemm_bf16_glds_kernel<{lay}, {1 if tiles >= 768 else 2}>"   # same rule as a3t_gemm_bf16_glds
     return f"gemm_bf16_kernel<{tn[A.dtype]}, {tn[B.dtype]}, {ak}, {bk}>"
 
 
@@ -73,13 +74,14 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
         L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
         e1.record()
-        PROFILE.append((_kernel_name(compute, a_cs, b_cs, A, B), 2.0 * M * N * K * batch, e0, e1,
+        tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch * splitk
+        PROFILE.append((_kernel_name(compute, a_cs, b_cs, A, B, tiles), 2.0 * M * N * K * batch, e0, e1,
                         (M, N, K, batch, taps, splitk)))
         return
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
 
 
-def _splitk_for(n_tiles, K, target=512, ktile=64):
+def _splitk_for(n_tiles, K, target=1000, ktile=64):
     """Token-reduction GEMMs (weight gradients) have few output tiles: split K over workgroups
     until the grid covers the 256 CUs a few times."""
     s = max(1, target // max(n_tiles, 1))

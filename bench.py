@@ -53,6 +53,44 @@ def build_trainer(cfg, device, compute, world, dropout=True):
     return A3TTrainer(cfg, store, compute=compute, lr=1.0, warmup_steps=4000, grad_clip=1.0, dropout=dropout)
 
 
+def vocoder_rtf(dev, B=8, Tf=1000, reps=3):
+    """BASELINE.json configs[4]: ParallelWaveGAN v1 (30 blocks, 64/128/64 ch, hop 300 = 4*5*3*5) mel -> wav
+    for B utterances of Tf frames (12.5 s each at 24 kHz); RTF = wall / audio seconds.  fp32 MFMA GEMMs."""
+    import numpy as np
+    from a3t_amd.vocoder import ParallelWaveGANGeneratorHIP
+    rs = np.random.RandomState(0)
+    shapes = {"first_conv.weight": (64, 1, 1), "first_conv.bias": (64,), "upsample_net.conv_in.weight": (80, 80, 5),
+              "last_conv_layers.1.weight": (64, 64, 1), "last_conv_layers.1.bias": (64,),
+              "last_conv_layers.3.weight": (1, 64, 1), "last_conv_layers.3.bias": (1,)}
+    for i, sc in enumerate((4, 5, 3, 5)):
+        shapes[f"upsample_net.upsample.up_layers.{2 * i + 1}.weight"] = (1, 1, 1, 2 * sc + 1)
+    for l in range(30):
+        p = f"conv_layers.{l}."
+        shapes.update({p + "conv.weight": (128, 64, 3), p + "conv.bias": (128,), p + "conv1x1_aux.weight": (128, 80, 1),
+                       p + "conv1x1_out.weight": (128, 64, 1), p + "conv1x1_out.bias": (128,)})
+    state = {}
+    for k, s in shapes.items():
+        fan = int(np.prod(s[1:])) if len(s) > 1 else 1
+        state[k] = (rs.standard_normal(s) * (1.0 / np.sqrt(fan) if len(s) > 1 else 0.05)).astype(np.float32)
+        if "up_layers" in k:
+            state[k] = np.abs(state[k]) / np.abs(state[k]).sum()
+    voc = ParallelWaveGANGeneratorHIP(state, device=dev)
+    c = torch.from_numpy((rs.standard_normal((B, Tf, 80)) * 1.5 - 4.0).astype(np.float32)).to(dev)
+    z = torch.randn(B, Tf * 300, 1, device=dev)
+    voc.inference(c, z)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        wav = voc.inference(c, z)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    audio_s = B * Tf * 300 / 24000.0
+    flops = 2.60e6 * B * Tf * 300
+    return dict(metric="vocoder RTF", rtf=dt / audio_s, ms=dt * 1e3, audio_seconds=audio_s, samples_per_s=B * Tf * 300 / dt,
+                tflops=flops / dt / 1e12, dtype="f32", finite=bool(torch.isfinite(wav).all()),
+                workload=f"ParallelWaveGAN v1 generator, B={B} x {Tf} frames, hop 300, 24 kHz")
+
+
 def cpu_baseline_worker(blocks, Tm, Tp, threads, budget_s):
     """Runs in a child process: the oracle (CPU restatement of the reference) fwd+bwd+clip+Adam on
     `threads` host cores over a bounded sample of the same workload.  Prints one JSON line."""
@@ -117,6 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable the recipe's dropout sites (debug only)")
+    ap.add_argument("--no-vocoder", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--threads", type=int, default=32)
@@ -196,8 +235,14 @@ def main():
         name, (fl, tt, n) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = fl / tt / 1e12
         peak = MFMA_PEAK["bf16" if "bf16" in name else "f32"]
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic_per_kernel.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        if os.path.exists(tf):                                                    # passes of this same command
+            for k, v in json.load(open(tf)).items():
+                if name in k:
+                    traffic = v["hbm_bytes_per_launch"]
         roofline = dict(bound="mfma", kernel=name, launches=n, avg_us=tt / n * 1e6, achieved=achieved, peak=peak,
-                        unit="TFLOP/s", frac=achieved / peak, traffic=None,
+                        unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
                         gemm_time_share=sum(v[1] for v in agg.values()) / (ms * 1e-3),
                         step_tflops=step_flops / (ms * 1e-3) / 1e12)
     if rank == 0:
@@ -213,6 +258,9 @@ def main():
                        "algorithmic_tflop_per_step": step_flops / 1e12, "final_loss": final_loss},
             "roofline": roofline,
         }
+        if world == 1 and not a.no_vocoder:
+            log("vocoder leg (ParallelWaveGAN v1, 8 x 1000 frames)")
+            out["vocoder"] = vocoder_rtf(dev)
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle on host cores, child process)")
             out["cpu_baseline"] = cpu_baseline(a.blocks, Tm, Tp, a.budget)
