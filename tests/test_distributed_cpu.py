@@ -64,3 +64,45 @@ def test_two_rank_gradient_equals_global_batch_mean():
     np.testing.assert_allclose(r["flat"].numpy(), ref.numpy(), atol=1e-6)
     assert abs(float(r["loss"]) - sum(keys) / 5) < 1e-6 and float(r["w"]) == 5.0
     assert r["stop"] is True
+
+
+def _overlap_worker(rank, world, init_file, out_file):
+    """A3TTrainer's overlapped reduction driven by a fake engine on CPU tensors: every flat-buffer
+    element must be all-reduced exactly once, whatever order the backward schedule reports groups in."""
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.params import ParamStore
+    c = A3TConfig(adim=32, heads=2, ff=64, enc_blocks=2, dec_blocks=2, postnet_layers=2, postnet_chans=16, vocab=11)
+    store = ParamStore(c, "cpu")
+
+    class FakeEngine:
+        def backward(self, on_group_done=None):
+            names = ["sfc.w"] + [f"dec.{i}.ffm.ln.g" for i in (1, 0)] + [f"enc.{i}.ffm.ln.g" for i in (1, 0)] + ["seg"]
+            hi = store.total
+            for n in names:                       # gradients become final from the top of the buffer down
+                lo = store.offsets[n][0]
+                store.grad[lo:hi] = float(rank + 1)
+                on_group_done(n)
+                hi = lo
+
+    tr = T.A3TTrainer.__new__(T.A3TTrainer)
+    tr.store, tr.engine, tr.cfg = store, FakeEngine(), c
+    bounds = [store.offsets[f"enc.{i}.ffm.ln.g"][0] for i in range(2)] + [store.offsets[f"dec.{i}.ffm.ln.g"][0] for i in range(2)]
+    bounds += [store.offsets["sfc.w"][0]]
+    tr.ranges = T.bucket_ranges(store.total, bounds, 10000)
+    tr.reducer = T.FlatAllReduce(store.grad, tr.ranges)
+    store.grad.zero_()
+    tr._backward_overlapped()
+    ok = bool((store.grad == float(sum(range(1, world + 1)))).all())
+    if rank == 0:
+        torch.save(dict(ok=ok, nranges=len(tr.ranges)), out_file)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_reduction_covers_flat_buffer_once():
+    with tempfile.TemporaryDirectory() as d:
+        init, out = os.path.join(d, "init"), os.path.join(d, "out.pt")
+        mp.spawn(_overlap_worker, args=(2, init, out), nprocs=2, join=True)
+        r = torch.load(out)
+    assert r["ok"] and r["nranges"] >= 2
