@@ -81,9 +81,12 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
 
 
-def _splitk_for(n_tiles, K, target=1000, ktile=64):
-    """Token-reduction GEMMs (weight gradients) have few output tiles: split K over workgroups
-    until the grid covers the 256 CUs a few times."""
+def _splitk_for(n_tiles, K, ktile=64):
+    """Token-reduction GEMMs (weight gradients) have few output tiles: split K over workgroups so the
+    grid is ONE resident wave of the kernel variant a3t_gemm will pick -- ~1000 workgroups for the
+    single-buffer variant (4/CU, chosen when tiles*splitk >= 768), ~440 for the double-buffered one
+    (2/CU); more splits only add fp32 atomics (measured on MI355X, tools/tn_bench*.py)."""
+    target = 1000 if n_tiles >= 64 else 440
     s = max(1, target // max(n_tiles, 1))
     s = min(s, max(1, K // (ktile * 8)))
     return int(s)
