@@ -1,7 +1,7 @@
 // gemm_bf16.hip -- bf16-operand MFMA GEMM for gfx950 with direct global->LDS staging.
 //
 // The production contraction kernel of the bf16 compute path (activations feeding GEMMs are
-// stored in bf16, weights are cast once per step).  Per 128x128x64 tile:
+// stored in bf16, weights are cast once per step).  Per (64*WM) x 128 x 64 tile:
 //   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip);
 //     LDS images are lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
 //     address and undone on the fragment read (same XOR involution on both sides);
@@ -9,8 +9,11 @@
 //     conflict-free ds_read_b128; reduction-strided operands ([k][rows]: W for data gradients,
 //     activations for weight gradients) are read with ds_read_b64_tr_b16, the CDNA4 LDS
 //     transpose read, so no register transposes are needed for the NN / TN layouts;
-//   * 4 waves x (2x2) v_mfma_f32_32x32x16_bf16 accumulators, LDS double buffered, one barrier
-//     per K-tile with the next tile's DMA in flight across the MFMA block.
+//   * 2*WM waves, each owning a 64x64 output sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.
+//     WM=2: 128x128 tile, 4 waves.  WM=4: 256x128 tile, 8 waves -- 25 % fewer DMA bytes per flop
+//     (the kernel is bound by the L2->LDS DMA rate, ~11-13 TB/s aggregate, not by the MFMA pipe);
+//   * STAGES=1: one LDS buffer, latency hidden by 3-5 co-resident workgroups per CU;
+//     STAGES=2: double buffered inside the workgroup (used when the grid is small).
 // Out-of-range rows / im2col padding / K tails read a 16-byte device zero page instead of
 // branching around the DMA.
 #include <hip/hip_runtime.h>
@@ -22,6 +25,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 __device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
@@ -31,17 +35,18 @@ __device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 
-// STAGES = 2: double-buffered LDS (64 KiB, 2 workgroups/CU, next tile's DMA in flight during the MFMAs)
-// STAGES = 1: single LDS buffer (32 KiB, up to 4 workgroups/CU: latency hidden by the other workgroups)
-template <int LAYOUT, int STAGES>
-// STAGES = 3: three LDS buffers (96 KiB, 1 workgroup/CU), the DMA of tile t+2 is issued while tile t is
-//             computed and the wait is a COUNTED s_waitcnt vmcnt(8) + raw s_barrier, so one tile's DMA
-//             stays in flight across every barrier (a __syncthreads() would drain it with vmcnt(0))
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void gemm_bf16_glds_kernel(GP p) {
-    constexpr int BM = 128, BN = 128, BK = 64;
+template <int LAYOUT, int STAGES, int WM>
+__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : 3))) void gemm_bf16_glds_kernel(GP p) {
+    constexpr int NW = 2 * WM;                 // waves
+    constexpr int BM = 64 * WM, BN = 128, BK = 64;
     constexpr bool A_KC = (LAYOUT != L_TN), B_KC = (LAYOUT == L_NT);
-    constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A|B][16 KiB]
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NA = 4;                      // A DMA instructions per wave per tile (BM*128 B / 1 KiB / NW)
+    constexpr int NB = 8 / WM;                 // B DMA instructions per wave per tile
+    // row-contiguous images: one k-row = (rows*2) bytes; a 1-KiB DMA instruction covers KPI k-rows
+    constexpr int A_LPR = BM / 8, A_KPI = 64 / A_LPR;   // lanes per k-row, k-rows per instruction
+    constexpr int B_LPR = BN / 8, B_KPI = 64 / B_LPR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [STAGES][A image | B image]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,27 +75,28 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
     const int wg_tap = WG ? (tn * BN) / wg_cin : 0;
     const int kshift = WG ? (wg_tap - p.pad) * p.dil : p.kshift;
 
-    // ---- per-lane source bookkeeping (4 DMA instructions per operand per tile) ---------------
-    // k-contiguous image: instr q of wave w covers tile rows (w*4+q)*8 + (lane>>3), 16-B chunk
-    //   position c = lane&7 holds source chunk c ^ ((row>>1)&7): ds_read_b128 is serviced in the lane
-    //   groups {0-3,12-15,20-27}/{4-11,16-19,28-31}, two 128-B rows share a 256-B bank line, so rows r and r+8
+    // ---- per-lane source bookkeeping --------------------------------------------------------------
+    // k-contiguous image: DMA instruction g covers tile rows g*8 + (lane>>3); 16-B chunk position
+    //   c = lane&7 holds source chunk c ^ ((row>>1)&7): ds_read_b128 is serviced in the lane groups
+    //   {0-3,12-15,20-27}/{4-11,16-19,28-31}, two 128-B rows share a 256-B bank line, so rows r and r+8
     //   of one group must land on different 16-B slots (measured: (row&7) left a 2-way conflict).
-    // row-contiguous image: instr q covers k-rows (w*4+q)*4 + (lane>>4), chunk position
-    //   c = lane&15 holds source chunk c ^ ((krow&3)<<2).
-    const u16* a_row[4];   // A_KC: row base pointer (nullptr-equivalent = invalid -> zero page)
-    int a_tp[4];           // A_KC conv: position in utterance
-    bool a_ok[4];
-    int a_sw[4];           // swizzled source chunk (elements offset = *8)
-    const u16* b_row[4];
-    bool b_ok[4];
-    int b_sw[4];
-    int a_tap[4], a_cc[4];  // running (tap, channel) of this lane's chunk for the im2col loader
-    int b_tap[4], b_cc[4];
+    // row-contiguous image: instruction g covers k-rows g*KPI + lane/LPR, chunk position c = lane%LPR
+    //   holds source chunk c ^ ((krow&3)<<2) (the 4 k-rows of a ds_read_b64_tr_b16 hit distinct banks).
+    const u16* a_row[NA];
+    int a_tp[NA];          // A_KC conv: position in utterance
+    bool a_ok[NA];
+    int a_sw[NA];          // k-contiguous: swizzled source chunk offset (elements); row-contiguous: k-row
+    int a_tap[NA], a_cc[NA];
+    const u16* b_row[NB];
+    bool b_ok[NB];
+    int b_sw[NB];
+    int b_tap[NB], b_cc[NB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        a_tap[q] = 0, a_cc[q] = 0, b_tap[q] = 0, b_cc[q] = 0;
+    for (int q = 0; q < NA; ++q) {
+        a_tap[q] = 0, a_cc[q] = 0, a_tp[q] = 0;
+        const int g = w * NA + q;
         if (A_KC) {
-            int r = (w * 4 + q) * 8 + (lane >> 3);
+            int r = g * 8 + (lane >> 3);
             int m = tm * BM + r;
             a_ok[q] = m < p.M;
             a_tp[q] = (p.taps > 1) ? (m % p.Tseq) : 0;
@@ -102,22 +108,26 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
                 a_cc[q] = kg - a_tap[q] * p.Kc;
             }
         } else {
-            int kr = (w * 4 + q) * 4 + (lane >> 4);
-            int col = tm * BM + (((lane & 15) ^ ((kr & 3) << 2)) * 8);
+            int kr = g * A_KPI + lane / A_LPR;
+            int col = tm * BM + (((lane % A_LPR) ^ ((kr & 3) << 2)) * 8);
             a_ok[q] = col < p.M;
             a_row[q] = A + col;
             a_sw[q] = kr;
-            a_tp[q] = 0;
         }
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        b_tap[q] = 0, b_cc[q] = 0;
+        const int g = w * NB + q;
         if (B_KC) {
-            int r = (w * 4 + q) * 8 + (lane >> 3);
+            int r = g * 8 + (lane >> 3);
             int n = tn * BN + r;
             b_ok[q] = n < p.N;
             b_row[q] = B + (int64_t)n * p.b_rs;
             b_sw[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         } else {
-            int kr = (w * 4 + q) * 4 + (lane >> 4);
-            int col = tn * BN + (((lane & 15) ^ ((kr & 3) << 2)) * 8);
+            int kr = g * B_KPI + lane / B_LPR;
+            int col = tn * BN + (((lane % B_LPR) ^ ((kr & 3) << 2)) * 8);
             b_ok[q] = col < p.N;
             b_row[q] = B + col;
             b_sw[q] = kr;
@@ -150,20 +160,20 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
         u_cc = kt0 * BK - u_tap * p.Kc;
     }
     auto issue = [&](int k0, int stage) {   // NOTE: called for consecutive tiles only (running state above)
-        unsigned char* sA = smem + stage * 2 * TILE_BYTES;
-        unsigned char* sB = sA + TILE_BYTES;
+        unsigned char* sA = smem + stage * STAGE_BYTES;
+        unsigned char* sB = sA + A_BYTES;
         if (A_KC && a_fast) {
             const int off = (u_tap - p.pad) * p.dil;
             const int64_t roff = (int64_t)off * p.a_rs + u_cc;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NA; ++q) {
                 const bool ok = a_ok[q] && ((unsigned)(a_tp[q] + off) < (unsigned)p.Tseq);
                 const u16* src = ok ? a_row[q] + roff + a_sw[q] : ZP;
-                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * 4 + q) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * NA + q) * 1024), 16, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NA; ++q) {
                 const u16* src = ZP;
                 const int kg = k0 + a_sw[q];
                 if (A_KC) {
@@ -180,13 +190,13 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
                 } else {
                     src = (a_ok[q] && kg < p.K) ? a_row[q] + (int64_t)kg * p.a_cs : ZP;
                 }
-                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * 4 + q) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * NA + q) * 1024), 16, 0, 0);
             }
         }
         if (B_KC) {
             const bool split = (p.taps > 1 && p.b_ts != p.Kc);   // (weights are [n][tap][c]: b_ts == Kc, no split)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NB; ++q) {
                 const int kg = k0 + b_sw[q];
                 int64_t koff = kg;
                 if (split) {
@@ -194,18 +204,18 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
                     koff = (int64_t)tap * p.b_ts + cc;
                 }
                 const u16* src = (b_ok[q] && kg < p.K) ? b_row[q] + koff : ZP;
-                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * NB + q) * 1024), 16, 0, 0);
             }
         } else if (b_fast) {
             const int64_t toff = (int64_t)u_tap * p.b_ts + (int64_t)u_cc * p.b_cs;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NB; ++q) {
                 const u16* src = b_ok[q] ? b_row[q] + toff + (int64_t)b_sw[q] * p.b_cs : ZP;
-                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * NB + q) * 1024), 16, 0, 0);
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NB; ++q) {
                 const u16* src = ZP;
                 const int kg = k0 + b_sw[q];
                 if (!WG && p.taps > 1) {
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
                 } else {
                     src = (b_ok[q] && kg < p.K) ? b_row[q] + (int64_t)kg * p.b_cs : ZP;
                 }
-                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * 4 + q) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * NB + q) * 1024), 16, 0, 0);
             }
         }
         if (a_fast || b_fast) {
@@ -241,48 +251,35 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64, lr = lane & 31, lk = lane >> 5;
-    // fragment read offsets (bytes inside one operand image), constant over the K loop
     auto frag_kc = [&](const unsigned char* img, int row, int kk) -> bf16x8 {
         int kc = kk * 2 + lk;
         return *(const bf16x8*)(img + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     };
-    auto frag_rc = [&](const unsigned char* img, int row0, int kk) -> bf16x8 {
+    auto frag_rc = [&](const unsigned char* img, int rowbytes, int row0, int kk) -> bf16x8 {
         // 16-lane group g: rows row0 + (g&1)*16 .. +15, k = kk*16 + (g>>1)*8 .. +7 (two 4-k transposed reads)
         const int g = lane >> 4, pp = lane & 15;
         const int col = row0 + (g & 1) * 16 + (pp & 3) * 4;
         const int kb = kk * 16 + (g >> 1) * 8 + (pp >> 2);
         const int k1 = kb + 4;
-        const unsigned char* a0 = img + kb * 256 + ((((col >> 3) ^ ((kb & 3) << 2))) << 4) + (col & 7) * 2;
-        const unsigned char* a1 = img + k1 * 256 + ((((col >> 3) ^ ((k1 & 3) << 2))) << 4) + (col & 7) * 2;
+        const unsigned char* a0 = img + kb * rowbytes + ((((col >> 3) ^ ((kb & 3) << 2))) << 4) + (col & 7) * 2;
+        const unsigned char* a1 = img + k1 * rowbytes + ((((col >> 3) ^ ((k1 & 3) << 2))) << 4) + (col & 7) * 2;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a1));
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
 
-    if (STAGES >= 2) issue(kt0 * BK, 0);
-    if (STAGES == 3 && kt0 + 1 < kt1) issue((kt0 + 1) * BK, 1);
+    if (STAGES == 2) issue(kt0 * BK, 0);
     int stage = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         if (STAGES == 1) {
             if (kt > kt0) __syncthreads();   // WAR: every wave is done reading the previous tile
             issue(kt * BK, 0);
         }
-        if (STAGES == 3) {
-            // each wave has 8 DMA ops per tile in flight: keep tile kt+1's, require tile kt's
-            if (kt + 1 < kt1)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();    // all waves' pieces of tile kt landed; buffer (kt+2)%3 is free
-            if (kt + 2 < kt1) issue((kt + 2) * BK, stage == 0 ? 2 : stage - 1);
-        } else {
-            __syncthreads();  // drains this tile's DMA (vmcnt(0) precedes the barrier) + WAR on the other stage
-        }
+        __syncthreads();  // drains this tile's DMA (vmcnt(0) precedes the barrier) + WAR on the other stage
         if (STAGES == 2 && kt + 1 < kt1) issue((kt + 1) * BK, stage ^ 1);
-        const unsigned char* sA = smem + stage * 2 * TILE_BYTES;
-        const unsigned char* sB = sA + TILE_BYTES;
+        const unsigned char* sA = smem + stage * STAGE_BYTES;
+        const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 a0, a1, b0, b1;
@@ -290,15 +287,15 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
                 a0 = frag_kc(sA, wm + lr, kk);
                 a1 = frag_kc(sA, wm + 32 + lr, kk);
             } else {
-                a0 = frag_rc(sA, wm, kk);
-                a1 = frag_rc(sA, wm + 32, kk);
+                a0 = frag_rc(sA, BM * 2, wm, kk);
+                a1 = frag_rc(sA, BM * 2, wm + 32, kk);
             }
             if (B_KC) {
                 b0 = frag_kc(sB, wn + lr, kk);
                 b1 = frag_kc(sB, wn + 32 + lr, kk);
             } else {
-                b0 = frag_rc(sB, wn, kk);
-                b1 = frag_rc(sB, wn + 32, kk);
+                b0 = frag_rc(sB, BN * 2, wn, kk);
+                b1 = frag_rc(sB, BN * 2, wn + 32, kk);
             }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
@@ -306,7 +303,6 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (STAGES == 2) stage ^= 1;
-        if (STAGES == 3) stage = (stage == 2) ? 0 : stage + 1;
     }
     if (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC) {   // coalesced 128-B atomic rows straight from the accumulators
 #pragma unroll
@@ -321,11 +317,14 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
                 }
         return;
     }
-    // Stage each wave's 64x64 fp32 sub-tile through its own 16 KiB of (now idle) LDS so that every
-    // lane finishes 4 consecutive columns: bias / residual / mask reads and the output stores
-    // become 16-byte (8-byte for bf16) accesses, 256 B contiguous per output row segment.
+    // Stage each wave's 64x64 fp32 sub-tile through its own slice of the (now idle) LDS, RP rows per pass,
+    // so that every lane finishes 4 consecutive columns: bias / residual / mask reads and the output
+    // stores become 16-byte (8-byte for bf16) accesses, 256 B contiguous per output row segment.
+    constexpr int LDS_PER_WAVE = STAGES * STAGE_BYTES / NW;            // 8/16 KiB (WM=2), 6/12 KiB (WM=4)
+    constexpr int RP = LDS_PER_WAVE >= 16384 ? 64 : (LDS_PER_WAVE >= 8192 ? 32 : 16);   // rows per pass
+    constexpr int NPASS = 64 / RP;
     __syncthreads();
-    float* ct = (float*)smem + w * (STAGES >= 2 ? 4096 : 2048);
+    float* ct = (float*)(smem + w * LDS_PER_WAVE);
     // (only this wave reads its region back; a wave is lock-step, LDS ops are issued in order)
     const int c4 = (lane & 15) * 4, r4 = lane >> 4;
     const int col = tn * BN + wn + c4;
@@ -333,90 +332,47 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : (STAGES == 1 ? 3 : 1)) void 
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && ks == 0 && col_ok) bias4 = *(const float4*)(p.bias + col);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    // STAGES==2: the whole 64x64 tile is staged at once; STAGES==1 (32 KiB LDS): 32 rows at a time
-    constexpr int HALVES = (STAGES >= 2) ? 1 : 2;
 #pragma unroll
-    for (int hf = 0; hf < HALVES; ++hf) {
+    for (int ps = 0; ps < NPASS; ++ps) {
+        // rows [ps*RP, ps*RP+RP) of the wave tile: MFMA block i = row/32, registers with (r>>2) in the pass
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        if (HALVES == 2 && i != hf) continue;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                ct[((HALVES == 2 ? 0 : i * 32) + (r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + lr] = acc[i][j][r];
-    }
+                for (int r = 0; r < 16; ++r) {
+                    const int lrow = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;   // row inside the wave tile
+                    // (the row range test only depends on i and r>>2: resolved at compile time per register)
+                    if ((i * 32 + 8 * (r >> 2)) / RP == ps) ct[(lrow - ps * RP) * 64 + j * 32 + lr] = acc[i][j][r];
+                }
 #pragma unroll 4
-    for (int it = 0; it < 16 / HALVES; ++it) {
-        const int srow = it * 4 + r4;                       // row inside the staged slab
-        const int lrow = srow + (HALVES == 2 ? hf * 32 : 0); // row inside the wave's 64x64 tile
-        const int row = tm * BM + wm + lrow;
-        if (row >= p.M || !col_ok) continue;
-        float4 v = *(const float4*)(ct + srow * 64 + c4);
-        const int64_t idx = zoff + (int64_t)row * p.c_rs + col;
-        v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
-        if (p.act != A3T_ACT_NONE) {
-            v.x = apply_act(v.x, p.act), v.y = apply_act(v.y, p.act);
-            v.z = apply_act(v.z, p.act), v.w = apply_act(v.w, p.act);
-        }
-        if (p.S) {
-            float4 sv;
-            if (p.s_dtype == A3T_BF16) {
-                uint2 t = *(const uint2*)((const u16*)p.S + idx);
-                sv = make_float4(bf2f(t.x & 0xffff), bf2f(t.x >> 16), bf2f(t.y & 0xffff), bf2f(t.y >> 16));
-            } else {
-                sv = *(const float4*)(p.S + idx);
-            }
-            v.x = sv.x > 0.f ? v.x : 0.f, v.y = sv.y > 0.f ? v.y : 0.f;
-            v.z = sv.z > 0.f ? v.z : 0.f, v.w = sv.w > 0.f ? v.w : 0.f;
-        }
-        if (p.drop_inv > 0.f) {
-            const unsigned int i0 = (unsigned int)idx;
-            v.x = rng_keep(p.drop_key, i0 + 0, p.drop_thr) ? v.x * p.drop_inv : 0.f;
-            v.y = rng_keep(p.drop_key, i0 + 1, p.drop_thr) ? v.y * p.drop_inv : 0.f;
-            v.z = rng_keep(p.drop_key, i0 + 2, p.drop_thr) ? v.z * p.drop_inv : 0.f;
-            v.w = rng_keep(p.drop_key, i0 + 3, p.drop_thr) ? v.w * p.drop_inv : 0.f;
-        }
-        v.x *= p.alpha, v.y *= p.alpha, v.z *= p.alpha, v.w *= p.alpha;
-        if (p.R && ks == 0) {
-            float4 rv = *(const float4*)(p.R + idx);
-            v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
-        }
-        cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
-        if (p.c_dtype == A3T_BF16) {
-            uint2 o;
-            o.x = f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-            o.y = f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-            *(uint2*)((u16*)p.C + idx) = o;
-        } else {
-            float* C = (float*)p.C + idx;
-            if (p.accumulate == A3T_ACC_STORE) {
-                *(float4*)C = v;
-            } else if (p.accumulate == A3T_ACC_ADD) {
-                float4 o = *(const float4*)C;
-                o.x += v.x, o.y += v.y, o.z += v.z, o.w += v.w;
-                *(float4*)C = o;
-            } else {
-                atomicAdd(C + 0, v.x), atomicAdd(C + 1, v.y), atomicAdd(C + 2, v.z), atomicAdd(C + 3, v.w);
-            }
+        for (int it = 0; it < RP / 4; ++it) {
+            const int srow = it * 4 + r4;
+            const int row = tm * BM + wm + ps * RP + srow;
+            if (row >= p.M || !col_ok) continue;
+            float4 v = *(const float4*)(ct + srow * 64 + c4);
+            const int64_t idx = zoff + (int64_t)row * p.c_rs + col;
+            epilogue_vec4(p, v, idx, bias4, ks, cs);
         }
     }
-    }
-    if (p.colsum) {   // lanes l, l+16, l+32, l+48 hold the same 4 columns (different rows)
-        cs.x += __shfl_xor(cs.x, 16, 64), cs.y += __shfl_xor(cs.y, 16, 64);
-        cs.z += __shfl_xor(cs.z, 16, 64), cs.w += __shfl_xor(cs.w, 16, 64);
-        cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64);
-        cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
-        if (lane < 16 && col_ok) {
-            float* o = p.colsum + z1 * p.colsum_bs1 + col;
-            atomicAdd(o + 0, p.colsum_scale * cs.x), atomicAdd(o + 1, p.colsum_scale * cs.y);
-            atomicAdd(o + 2, p.colsum_scale * cs.z), atomicAdd(o + 3, p.colsum_scale * cs.w);
-        }
-    }
+    if (p.colsum) colsum_flush(p, cs, lane, col_ok, z1, col);
 }
 
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 static inline bool m8(int64_t v) { return (v % 8) == 0; }
+
+int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_t256.hip
+
+template <int LY, int ST, int WM>
+static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
+    constexpr int lds = ST * (64 * WM + 128) * 64 * 2;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<LY, ST, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, ST, WM>), grid, dim3(128 * WM), lds, stream, pv);
+}
 
 // returns -1 when the descriptor does not meet the alignment contract of this kernel
 int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t stream) {
@@ -437,41 +393,41 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     pv.epi_vec = (p.N % 4 == 0) && (p.c_rs % 4 == 0) && (p.c_bs0 % 4 == 0) && (p.c_bs1 % 4 == 0) &&
                  al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
     if (p.colsum && !pv.epi_vec) return -1;
-    const int tiles_m = (p.M + 127) / 128;
-    dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk)), block(256);
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("A3T_GEMM_STAGES");
-        forced = e ? (e[0] == '1' ? 1 : (e[0] == '3' ? 3 : 2)) : 0;
-        const int l2 = 4 * 128 * 64 * 2;
-        const int l3 = 6 * 128 * 64 * 2;
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, l3);
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, l3);
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_TN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, l3);
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_NN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<L_TN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l2);
+
+    {   // large GEMMs: 256x256 ping-pong kernel (returns -1 when the shape does not qualify)
+        const int rc = a3t_gemm_bf16_t256(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
+        if (rc >= 0) return rc;
     }
-    // many tiles per CU: single LDS buffer, 3-4 co-resident workgroups hide the DMA latency (measured
-    // +8..18 % on the FFN shapes); few tiles per CU: double buffering inside the workgroup wins.
-    const long total_tiles = (long)p.tiles_n * tiles_m * batch * p.splitk;
-    const int stages = forced ? forced : (total_tiles >= 768 ? 1 : 2);
-    const size_t lds = (size_t)stages * 2 * 128 * 64 * 2;
-#define LAUNCH(LY)                                                                                  \
-    do {                                                                                            \
-        if (stages == 2)                                                                            \
-            hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 2>), grid, block, lds, stream, pv);       \
-        else if (stages == 3)                                                                       \
-            hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 3>), grid, block, lds, stream, pv);       \
-        else                                                                                        \
-            hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, 1>), grid, block, lds, stream, pv);       \
-    } while (0)
-    if (AK && BKC)
-        LAUNCH(L_NT);
-    else if (AK && !BKC)
-        LAUNCH(L_NN);
-    else
-        LAUNCH(L_TN);
-#undef LAUNCH
-    return (int)hipGetLastError();
+    static int forced_st = -1, forced_wm = -1;
+    if (forced_st < 0) {
+        const char* e = getenv("A3T_GEMM_STAGES");
+        forced_st = e ? (e[0] == '1' ? 1 : 2) : 0;
+        const char* f = getenv("A3T_GEMM_WM");
+        forced_wm = f ? (f[0] == '4' ? 4 : 2) : 0;
+    }
+    // Variant choice (measured on MI355X, tools/gemm_bench*.py).  The 256-row tile moves 25 % fewer DMA
+    // bytes per flop but halves the co-resident workgroups (register budget: 2 x 8 waves per CU); it only
+    // wins for the long-K, narrow-N NT shape (FFN w_2 forward: 606 -> 696 TFLOP/s) and loses 5-40 % on
+    // everything else, so it is selected for exactly that shape.  Single LDS buffer + co-resident
+    // workgroups when the grid is large, double buffering inside the workgroup when it is small.
+    const long t128 = (long)p.tiles_n * ((p.M + 127) / 128) * batch * p.splitk;
+    const long t256 = (long)p.tiles_n * ((p.M + 255) / 256) * batch * p.splitk;
+    const bool nt = AK && BKC;
+    int wm = forced_wm ? forced_wm : ((nt && p.N <= 512 && p.K >= 2048 && t256 >= 384) ? 4 : 2);
+    if (!nt) wm = 2;
+    const long tiles = (wm == 4) ? t256 : t128;
+    const int stages = forced_st ? forced_st : (tiles >= 768 ? 1 : 2);
+    const int tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
+    dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk));
+    const int ly = (AK && BKC) ? L_NT : (AK ? L_NN : L_TN);
+#define V(LY, ST, WM_)                                  \
+    if (ly == LY && stages == ST && wm == WM_) {         \
+        launch_variant<LY, ST, WM_>(pv, grid, stream);   \
+        return (int)hipGetLastError();                   \
+    }
+    V(L_NT, 1, 2) V(L_NT, 2, 2) V(L_NT, 1, 4) V(L_NT, 2, 4)
+    V(L_NN, 1, 2) V(L_NN, 2, 2)
+    V(L_TN, 1, 2) V(L_TN, 2, 2)
+#undef V
+    return A3T_EINVAL;
 }

@@ -107,3 +107,65 @@ __device__ __forceinline__ void epilogue_store(const GP& p, int64_t zoff, int ro
         atomicAdd(&C[idx], v);
 }
 
+
+// Vector epilogue for 4 consecutive output columns (contract checked on the host: GP::epi_vec):
+// bias -> activation -> ReLU'(S) mask -> dropout -> alpha -> residual -> store; `cs` accumulates the
+// stored values for the fused column sums.  Never used with A3T_ACC_ATOMIC.
+__device__ __forceinline__ void epilogue_vec4(const GP& p, float4 v, int64_t idx, const float4& bias4, int ks, float4& cs) {
+    v.x += bias4.x, v.y += bias4.y, v.z += bias4.z, v.w += bias4.w;
+    if (p.act != A3T_ACT_NONE) {
+        v.x = apply_act(v.x, p.act), v.y = apply_act(v.y, p.act);
+        v.z = apply_act(v.z, p.act), v.w = apply_act(v.w, p.act);
+    }
+    if (p.S) {
+        float4 sv;
+        if (p.s_dtype == A3T_BF16) {
+            uint2 t = *(const uint2*)((const unsigned short*)p.S + idx);
+            sv = make_float4(bf2f(t.x & 0xffff), bf2f(t.x >> 16), bf2f(t.y & 0xffff), bf2f(t.y >> 16));
+        } else {
+            sv = *(const float4*)(p.S + idx);
+        }
+        v.x = sv.x > 0.f ? v.x : 0.f, v.y = sv.y > 0.f ? v.y : 0.f;
+        v.z = sv.z > 0.f ? v.z : 0.f, v.w = sv.w > 0.f ? v.w : 0.f;
+    }
+    if (p.drop_inv > 0.f) {
+        const unsigned int i0 = (unsigned int)idx;
+        v.x = rng_keep(p.drop_key, i0 + 0, p.drop_thr) ? v.x * p.drop_inv : 0.f;
+        v.y = rng_keep(p.drop_key, i0 + 1, p.drop_thr) ? v.y * p.drop_inv : 0.f;
+        v.z = rng_keep(p.drop_key, i0 + 2, p.drop_thr) ? v.z * p.drop_inv : 0.f;
+        v.w = rng_keep(p.drop_key, i0 + 3, p.drop_thr) ? v.w * p.drop_inv : 0.f;
+    }
+    v.x *= p.alpha, v.y *= p.alpha, v.z *= p.alpha, v.w *= p.alpha;
+    if (p.R && ks == 0) {
+        float4 rv = *(const float4*)(p.R + idx);
+        v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+    }
+    cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
+    if (p.c_dtype == A3T_BF16) {
+        uint2 o;
+        o.x = f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+        o.y = f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+        *(uint2*)((unsigned short*)p.C + idx) = o;
+    } else {
+        float* C = (float*)p.C + idx;
+        if (p.accumulate == A3T_ACC_STORE) {
+            *(float4*)C = v;
+        } else {   // A3T_ACC_ADD
+            float4 o = *(const float4*)C;
+            o.x += v.x, o.y += v.y, o.z += v.z, o.w += v.w;
+            *(float4*)C = o;
+        }
+    }
+}
+// lanes l, l+16, l+32, l+48 of a wave hold the same 4 columns (different rows): reduce, then one atomic per column
+__device__ __forceinline__ void colsum_flush(const GP& p, float4 cs, int lane, bool col_ok, int z1, int col) {
+    cs.x += __shfl_xor(cs.x, 16, 64), cs.y += __shfl_xor(cs.y, 16, 64);
+    cs.z += __shfl_xor(cs.z, 16, 64), cs.w += __shfl_xor(cs.w, 16, 64);
+    cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64);
+    cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
+    if (lane < 16 && col_ok) {
+        float* o = p.colsum + z1 * p.colsum_bs1 + col;
+        atomicAdd(o + 0, p.colsum_scale * cs.x), atomicAdd(o + 1, p.colsum_scale * cs.y);
+        atomicAdd(o + 2, p.colsum_scale * cs.z), atomicAdd(o + 3, p.colsum_scale * cs.w);
+    }
+}

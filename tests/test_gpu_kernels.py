@@ -292,3 +292,26 @@ def test_layernorm_bwd_bf16_input_copy_and_fused_column_sum(M, D):
     _close(dg, g.grad, atol=1e-4 * math.sqrt(M), rtol=1e-4)
     _close(db, b.grad, atol=1e-4 * math.sqrt(M), rtol=1e-4)
     _close(cs, 0.5 * ref.sum(0), atol=2e-4 * math.sqrt(M), rtol=1e-4)
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+def test_gemm_256x256_pingpong_kernel(layout):
+    """Shapes that the dispatcher routes to gemm_bf16_t256_kernel (K/splitk >= 4096, >= 200 full 256x256 tiles):
+    bf16 operands, fp32 accumulate, checked against an fp32 matmul of the same bf16-rounded inputs.
+    Transpose-detecting (non-square operands, M != N) and with a ragged last row tile."""
+    ops = _ops()
+    from a3t_amd._lib import BF16
+    M, N, K = 3904 + 256 * 13, 2048, 4096          # 7232 rows: 29 row tiles (last one partial: 64 rows), 8 col tiles
+    x = (_rand(M, K, seed=1) * 0.5).to(DEV).bfloat16()
+    bias = _rand(N, seed=3).to(DEV)
+    if layout == "nt":
+        W = (_rand(N, K, seed=2) * K ** -0.5).to(DEV).bfloat16()
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.linear_fwd(x, W, out, bias=bias, compute=BF16)
+        ref = x.float() @ W.float().t() + bias
+    else:
+        W = (_rand(K, N, seed=2) * K ** -0.5).to(DEV).bfloat16()   # dx = dy @ W with dy := x, W stored [K][N]
+        out = torch.empty(M, N, device=DEV, dtype=torch.float32)
+        ops.linear_bwd_data(x, W, out, compute=BF16)
+        ref = x.float() @ W.float()
+    _close(out, ref, atol=2e-2, rtol=2e-2)

@@ -4,8 +4,9 @@ import torch
 from a3t_amd import ops
 from a3t_amd._lib import BF16
 dev="cuda"
-def timeit(fn, n=10):
-    fn(); torch.cuda.synchronize()
+def timeit(fn, n=30):
+    for _ in range(60): fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
