@@ -51,9 +51,9 @@ _SIGS = {
     "a3t_glu_dwconv_bwd": [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_add_pos_bias": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_add_pos_bias_bwd": [_P, _P, _P, c_int, c_int, c_int, _P],
-    "a3t_relpos_softmax_fwd": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
+    "a3t_relpos_softmax_fwd": [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
                                c_float, ctypes.c_uint32, _P],
-    "a3t_relpos_softmax_bwd": [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
+    "a3t_relpos_softmax_bwd": [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
                                c_float, _P],
     "a3t_mask_fill": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint32,

@@ -8,6 +8,7 @@
 
 #define WAVE 64
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ float bf2f_(unsigned int h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
@@ -283,17 +284,19 @@ extern "C" int a3t_add_pos_bias_bwd(const void* dqu, const void* dqv, void* dqkv
 // Legacy rel_shift (attention.py:145-165) in closed form on the COMPACT BD = (q+v) P^T matrix:
 //   j <= i : BD[i][T-1-(i-j)]     j == i+1 : 0     j > i+1 : BD[i+1][j-i-2]
 // i.e. each shifted row is two contiguous segments of BD -> coalesced reads, no padded copy.
-__device__ __forceinline__ float bd_shift(const float* __restrict__ BDz, int T, int i, int j) {
-    if (j <= i) return BDz[(int64_t)i * T + (T - 1 - i + j)];
+// (Equivalently BD[r][c] <-> flat score index r*(T+1) + c - (T-1): consecutive BD rows are consecutive flat windows
+//  of the score matrix separated by the one skipped element S[r][r+1].)
+__device__ __forceinline__ float bd_shift(const void* __restrict__ BDz, int dt, int T, int i, int j) {
+    if (j <= i) return ldx(BDz, dt, (int64_t)i * T + (T - 1 - i + j));
     if (j == i + 1) return 0.f;
-    return BDz[(int64_t)(i + 1) * T + (j - i - 2)];
+    return ldx(BDz, dt, (int64_t)(i + 1) * T + (j - i - 2));
 }
 
 // one wave per (z, i) row.  NV > 0: the row is read ONCE and kept in NV registers per lane
 // (T <= 64*NV); NV == 0: generic three-pass fallback for very long rows.
 template <int NV>
-__global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __restrict__ ac,
-                                                                 const float* __restrict__ bd,
+__global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const void* __restrict__ ac,
+                                                                 const void* __restrict__ bd, int s_dt,
                                                                  const uint8_t* __restrict__ keymask,
                                                                  void* __restrict__ probs, int p_dt, int H, int T,
                                                                  int64_t ac_bs, int64_t bd_bs, int64_t p_bs,
@@ -305,8 +308,9 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     const int64_t zz = row / T;
     const int i = (int)(row - zz * T);
     const int b = (int)(zz / H);
-    const float* ar = ac + zz * ac_bs + (int64_t)i * T;
-    const float* bz = bd + zz * bd_bs;
+    const int64_t ao = zz * ac_bs + (int64_t)i * T;
+    const void* bz = (s_dt == A3T_BF16) ? (const void*)((const unsigned short*)bd + zz * bd_bs)
+                                        : (const void*)((const float*)bd + zz * bd_bs);
     const uint8_t* mk = keymask + (int64_t)b * T;
     const int64_t po = zz * p_bs + (int64_t)i * T;
     const float NEG = -3.4028235e38f;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
         for (int q = 0; q < NV; ++q) {
             int j = lane + q * 64;
             v[q] = NEG;
-            if (j < T && mk[j]) v[q] = (ar[j] + bd_shift(bz, T, i, j)) * scale;
+            if (j < T && mk[j]) v[q] = (ldx(ac, s_dt, ao + j) + bd_shift(bz, s_dt, T, i, j)) * scale;
             mx = fmaxf(mx, v[q]);
         }
         mx = wmax(mx);
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     int any = 0;
     for (int j = lane; j < T; j += 64)
         if (mk[j]) {
-            mx = fmaxf(mx, (ar[j] + bd_shift(bz, T, i, j)) * scale);
+            mx = fmaxf(mx, (ldx(ac, s_dt, ao + j) + bd_shift(bz, s_dt, T, i, j)) * scale);
             any = 1;
         }
     mx = wmax(mx);
@@ -358,13 +362,106 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
     }
     float s = 0.f;
     for (int j = lane; j < T; j += 64)
-        if (mk[j]) s += expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx);
+        if (mk[j]) s += expf((ldx(ac, s_dt, ao + j) + bd_shift(bz, s_dt, T, i, j)) * scale - mx);
     s = wsum(s);
     const float inv_s = 1.f / s;
     for (int j = lane; j < T; j += 64) {
-        const float pj = mk[j] ? expf((ar[j] + bd_shift(bz, T, i, j)) * scale - mx) * inv_s : 0.f;
+        const float pj = mk[j] ? expf((ldx(ac, s_dt, ao + j) + bd_shift(bz, s_dt, T, i, j)) * scale - mx) * inv_s : 0.f;
         stx(probs, p_dt, po + j, pj);
         if (pdrop) stx(pdrop, p_dt, po + j, rng_keep(key, (unsigned int)(po + j), thr) ? pj * inv : 0.f);
+    }
+}
+
+// ---- all-bf16 fast path (bf16 compute mode): T % 8 == 0, every lane owns NC chunks of 8 consecutive keys, so the
+// row-aligned tensors (ac, key mask, probs, dropped probs, dprobs, ds) move as 16-byte accesses; only the shifted
+// bd / dbd elements (arbitrary 2-byte alignment) are touched one bf16 at a time.
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    f[0] = bf2f_(u.x & 0xffff), f[1] = bf2f_(u.x >> 16), f[2] = bf2f_(u.y & 0xffff), f[3] = bf2f_(u.y >> 16);
+    f[4] = bf2f_(u.z & 0xffff), f[5] = bf2f_(u.z >> 16), f[6] = bf2f_(u.w & 0xffff), f[7] = bf2f_(u.w >> 16);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 u;
+    u.x = io_f2bf(f[0]) | ((unsigned)io_f2bf(f[1]) << 16), u.y = io_f2bf(f[2]) | ((unsigned)io_f2bf(f[3]) << 16);
+    u.z = io_f2bf(f[4]) | ((unsigned)io_f2bf(f[5]) << 16), u.w = io_f2bf(f[6]) | ((unsigned)io_f2bf(f[7]) << 16);
+    return u;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void relpos_softmax_fwd_bf16_kernel(
+    const unsigned short* __restrict__ ac, const unsigned short* __restrict__ bd, const uint8_t* __restrict__ keymask,
+    unsigned short* __restrict__ probs, int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs, float scale,
+    int64_t nrows, unsigned short* __restrict__ pdrop, unsigned int thr, float inv, unsigned int key) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t zz = row / T;
+    const int i = (int)(row - zz * T);
+    const int b = (int)(zz / H);
+    const unsigned short* ar = ac + zz * ac_bs + (int64_t)i * T;
+    const unsigned short* b0 = bd + zz * bd_bs + (int64_t)i * T + (T - 1 - i);   // + j        (j <= i)
+    const unsigned short* b1 = bd + zz * bd_bs + (int64_t)(i + 1) * T - i - 2;   // + j        (j >= i + 2)
+    const uint8_t* mk = keymask + (int64_t)b * T;
+    const int64_t po = zz * p_bs + (int64_t)i * T;
+    const float NEG = -3.4028235e38f;
+    const int nch = T >> 3;
+    float v[NC][8];
+    float mx = NEG;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = lane + q * 64, j0 = c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[q][e] = NEG;
+        if (c < nch) {
+            float a[8];
+            unpack8(*(const uint4*)(ar + j0), a);
+            const uint2 m2 = *(const uint2*)(mk + j0);
+            float bv[8];
+            if (j0 + 7 <= i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = bf2f_(b0[j0 + e]);
+            } else if (j0 >= i + 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = bf2f_(b1[j0 + e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = j0 + e;
+                    bv[e] = (j <= i) ? bf2f_(b0[j]) : (j == i + 1 ? 0.f : bf2f_(b1[j]));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned int mb = ((e < 4 ? m2.x : m2.y) >> (8 * (e & 3))) & 0xff;
+                if (mb) v[q][e] = (a[e] + bv[e]) * scale;
+                mx = fmaxf(mx, v[q][e]);
+            }
+        }
+    }
+    mx = wmax(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[q][e] = (v[q][e] > NEG) ? expf(v[q][e] - mx) : 0.f;
+            s += v[q][e];
+        }
+    s = wsum(s);
+    const float inv_s = s > 0.f ? 1.f / s : 0.f;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = lane + q * 64, j0 = c * 8;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[q][e] * inv_s;
+            *(uint4*)(probs + po + j0) = pack8(o);
+            if (pdrop) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rng_keep(key, (unsigned int)(po + j0 + e), thr) ? o[e] * inv : 0.f;
+                *(uint4*)(pdrop + po + j0) = pack8(o);
+            }
+        }
     }
 }
 
@@ -377,9 +474,17 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_kernel(const float* __
         else if ((T) <= 2048) { CALL(32); } \
         else { CALL(0); }                  \
     } while (0)
+#define SM_DISPATCH_VEC(T, CALL)            \
+    do {                                    \
+        if ((T) <= 512) { CALL(1); }        \
+        else if ((T) <= 1024) { CALL(2); }  \
+        else if ((T) <= 1536) { CALL(3); }  \
+        else { CALL(4); }                   \
+    } while (0)
+static inline bool sm_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, void* probs,
-                                      int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs,
+extern "C" int a3t_relpos_softmax_fwd(const void* ac, const void* bd, int scores_dtype, const uint8_t* keymask,
+                                      void* probs, int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs,
                                       int64_t p_bs, float scale, void* probs_drop, float drop_p, uint32_t drop_key,
                                       void* stream) {
     int64_t nrows = (int64_t)B * H * T;
@@ -387,10 +492,21 @@ extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const ui
     if (drop_p == 0.f) probs_drop = nullptr;
     const unsigned int thr = (unsigned int)((double)drop_p * 4294967296.0);
     const float dinv = 1.f / (1.f - drop_p);
+    if (scores_dtype == A3T_BF16 && probs_dtype == A3T_BF16 && T % 8 == 0 && T <= 2048 && ac_bs % 8 == 0 &&
+        p_bs % 8 == 0 && sm_al16(ac) && sm_al16(probs) && sm_al16(keymask) && (!probs_drop || sm_al16(probs_drop))) {
+#define CALLV(NC)                                                                                                     \
+    hipLaunchKernelGGL(relpos_softmax_fwd_bf16_kernel<NC>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
+                       (hipStream_t)stream, (const unsigned short*)ac, (const unsigned short*)bd, keymask,            \
+                       (unsigned short*)probs, H, T, ac_bs, bd_bs, p_bs, scale, nrows, (unsigned short*)probs_drop, \
+                       thr, dinv, drop_key)
+        SM_DISPATCH_VEC(T, CALLV);
+#undef CALLV
+        return (int)hipGetLastError();
+    }
 #define CALL(NV)                                                                                                 \
     hipLaunchKernelGGL(relpos_softmax_fwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
-                       (hipStream_t)stream, ac, bd, keymask, probs, probs_dtype, H, T, ac_bs, bd_bs, p_bs, scale, nrows, \
-                       probs_drop, thr, dinv, drop_key)
+                       (hipStream_t)stream, ac, bd, scores_dtype, keymask, probs, probs_dtype, H, T, ac_bs, bd_bs, p_bs, \
+                       scale, nrows, probs_drop, thr, dinv, drop_key)
     SM_DISPATCH(T, CALL);
 #undef CALL
     return (int)hipGetLastError();
@@ -400,7 +516,8 @@ extern "C" int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const ui
 // when fp32) and scattered un-shifted into the compact dBD (every dBD element written exactly once).
 template <int NV>
 __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __restrict__ probs, int p_dt,
-                                                                 const float* dprobs, void* ds, void* __restrict__ dbd,
+                                                                 const void* dprobs, int dp_dt, void* ds,
+                                                                 void* __restrict__ dbd,
                                                                  int o_dt, int T, int64_t p_bs, int64_t dp_bs,
                                                                  int64_t o_bs, float scale, int64_t nrows,
                                                                  const void* __restrict__ pdrop, float dinv) {
@@ -416,7 +533,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
     const int64_t zz = row / T;
     const int i = (int)(row - zz * T);
     const int64_t po = zz * p_bs + (int64_t)i * T;
-    const float* dr = dprobs + zz * dp_bs + (int64_t)i * T;
+    const int64_t dro = zz * dp_bs + (int64_t)i * T;
     const int64_t oz = zz * o_bs;
     float pv[NV > 0 ? NV : 1], dv[NV > 0 ? NV : 1];
     float s = 0.f;
@@ -425,11 +542,11 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
         for (int q = 0; q < NV; ++q) {
             int j = lane + q * 64;
             pv[q] = (j < T) ? ldx(probs, p_dt, po + j) : 0.f;
-            dv[q] = (j < T) ? dpv(po + j, dr[j]) : 0.f;
+            dv[q] = (j < T) ? dpv(po + j, ldx(dprobs, dp_dt, dro + j)) : 0.f;
             s += pv[q] * dv[q];
         }
     } else {
-        for (int j = lane; j < T; j += 64) s += ldx(probs, p_dt, po + j) * dpv(po + j, dr[j]);
+        for (int j = lane; j < T; j += 64) s += ldx(probs, p_dt, po + j) * dpv(po + j, ldx(dprobs, dp_dt, dro + j));
     }
     s = wsum(s);
     auto emit = [&](int j, float v) {
@@ -446,22 +563,108 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
             if (j < T) emit(j, pv[q] * (dv[q] - s) * scale);
         }
     } else {
-        for (int j = lane; j < T; j += 64) emit(j, ldx(probs, p_dt, po + j) * (dpv(po + j, dr[j]) - s) * scale);
+        for (int j = lane; j < T; j += 64)
+            emit(j, ldx(probs, p_dt, po + j) * (dpv(po + j, ldx(dprobs, dp_dt, dro + j)) - s) * scale);
     }
     if (i == 0)  // BD[0][0..T-2] never reaches the scores
         for (int j = lane; j < T - 1; j += 64) stx(dbd, o_dt, oz + j, 0.f);
 }
 
-extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const float* dprobs, void* ds, void* dbd,
-                                      int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
-                                      float scale, const void* probs_drop, float drop_p, void* stream) {
+template <int NC>
+__global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
+    const unsigned short* __restrict__ probs, const unsigned short* __restrict__ dprobs, unsigned short* __restrict__ ds,
+    unsigned short* __restrict__ dbd, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs, float scale, int64_t nrows,
+    const unsigned short* __restrict__ pdrop, float dinv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int64_t zz = row / T;
+    const int i = (int)(row - zz * T);
+    const int64_t po = zz * p_bs + (int64_t)i * T;
+    const unsigned short* dr = dprobs + zz * dp_bs + (int64_t)i * T;
+    unsigned short* so = ds + zz * o_bs + (int64_t)i * T;
+    unsigned short* d0 = dbd + zz * o_bs + (int64_t)i * T + (T - 1 - i);    // + j   (j <= i)
+    unsigned short* d1 = dbd + zz * o_bs + (int64_t)(i + 1) * T - i - 2;    // + j   (j >= i + 2)
+    const int nch = T >> 3;
+    float pv[NC][8], dv[NC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = lane + q * 64, j0 = c * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[q][e] = 0.f, dv[q][e] = 0.f;
+        if (c < nch) {
+            unpack8(*(const uint4*)(probs + po + j0), pv[q]);
+            unpack8(*(const uint4*)(dr + j0), dv[q]);
+            if (pdrop) {
+                const uint4 m = *(const uint4*)(pdrop + po + j0);
+                const unsigned int mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned int h = (mw[e >> 1] >> (16 * (e & 1))) & 0x7fff;   // |x| != 0  (ignores -0)
+                    dv[q][e] = h ? dv[q][e] * dinv : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += pv[q][e] * dv[q][e];
+        }
+    }
+    s = wsum(s);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const int c = lane + q * 64, j0 = c * 8;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = pv[q][e] * (dv[q][e] - s) * scale;
+            const uint4 u = pack8(o);
+            *(uint4*)(so + j0) = u;
+            const unsigned int uw[4] = {u.x, u.y, u.z, u.w};
+            if (j0 + 7 <= i) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d0[j0 + e] = (unsigned short)(uw[e >> 1] >> (16 * (e & 1)));
+            } else if (j0 >= i + 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d1[j0 + e] = (unsigned short)(uw[e >> 1] >> (16 * (e & 1)));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = j0 + e;
+                    const unsigned short hv = (unsigned short)(uw[e >> 1] >> (16 * (e & 1)));
+                    if (j <= i)
+                        d0[j] = hv;
+                    else if (j > i + 1)
+                        d1[j] = hv;
+                }
+            }
+        }
+    }
+    if (i == 0)  // BD[0][0..T-2] never reaches the scores
+        for (int j = lane; j < T - 1; j += 64) dbd[zz * o_bs + j] = 0;
+}
+
+extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprobs, int dprobs_dtype, void* ds,
+                                      void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs,
+                                      int64_t o_bs, float scale, const void* probs_drop, float drop_p, void* stream) {
     const float dinv = 1.f / (1.f - drop_p);
     if (drop_p == 0.f) probs_drop = nullptr;
     int64_t nrows = (int64_t)B * H * T;
+    if (probs_dtype == A3T_BF16 && dprobs_dtype == A3T_BF16 && out_dtype == A3T_BF16 && T % 8 == 0 && T <= 2048 &&
+        p_bs % 8 == 0 && dp_bs % 8 == 0 && o_bs % 8 == 0 && sm_al16(probs) && sm_al16(dprobs) && sm_al16(ds) &&
+        (!probs_drop || sm_al16(probs_drop)) && ds != dprobs) {
+#define CALLV(NC)                                                                                                  \
+    hipLaunchKernelGGL(relpos_softmax_bwd_bf16_kernel<NC>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,        \
+                       (hipStream_t)stream, (const unsigned short*)probs, (const unsigned short*)dprobs,          \
+                       (unsigned short*)ds, (unsigned short*)dbd, T, p_bs, dp_bs, o_bs, scale, nrows,             \
+                       (const unsigned short*)probs_drop, dinv)
+        SM_DISPATCH_VEC(T, CALLV);
+#undef CALLV
+        return (int)hipGetLastError();
+    }
 #define CALL(NV)                                                                                                 \
     hipLaunchKernelGGL(relpos_softmax_bwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
-                       (hipStream_t)stream, probs, probs_dtype, dprobs, ds, dbd, out_dtype, T, p_bs, dp_bs, o_bs, scale, nrows, \
-                       probs_drop, dinv)
+                       (hipStream_t)stream, probs, probs_dtype, dprobs, dprobs_dtype, ds, dbd, out_dtype, T, p_bs, dp_bs, \
+                       o_bs, scale, nrows, probs_drop, dinv)
     SM_DISPATCH(T, CALL);
 #undef CALL
     return (int)hipGetLastError();

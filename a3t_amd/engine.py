@@ -202,8 +202,10 @@ class MLMEngine:
         ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
         P = self._act(tag + ".P", (T, d))
         ops.linear_fwd(pos, self.W(pre + ".wpos"), P, compute=cmp)
-        ac = self.ws.get("tmp.ac", (B, H, T, T))
-        bd = self.ws.get("tmp.bd", (B, H, T, T))
+        # score-sized scratch: fp32 in fp32 mode; bf16 logits (fp32 softmax math) in bf16 mode
+        sdt = torch.bfloat16 if self.bf16 else torch.float32
+        ac = self.ws.get("tmp.ac", (B, H, T, T), sdt)
+        bd = self.ws.get("tmp.bd", (B, H, T, T), sdt)
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
         # ac[b,h] = (q+u) k^T ; bd[b,h] = (q+v) P_h^T   (attention.py:190-203)
@@ -243,7 +245,8 @@ class MLMEngine:
         dqkv = self._act("tmp.dqkv", (M, 3 * d))
         dkk = dqkv.view(-1)[d:]
         dvv = dqkv.view(-1)[2 * d:]
-        dpr = self.ws.get("tmp.ac", (B, H, T, T))      # reuse the fp32 score buffers
+        sdt = torch.bfloat16 if self.bf16 else torch.float32
+        dpr = self.ws.get("tmp.ac", (B, H, T, T), sdt)      # reuse the score buffers
         zb = (H * T * T, T * T)
         # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
         ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
@@ -260,7 +263,7 @@ class MLMEngine:
             dbd = self.ws.get("tmp.dbd16", (B, H, T, T), torch.bfloat16)
         else:
             ds = dpr
-            dbd = self.ws.get("tmp.bd", (B, H, T, T))
+            dbd = self.ws.get("tmp.bd", (B, H, T, T), sdt)
         ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=pdrop,
                                drop_p=c.attention_dropout_rate if pdrop is not None else 0.0)
         dqu = self._act("tmp.dqu", (M, d))

@@ -239,14 +239,14 @@ def add_pos_bias_bwd(dqu, dqv, dqkv):
 
 
 def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale, probs_drop=None, drop=(0.0, 0)):
-    L.check(L.load().a3t_relpos_softmax_fwd(_ptr(ac), _ptr(bd), _ptr(keymask), _ptr(probs), _dt(probs), B, H, T,
+    L.check(L.load().a3t_relpos_softmax_fwd(_ptr(ac), _ptr(bd), _dt(ac), _ptr(keymask), _ptr(probs), _dt(probs), B, H, T,
                                             T * T, T * T, T * T, scale, _ptr(probs_drop), drop[0], drop[1],
                                             _stream()), "softmax_fwd")
 
 
 def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, drop_p=0.0):
     """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place)."""
-    L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _dt(probs), _ptr(dprobs), _ptr(ds), _ptr(dbd), _dt(dbd), B, H,
+    L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _dt(probs), _ptr(dprobs), _dt(dprobs), _ptr(ds), _ptr(dbd), _dt(dbd), B, H,
                                             T, T * T, T * T, T * T, scale, _ptr(probs_drop), drop_p, _stream()),
             "softmax_bwd")
 

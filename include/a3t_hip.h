@@ -147,8 +147,9 @@ int a3t_add_pos_bias_bwd(const void* dqu, const void* dqv, void* dqkv, int dtype
  * (masked_fill(min) -> softmax -> masked_fill(0), attention.py:78-86).  bd is the COMPACT
  * (q+v)P^T matrix; the legacy rel_shift (attention.py:145-165) is applied on the fly in closed
  * form: j<=i -> bd[i][T-1-i+j], j==i+1 -> 0, j>i+1 -> bd[i+1][j-i-2].
- * z = b*H + h; keymask uint8 [B][T]; *_bs = per-z strides (elements). */
-int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keymask, void* probs,
+ * z = b*H + h; keymask uint8 [B][T]; *_bs = per-z strides (elements); ac and bd share scores_dtype
+ * (fp32, or bf16 in bf16 compute mode -- the usual bf16-training practice of bf16 logits, fp32 softmax math). */
+int a3t_relpos_softmax_fwd(const void* ac, const void* bd, int scores_dtype, const uint8_t* keymask, void* probs,
                            int probs_dtype, int B, int H, int T, int64_t ac_bs, int64_t bd_bs, int64_t p_bs,
                            float scale, void* probs_drop, float drop_p, uint32_t drop_key, void* stream);
 /* probs_drop (optional, drop_p > 0): the attention-dropout'ed probabilities fed to probs @ V
@@ -156,8 +157,8 @@ int a3t_relpos_softmax_fwd(const float* ac, const float* bd, const uint8_t* keym
 /* ds = probs * (dprobs - sum_j dprobs*probs) * scale (= gradient of ac; may alias dprobs when fp32)
  * and the same values scattered un-shifted into dbd (= gradient of the compact bd; fully
  * overwritten).  ds and dbd share out_dtype and the per-z stride o_bs. */
-int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const float* dprobs, void* ds, void* dbd,
-                           int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
+int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprobs, int dprobs_dtype, void* ds,
+                           void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
                            float scale, const void* probs_drop, float drop_p, void* stream);
 
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */

@@ -315,3 +315,42 @@ def test_gemm_256x256_pingpong_kernel(layout):
         ops.linear_bwd_data(x, W, out, compute=BF16)
         ref = x.float() @ W.float()
     _close(out, ref, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("B,H,T", [(3, 2, 72), (2, 2, 200), (1, 2, 1120), (2, 2, 37)])
+def test_relpos_softmax_bf16_scores(B, H, T):
+    """bf16 compute mode: ac / bd / dprobs / probs / ds / dbd all stored in bf16 (fp32 math inside).  T % 8 == 0
+    takes the 16-byte vector kernels, T = 37 the scalar typed path; both against fp32 torch math on the SAME
+    bf16-rounded inputs, with key padding, a fully padded utterance and attention dropout replayed from the saved
+    dropped probabilities."""
+    ops = _ops()
+    bf = lambda t: t.bfloat16().float()
+    ac = bf(_rand(B, H, T, T, seed=1, scale=3.0)).requires_grad_(True)
+    bd = bf(_rand(B, H, T, T, seed=2, scale=3.0)).requires_grad_(True)
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    if B > 1:
+        mask[1, 0, T // 2:] = False
+    if B > 2:
+        mask[2] = False
+    scale, pdrop_p, key = 0.3, 0.25, 12345
+    s = (ac + O.rel_shift_legacy(bd)) * scale
+    m = mask.unsqueeze(1).eq(0)
+    pr = torch.softmax(s.masked_fill(m, float(np.finfo(np.float32).min)), dim=-1).masked_fill(m, 0.0)
+    probs = torch.empty(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    pd = torch.empty_like(probs)
+    km = mask.view(B, T).to(DEV).view(torch.uint8)
+    ops.relpos_softmax_fwd(ac.detach().to(DEV).bfloat16(), bd.detach().to(DEV).bfloat16(), km, probs, B, H, T, scale,
+                           probs_drop=pd, drop=(pdrop_p, key))
+    _close(probs, pr, atol=4e-3, rtol=1e-2)
+    keep = (pd.float() != 0).cpu()
+    frac = keep[pr > 1e-3].float().mean()
+    assert abs(float(frac) - (1 - pdrop_p)) < 0.05
+    _close(pd.float().cpu()[keep], (probs.float().cpu() / (1 - pdrop_p))[keep], atol=4e-3, rtol=1e-2)
+    # backward: gradient arrives for the DROPPED probabilities
+    dpd = bf(_rand(B, H, T, T, seed=3))
+    (pr * keep.float() / (1 - pdrop_p)).backward(dpd)
+    ds = torch.empty(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    dbd = torch.full((B, H, T, T), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.relpos_softmax_bwd(probs, dpd.to(DEV).bfloat16(), ds, dbd, B, H, T, scale, probs_drop=pd, drop_p=pdrop_p)
+    _close(ds, ac.grad, atol=6e-3, rtol=3e-2)
+    _close(dbd, bd.grad, atol=6e-3, rtol=3e-2)

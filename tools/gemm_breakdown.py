@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 prof, ops.PROFILE = ops.PROFILE, None
 agg = {}
 for name, fl, e0, e1, shape in prof:
-    k = (name[-5:-1], shape)
+    k = (name[name.index("<"):], shape)
     a = agg.setdefault(k, [0, 0.0, 0.0])
     a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += fl
 tot = sum(a[1] for a in agg.values())
