@@ -40,15 +40,25 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const void* __restr
     const int pad = (K - 1) / 2;
     const int64_t mbase = (int64_t)b * Tseq;
     const int rows = DW_TT + K - 1;
-    for (int r = ty; r < rows; r += 4) {
-        int t = t0 - pad + r;
-        float v = 0.f;
-        if (c < C && t >= 0 && t < Tseq) {
-            const int64_t gi = (mbase + t) * (int64_t)(2 * C);
-            v = ldx(g, g_dt, gi + c) * sigm(ldx(g, g_dt, gi + C + c));
-            if (r >= pad && r < pad + DW_TT) stx(glu, glu_dt, (mbase + t) * (int64_t)C + c, v);
+    // (batches of 8 rows per thread, loads issued back to back -- see the backward kernel)
+    for (int rb = ty; rb < rows; rb += 32) {
+        float ga[8], gb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rb + 4 * u, t = t0 - pad + r;
+            const bool ok = (c < C) && (r < rows) && (t >= 0) && (t < Tseq);
+            const int64_t gi = ok ? (mbase + t) * (int64_t)(2 * C) + c : 0;
+            ga[u] = ldx(g, g_dt, gi);
+            gb[u] = ldx(g, g_dt, gi + (ok ? C : 0));
         }
-        win[r][tx] = v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = rb + 4 * u, t = t0 - pad + r;
+            const bool ok = (c < C) && (r < rows) && (t >= 0) && (t < Tseq);
+            const float v = ok ? ga[u] * sigm(gb[u]) : 0.f;
+            if (ok && r >= pad && r < pad + DW_TT) stx(glu, glu_dt, (mbase + t) * (int64_t)C + c, v);
+            if (r < rows) win[r][tx] = v;
+        }
     }
     __syncthreads();
     if (c >= C) return;
@@ -103,7 +113,7 @@ extern "C" int a3t_glu_dwconv_fwd(const void* g, int g_dtype, const float* wdw, 
 // One block = 64 channels x `tiles_per_block` consecutive time tiles of one utterance: the weight
 // gradient partials stay in registers across the tiles, so the LDS reduction + atomics happen once.
 template <int KT>
-__global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __restrict__ dz, const void* __restrict__ g,
+__global__ __launch_bounds__(256, 3) void glu_dwconv_bwd_kernel(const float* __restrict__ dz, const void* __restrict__ g,
                                                              int g_dt, const void* __restrict__ glu, int glu_dt,
                                                              const float* __restrict__ wdw, void* __restrict__ dg,
                                                              int dg_dt, float* dwdw, float* dbdw, float* dgsum, int C,
@@ -127,40 +137,85 @@ __global__ __launch_bounds__(256) void glu_dwconv_bwd_kernel(const float* __rest
     float db = 0.f, sga = 0.f, sgb = 0.f;
     for (int tile = tile0; tile < min(tiles_t, tile0 + tiles_per_block); ++tile) {
         const int t0 = tile * DW_TT;
-        __syncthreads();
-        for (int r = ty; r < rows; r += 4) {
-            int t = t0 - pad + r;
-            float a = 0.f, q = 0.f;
-            if (c < C && t >= 0 && t < Tseq) {
-                a = dz[(mbase + t) * (int64_t)C + c];
-                q = ldx(glu, glu_dt, (mbase + t) * (int64_t)C + c);
+        // The GLU inputs of this thread's next 4 outputs are requested one step ahead (first group: before the window
+        // staging), so the loads complete under LDS work / FMAs instead of one dependent HBM round trip per output.
+        float gan[4], gbn[4];
+        auto prefetch_g = [&](int i) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int t = t0 + ty * 4 + 16 * i + tt;
+                gan[tt] = gbn[tt] = 0.f;
+                if (c < C && t < Tseq) {
+                    const int64_t gi = (mbase + t) * (int64_t)(2 * C);
+                    gan[tt] = ldx(g, g_dt, gi + c);
+                    gbn[tt] = ldx(g, g_dt, gi + C + c);
+                }
             }
-            wdz[r][tx] = a;
-            wgl[r][tx] = q;
+        };
+        if (K == KT) prefetch_g(0);
+        __syncthreads();
+        // window staging in batches of 8 rows per thread: the 16 loads of a batch are issued back to back (invalid
+        // rows read element 0 and are zeroed by a select -- no branch that would serialise one round trip per row)
+        for (int rb = ty; rb < rows; rb += 32) {
+            float a[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 4 * u, t = t0 - pad + r;
+                const bool ok = (c < C) && (r < rows) && (t >= 0) && (t < Tseq);
+                const int64_t idx = ok ? (mbase + t) * (int64_t)C + c : 0;
+                a[u] = dz[idx];
+                q[u] = ldx(glu, glu_dt, idx);
+                a[u] = ok ? a[u] : 0.f;
+                q[u] = ok ? q[u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + 4 * u;
+                if (r < rows) wdz[r][tx] = a[u], wgl[r][tx] = q[u];
+            }
         }
         __syncthreads();
         if (c < C && K == KT) {   // register-blocked: 4 consecutive time steps per window read
-            for (int r0 = ty * 4; r0 < DW_TT; r0 += 16) {
-                float u[KT + 3], q[KT + 3];
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) {
+                const int r0 = ty * 4 + 16 * i;
+                float ga[4], gb[4];
 #pragma unroll
-                for (int j = 0; j < KT + 3; ++j) {
-                    u[j] = wdz[r0 + j][tx];
-                    q[j] = wgl[r0 + j][tx];
+                for (int tt = 0; tt < 4; ++tt) ga[tt] = gan[tt], gb[tt] = gbn[tt];
+                if (i < 3) prefetch_g(i + 1);
+                float acc[4], dzt[4];
+                {   // data gradient: dglu[t] = sum_k w[k] * dz[t + pad - k]
+                    float u[KT + 3];
+#pragma unroll
+                    for (int j = 0; j < KT + 3; ++j) u[j] = wdz[r0 + j][tx];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) a += w[k] * u[tt + KT - 1 - k];
+                        acc[tt] = a;
+                        dzt[tt] = u[tt + (KT - 1) / 2];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the two 34-value windows from being live at once
+                {   // weight gradient: dw[k] += dz[t] * glu[t + k - pad]
+                    float q[KT + 3];
+#pragma unroll
+                    for (int j = 0; j < KT + 3; ++j) q[j] = wgl[r0 + j][tx];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+                        for (int k = 0; k < KT; ++k) dw[k] += dzt[tt] * q[tt + k];
+                        db += dzt[tt];
+                    }
                 }
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
-                    float acc = 0.f;   // dglu[t] = sum_k w[k] * dz[t + pad - k]
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) acc += w[k] * u[tt + KT - 1 - k];
-                    const float dzt = u[tt + (KT - 1) / 2];
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) dw[k] += dzt * q[tt + k];
-                    db += dzt;
-                    int t = t0 + r0 + tt;
+                    const int t = t0 + r0 + tt;
                     if (t < Tseq) {
                         const int64_t gi = (mbase + t) * (int64_t)(2 * C);
-                        float ga = ldx(g, g_dt, gi + c), sb = sigm(ldx(g, g_dt, gi + C + c));
-                        const float da = acc * sb, dbb = acc * ga * sb * (1.f - sb);
+                        const float sb = sigm(gb[tt]);
+                        const float da = acc[tt] * sb, dbb = acc[tt] * ga[tt] * sb * (1.f - sb);
                         stx(dg, dg_dt, gi + c, da);
                         stx(dg, dg_dt, gi + C + c, dbb);
                         sga += da, sgb += dbb;

@@ -2,6 +2,7 @@
 // LayerNorm fwd/bwd (one wave64 per row, __shfl_xor butterflies), column reductions with
 // double-precision atomics (bias grads, BatchNorm statistics), BatchNorm(+Swish/tanh) fwd/bwd.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "../../include/a3t_hip.h"
 #include "dtype_io.h"
@@ -147,8 +148,13 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
     for (int row = (blockIdx.x * 4 + wv) * 2 + half; row < M; row += gridDim.x * 8) {
         const float mu = mean[row], rs = rstd[row];
         const int64_t ro = (int64_t)row * D;
-        float4 xh[NQ], dg[NQ];
+        float4 xh[NQ], dg[NQ], rr[NQ];
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {   // the residual gradient is requested with the row, not after the reduction
+            rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dres) rr[i] = *(const float4*)(dres + ro + (hl + 32 * i) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int c = (hl + 32 * i) * 4;
@@ -178,10 +184,7 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
             const int c = (hl + 32 * i) * 4;
             float4 o = make_float4(rs * (dg[i].x - s1 - xh[i].x * s2), rs * (dg[i].y - s1 - xh[i].y * s2),
                                    rs * (dg[i].z - s1 - xh[i].z * s2), rs * (dg[i].w - s1 - xh[i].w * s2));
-            if (dres) {
-                float4 r = *(const float4*)(dres + ro + c);
-                o.x += r.x, o.y += r.y, o.z += r.z, o.w += r.w;
-            }
+            o.x += rr[i].x, o.y += rr[i].y, o.z += rr[i].z, o.w += rr[i].w;
             *(float4*)(dx + ro + c) = o;
             if (dx16) {
                 uint2 h;
@@ -248,7 +251,15 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
     if (D % 128 == 0 && D <= 512 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
         (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)gamma % 16 == 0)) {
         int vb = (M + 7) / 8;
-        if (vb > 2048) vb = 2048;
+        static int vb_max = 0;
+        if (!vb_max) {
+            const char* e = getenv("A3T_LN_BLOCKS");
+            // 2 workgroups per CU: every workgroup ends with 3*D same-address atomics (dgamma, dbeta, dx column sums),
+            // and with 2048 workgroups that serialised tail cost more than the row streaming itself (66 -> 45 us at
+            // M = 35840, D = 384: tools/ln_bench.py)
+            vb_max = e ? atoi(e) : 512;
+        }
+        if (vb > vb_max) vb = vb_max;
 #define VCALL(NQ)                                                                                                   \
     hipLaunchKernelGGL(ln_bwd_vec_kernel<NQ>, dim3(vb), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
                        rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D)
