@@ -93,9 +93,18 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const void* __restr
     }
 }
 
+// 16-byte-per-lane fast paths for bf16 storage (dwconv_vec.hip)
+int a3t_glu_dwconv_fwd_vec(const void* g, const float* wdw, const float* bdw, void* glu, float* z, int M, int C, int K,
+                           int Tseq, hipStream_t stream);
+int a3t_glu_dwconv_bwd_vec(const float* dz, const void* g, const void* glu, const float* wdw, void* dg, float* dwdw,
+                           float* dbdw, float* dg_colsum, int M, int C, int K, int Tseq, hipStream_t stream);
+static inline bool dw_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 extern "C" int a3t_glu_dwconv_fwd(const void* g, int g_dtype, const float* wdw, const float* bdw, void* glu,
                                   int glu_dtype, float* z, int M, int C, int K, int Tseq, void* stream) {
     if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
+    if (g_dtype == A3T_BF16 && glu_dtype == A3T_BF16 && C % 64 == 0 && dw_al16(g) && dw_al16(glu) && dw_al16(z))
+        return a3t_glu_dwconv_fwd_vec(g, wdw, bdw, glu, z, M, C, K, Tseq, (hipStream_t)stream);
     int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
     dim3 grid((C + 63) / 64, B * tiles_t);
     if (K <= 7)
@@ -274,6 +283,9 @@ extern "C" int a3t_glu_dwconv_bwd(const float* dz, const void* g, int g_dtype, c
                                   const float* wdw, void* dg, int dg_dtype, float* dwdw, float* dbdw, float* dg_colsum,
                                   int M, int C, int K, int Tseq, void* stream) {
     if (K > DW_KMAX || (K & 1) == 0 || Tseq <= 0 || M % Tseq) return A3T_EINVAL;
+    if (g_dtype == A3T_BF16 && glu_dtype == A3T_BF16 && dg_dtype == A3T_BF16 && C % 64 == 0 && dw_al16(g) &&
+        dw_al16(glu) && dw_al16(dg) && dw_al16(dz))
+        return a3t_glu_dwconv_bwd_vec(dz, g, glu, wdw, dg, dwdw, dbdw, dg_colsum, M, C, K, Tseq, (hipStream_t)stream);
     int B = M / Tseq, tiles_t = (Tseq + DW_TT - 1) / DW_TT;
     // enough blocks to fill 256 CUs a few times, as few weight-gradient reductions as possible
     int cb = (C + 63) / 64;

@@ -354,3 +354,32 @@ def test_relpos_softmax_bf16_scores(B, H, T):
     ops.relpos_softmax_bwd(probs, dpd.to(DEV).bfloat16(), ds, dbd, B, H, T, scale, probs_drop=pd, drop_p=pdrop_p)
     _close(ds, ac.grad, atol=6e-3, rtol=3e-2)
     _close(dbd, bd.grad, atol=6e-3, rtol=3e-2)
+
+
+@pytest.mark.parametrize("B,T,C,K", [(2, 150, 64, 7), (3, 130, 128, 31), (1, 70, 384, 5), (2, 1120, 384, 31)])
+def test_glu_dwconv_bf16_vector_path(B, T, C, K):
+    """bf16 storage, C % 64 == 0 -> dwconv_vec.hip (16-byte lane accesses).  Reference: fp32 torch math on the same
+    bf16-rounded g; the backward feeds the kernel's own bf16 glu (as the engine does)."""
+    ops = _ops()
+    g = _rand(B, T, 2 * C, seed=1).bfloat16().float().requires_grad_(True)
+    w = _rand(C, 1, K, seed=2, scale=K ** -0.5).requires_grad_(True)
+    b = _rand(C, seed=3).requires_grad_(True)
+    glu = F.glu(g.transpose(1, 2), dim=1)
+    z = F.conv1d(glu, w, b, padding=(K - 1) // 2, groups=C).transpose(1, 2)
+    dz = _rand(B, T, C, seed=4)
+    z.backward(dz)
+    gd = g.detach().reshape(B * T, 2 * C).to(DEV).bfloat16()
+    wd, bd = w.detach().reshape(C, K).contiguous().to(DEV), b.detach().to(DEV)
+    glud = torch.empty(B * T, C, device=DEV, dtype=torch.bfloat16)
+    zd = torch.empty(B * T, C, device=DEV)
+    ops.glu_dwconv_fwd(gd, wd, bd, glud, zd, T)
+    _close(glud.view(B, T, C), glu.transpose(1, 2), atol=1e-2, rtol=1e-2)
+    _close(zd.view(B, T, C), z, atol=2e-5, rtol=1e-4)       # the conv reads the un-rounded GLU window
+    dg = torch.empty(B * T, 2 * C, device=DEV, dtype=torch.bfloat16)
+    dw, dbb, dgs = torch.zeros(C, K, device=DEV), torch.zeros(C, device=DEV), torch.zeros(2 * C, device=DEV)
+    ops.glu_dwconv_bwd(dz.reshape(B * T, C).to(DEV), gd, glud, wd, dg, dw, dbb, T, dgsum=dgs)
+    _close(dg.view(B, T, 2 * C), g.grad, atol=2e-2, rtol=2e-2)
+    scale = float(w.grad.abs().max())
+    _close(dw, w.grad.view(C, K), atol=1e-2 * scale, rtol=2e-2)   # glu enters the weight gradient bf16-rounded
+    _close(dbb, b.grad, atol=1e-3 * float(b.grad.abs().max()) + 1e-4, rtol=1e-4)
+    _close(dgs, g.grad.reshape(-1, 2 * C).sum(0), atol=2e-2 * float(g.grad.abs().sum(dim=(0, 1)).max()) / 10, rtol=5e-2)
