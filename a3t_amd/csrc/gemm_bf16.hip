@@ -35,8 +35,12 @@ __device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 
-template <int LAYOUT, int STAGES, int WM>
-__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : 3))) void gemm_bf16_glds_kernel(GP p) {
+// CONV = false: plain GEMM (taps == 1, no token shift): the im2col / shift bookkeeping is compiled out, which brings the
+// single-buffer variant under 128 VGPRs -> 4 workgroups per CU (1024 slots: the 840-tile N = 384 GEMMs run in one round)
+template <int LAYOUT, int STAGES, int WM, bool CONV>
+__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : (CONV ? 3 : 4)))) void gemm_bf16_glds_kernel(GP p) {
+    const int TAPS = CONV ? p.taps : 1;
+    const int KSM = CONV ? p.kshift_mode : 0;
     constexpr int NW = 2 * WM;                 // waves
     constexpr int BM = 64 * WM, BN = 128, BK = 64;
     constexpr bool A_KC = (LAYOUT != L_TN), B_KC = (LAYOUT == L_NT);
@@ -70,8 +74,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
     const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
     if (kt0 >= kt1) return;
 
-    const bool WG = (LAYOUT == L_TN) && (p.taps > 1);
-    const int wg_cin = WG ? p.N / p.taps : 1;
+    const bool WG = (LAYOUT == L_TN) && (TAPS > 1);
+    const int wg_cin = WG ? p.N / TAPS : 1;
     const int wg_tap = WG ? (tn * BN) / wg_cin : 0;
     const int kshift = WG ? (wg_tap - p.pad) * p.dil : p.kshift;
 
@@ -99,10 +103,10 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
             int r = g * 8 + (lane >> 3);
             int m = tm * BM + r;
             a_ok[q] = m < p.M;
-            a_tp[q] = (p.taps > 1) ? (m % p.Tseq) : 0;
+            a_tp[q] = (TAPS > 1) ? (m % p.Tseq) : 0;
             a_row[q] = A + (int64_t)m * p.a_rs;
             a_sw[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-            if (p.taps > 1) {
+            if (TAPS > 1) {
                 int kg = kt0 * BK + a_sw[q];
                 a_tap[q] = kg / p.Kc;
                 a_cc[q] = kg - a_tap[q] * p.Kc;
@@ -139,10 +143,10 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
                 // lies inside one tap (Cin % 128 == 0), which fixes this block's token shift
                 b_row[q] = B + (col - wg_tap * wg_cin);
                 b_cc[q] = kg % p.Tseq;
-            } else if (p.taps > 1) {
+            } else if (TAPS > 1) {
                 b_tap[q] = kg / p.Kc;
                 b_cc[q] = kg - b_tap[q] * p.Kc;
-            } else if (p.kshift_mode) {
+            } else if (KSM) {
                 b_cc[q] = kg % p.Tseq;
             }
         }
@@ -151,8 +155,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
     // Uniform (scalar) decomposition of the tile's first k into (tap, channel): when the channel count is
     // a multiple of BK every lane of a tile works on the same tap, so the im2col row shift, its 64-bit
     // row offset and the validity test reduce to a few VALU ops and one v_cndmask per DMA (no branches).
-    const bool a_fast = A_KC && p.taps > 1 && (p.Kc % BK == 0);
-    const bool b_fast = !B_KC && !WG && p.taps > 1 && (p.Kc % BK == 0);
+    const bool a_fast = A_KC && TAPS > 1 && (p.Kc % BK == 0);
+    const bool b_fast = !B_KC && !WG && TAPS > 1 && (p.Kc % BK == 0);
     const bool ks_fast = p.Tseq >= BK;
     int u_tap = 0, u_cc = 0;
     if (a_fast || b_fast) {
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
                 const u16* src = ZP;
                 const int kg = k0 + a_sw[q];
                 if (A_KC) {
-                    if (p.taps > 1) {
+                    if (TAPS > 1) {
                         if (a_ok[q] && kg < p.K) {
                             int off = (a_tap[q] - p.pad) * p.dil, tt = a_tp[q] + off;
                             if (tt >= 0 && tt < p.Tseq) src = a_row[q] + (int64_t)off * p.a_rs + a_cc[q];
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
             }
         }
         if (B_KC) {
-            const bool split = (p.taps > 1 && p.b_ts != p.Kc);   // (weights are [n][tap][c]: b_ts == Kc, no split)
+            const bool split = (TAPS > 1 && p.b_ts != p.Kc);   // (weights are [n][tap][c]: b_ts == Kc, no split)
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int kg = k0 + b_sw[q];
@@ -218,11 +222,11 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
             for (int q = 0; q < NB; ++q) {
                 const u16* src = ZP;
                 const int kg = k0 + b_sw[q];
-                if (!WG && p.taps > 1) {
+                if (!WG && TAPS > 1) {
                     if (b_ok[q] && kg < p.K) src = b_row[q] + (int64_t)b_tap[q] * p.b_ts + (int64_t)b_cc[q] * p.b_cs;
                     b_cc[q] += BK;
                     while (b_cc[q] >= p.Kc) b_cc[q] -= p.Kc, ++b_tap[q];
-                } else if (WG || p.kshift_mode) {
+                } else if (WG || KSM) {
                     const bool ok = b_ok[q] && kg < p.K && ((unsigned)(b_cc[q] + kshift) < (unsigned)p.Tseq);
                     src = ok ? b_row[q] + (int64_t)(kg + kshift) * p.b_cs : ZP;
                     b_cc[q] += BK;
@@ -363,15 +367,15 @@ static inline bool m8(int64_t v) { return (v % 8) == 0; }
 
 int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_t256.hip
 
-template <int LY, int ST, int WM>
+template <int LY, int ST, int WM, bool CV>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
     constexpr int lds = ST * (64 * WM + 128) * 64 * 2;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<LY, ST, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<LY, ST, WM, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, ST, WM>), grid, dim3(128 * WM), lds, stream, pv);
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, ST, WM, CV>), grid, dim3(128 * WM), lds, stream, pv);
 }
 
 // returns -1 when the descriptor does not meet the alignment contract of this kernel
@@ -420,14 +424,16 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     const int tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
     dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk));
     const int ly = (AK && BKC) ? L_NT : (AK ? L_NN : L_TN);
-#define V(LY, ST, WM_)                                  \
-    if (ly == LY && stages == ST && wm == WM_) {         \
-        launch_variant<LY, ST, WM_>(pv, grid, stream);   \
-        return (int)hipGetLastError();                   \
+    const bool conv = (p.taps > 1) || p.kshift_mode;
+#define V(LY, ST, WM_, CV)                                   \
+    if (ly == LY && stages == ST && wm == WM_ && conv == CV) { \
+        launch_variant<LY, ST, WM_, CV>(pv, grid, stream);     \
+        return (int)hipGetLastError();                         \
     }
-    V(L_NT, 1, 2) V(L_NT, 2, 2) V(L_NT, 1, 4) V(L_NT, 2, 4)
-    V(L_NN, 1, 2) V(L_NN, 2, 2)
-    V(L_TN, 1, 2) V(L_TN, 2, 2)
+    V(L_NT, 1, 2, false) V(L_NT, 2, 2, false) V(L_NT, 1, 4, false) V(L_NT, 2, 4, false)
+    V(L_NT, 1, 2, true) V(L_NT, 2, 2, true) V(L_NT, 1, 4, true) V(L_NT, 2, 4, true)
+    V(L_NN, 1, 2, false) V(L_NN, 2, 2, false) V(L_NN, 1, 2, true) V(L_NN, 2, 2, true)
+    V(L_TN, 1, 2, false) V(L_TN, 2, 2, false) V(L_TN, 1, 2, true) V(L_TN, 2, 2, true)
 #undef V
     return A3T_EINVAL;
 }
