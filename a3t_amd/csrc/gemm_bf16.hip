@@ -35,10 +35,12 @@ __device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 
-// CONV = false: plain GEMM (taps == 1, no token shift): the im2col / shift bookkeeping is compiled out, which brings the
+// CONV = 0: plain GEMM (taps == 1, no token shift): the im2col / shift bookkeeping is compiled out, which brings the
 // single-buffer variant under 128 VGPRs -> 4 workgroups per CU (1024 slots: the 840-tile N = 384 GEMMs run in one round)
-template <int LAYOUT, int STAGES, int WM, bool CONV>
-__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : (CONV ? 3 : 4)))) void gemm_bf16_glds_kernel(GP p) {
+// CONV = 1: conv / data-gradient GEMM whose channel count is a multiple of BK (one tap per K-tile, uniform tracking only);
+// CONV = 2: generic per-lane (tap, channel) tracking, fused conv weight gradient, token-shifted weight gradient.
+template <int LAYOUT, int STAGES, int WM, int CONV>
+__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : ((CONV == 2 || (CONV == 1 && LAYOUT == L_NN)) ? 3 : 4)))) void gemm_bf16_glds_kernel(GP p) {
     const int TAPS = CONV ? p.taps : 1;
     const int KSM = CONV ? p.kshift_mode : 0;
     constexpr int NW = 2 * WM;                 // waves
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
     const int kt0 = ks * per, kt1 = min(ktiles, kt0 + per);
     if (kt0 >= kt1) return;
 
-    const bool WG = (LAYOUT == L_TN) && (TAPS > 1);
+    const bool WG = (CONV == 2) && (LAYOUT == L_TN) && (TAPS > 1);
     const int wg_cin = WG ? p.N / TAPS : 1;
     const int wg_tap = WG ? (tn * BN) / wg_cin : 0;
     const int kshift = WG ? (wg_tap - p.pad) * p.dil : p.kshift;
@@ -155,8 +157,8 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
     // Uniform (scalar) decomposition of the tile's first k into (tap, channel): when the channel count is
     // a multiple of BK every lane of a tile works on the same tap, so the im2col row shift, its 64-bit
     // row offset and the validity test reduce to a few VALU ops and one v_cndmask per DMA (no branches).
-    const bool a_fast = A_KC && TAPS > 1 && (p.Kc % BK == 0);
-    const bool b_fast = !B_KC && !WG && TAPS > 1 && (p.Kc % BK == 0);
+    const bool a_fast = (CONV == 1) ? A_KC : (A_KC && TAPS > 1 && (p.Kc % BK == 0));
+    const bool b_fast = (CONV == 1) ? !B_KC : (!B_KC && !WG && TAPS > 1 && (p.Kc % BK == 0));
     const bool ks_fast = p.Tseq >= BK;
     int u_tap = 0, u_cc = 0;
     if (a_fast || b_fast) {
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
             }
         }
         if (B_KC) {
-            const bool split = (TAPS > 1 && p.b_ts != p.Kc);   // (weights are [n][tap][c]: b_ts == Kc, no split)
+            const bool split = (CONV == 2) && (TAPS > 1 && p.b_ts != p.Kc);   // (weights are [n][tap][c]: b_ts == Kc, no split)
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int kg = k0 + b_sw[q];
@@ -367,7 +369,7 @@ static inline bool m8(int64_t v) { return (v % 8) == 0; }
 
 int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_t256.hip
 
-template <int LY, int ST, int WM, bool CV>
+template <int LY, int ST, int WM, int CV>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
     constexpr int lds = ST * (64 * WM + 128) * 64 * 2;
     static bool attr = false;
@@ -424,16 +426,19 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     const int tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
     dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk));
     const int ly = (AK && BKC) ? L_NT : (AK ? L_NN : L_TN);
-    const bool conv = (p.taps > 1) || p.kshift_mode;
+    int conv = 0;
+    if (p.taps > 1 || p.kshift_mode)
+        conv = (p.taps > 1 && ly != L_TN && p.Kc % 64 == 0 && p.K % 64 == 0 && (ly != L_NT || p.b_ts == p.Kc)) ? 1 : 2;
 #define V(LY, ST, WM_, CV)                                   \
     if (ly == LY && stages == ST && wm == WM_ && conv == CV) { \
         launch_variant<LY, ST, WM_, CV>(pv, grid, stream);     \
         return (int)hipGetLastError();                         \
     }
-    V(L_NT, 1, 2, false) V(L_NT, 2, 2, false) V(L_NT, 1, 4, false) V(L_NT, 2, 4, false)
-    V(L_NT, 1, 2, true) V(L_NT, 2, 2, true) V(L_NT, 1, 4, true) V(L_NT, 2, 4, true)
-    V(L_NN, 1, 2, false) V(L_NN, 2, 2, false) V(L_NN, 1, 2, true) V(L_NN, 2, 2, true)
-    V(L_TN, 1, 2, false) V(L_TN, 2, 2, false) V(L_TN, 1, 2, true) V(L_TN, 2, 2, true)
+    V(L_NT, 1, 2, 0) V(L_NT, 2, 2, 0) V(L_NT, 1, 4, 0) V(L_NT, 2, 4, 0)
+    V(L_NT, 1, 2, 1) V(L_NT, 2, 2, 1) V(L_NT, 1, 4, 1) V(L_NT, 2, 4, 1)
+    V(L_NT, 1, 2, 2) V(L_NT, 2, 2, 2) V(L_NT, 1, 4, 2) V(L_NT, 2, 4, 2)
+    V(L_NN, 1, 2, 0) V(L_NN, 2, 2, 0) V(L_NN, 1, 2, 1) V(L_NN, 2, 2, 1) V(L_NN, 1, 2, 2) V(L_NN, 2, 2, 2)
+    V(L_TN, 1, 2, 0) V(L_TN, 2, 2, 0) V(L_TN, 1, 2, 2) V(L_TN, 2, 2, 2)
 #undef V
     return A3T_EINVAL;
 }
