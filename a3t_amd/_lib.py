@@ -81,7 +81,7 @@ _SIGS = {
     "a3t_dropout": [_P, c_int, _P, c_int, c_int64, c_float, ctypes.c_uint32, c_float, _P],
     "a3t_dropout_bwd_cast": [_P, _P, c_int, _P, c_float, c_int, c_int, c_float, ctypes.c_uint32, _P],
 }
-EXPORTS = sorted(list(_SIGS) + ["a3t_version"])
+EXPORTS = sorted(list(_SIGS) + ["a3t_version", "a3t_gemm_last_kernel"])
 
 _lib = None
 
@@ -106,6 +106,8 @@ def load():
         fn.restype = c_int
     lib.a3t_version.restype = c_char_p
     lib.a3t_version.argtypes = []
+    lib.a3t_gemm_last_kernel.restype = c_char_p
+    lib.a3t_gemm_last_kernel.argtypes = []
     _lib = lib
     return lib
 

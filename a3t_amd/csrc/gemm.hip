@@ -21,6 +21,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t stream);
 
+#include <stdarg.h>
+#include <stdio.h>
+static thread_local char g_last_kernel[128] = "";
+void a3t_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* a3t_gemm_last_kernel(void) { return g_last_kernel; }
+
 // =============================================================================================
 // fp32 MFMA kernel: LDS tiles are k-major ([BK][BM+4]) so a lane's single-float fragment read is
 // conflict free (lanes 0-31 -> 32 consecutive rows, lanes 32-63 -> next k).
@@ -492,6 +503,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         else
             LAUNCH_F32(false, false);
 #undef LAUNCH_F32
+        a3t_note_kernel("gemm_f32_kernel<%s, %s, %s>", AK ? "true" : "false", BKC ? "true" : "false", vec ? "true" : "false");
         return (int)hipGetLastError();
     }
     if (d->compute != A3T_BF16) return A3T_EINVAL;
@@ -533,5 +545,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     else
         LAUNCH_BF(unsigned short, unsigned short);
 #undef LAUNCH_BF
+    a3t_note_kernel("gemm_bf16_kernel<%s, %s, %s, %s>", d->a_dtype == A3T_F32 ? "float" : "unsigned short",
+                    d->b_dtype == A3T_F32 ? "float" : "unsigned short", AK ? "true" : "false", BKC ? "true" : "false");
     return (int)hipGetLastError();
 }

@@ -40,7 +40,7 @@ enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 // CONV = 1: conv / data-gradient GEMM whose channel count is a multiple of BK (one tap per K-tile, uniform tracking only);
 // CONV = 2: generic per-lane (tap, channel) tracking, fused conv weight gradient, token-shifted weight gradient.
 template <int LAYOUT, int STAGES, int WM, int CONV>
-__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : ((CONV == 2 || (CONV == 1 && LAYOUT == L_NN)) ? 3 : 4)))) void gemm_bf16_glds_kernel(GP p) {
+__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : (CONV == 2 ? 3 : 4)))) void gemm_bf16_glds_kernel(GP p) {
     const int TAPS = CONV ? p.taps : 1;
     const int KSM = CONV ? p.kshift_mode : 0;
     constexpr int NW = 2 * WM;                 // waves
@@ -157,6 +157,14 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
     // Uniform (scalar) decomposition of the tile's first k into (tap, channel): when the channel count is
     // a multiple of BK every lane of a tile works on the same tap, so the im2col row shift, its 64-bit
     // row offset and the validity test reduce to a few VALU ops and one v_cndmask per DMA (no branches).
+    if (CONV == 1) {   // fold the per-lane constants into the row pointers (frees 8 VGPRs: the NN variant then fits 128)
+#pragma unroll
+        for (int q = 0; q < NA; ++q) a_row[q] += a_sw[q];
+        if (!B_KC) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) b_row[q] += (int64_t)b_sw[q] * p.b_cs;
+        }
+    }
     const bool a_fast = (CONV == 1) ? A_KC : (A_KC && TAPS > 1 && (p.Kc % BK == 0));
     const bool b_fast = (CONV == 1) ? !B_KC : (!B_KC && !WG && TAPS > 1 && (p.Kc % BK == 0));
     const bool ks_fast = p.Tseq >= BK;
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
                 const bool ok = a_ok[q] && ((unsigned)(a_tp[q] + off) < (unsigned)p.Tseq);
-                const u16* src = ok ? a_row[q] + roff + a_sw[q] : ZP;
+                const u16* src = ok ? a_row[q] + roff + (CONV == 1 ? 0 : a_sw[q]) : ZP;
                 __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sA + (w * NA + q) * 1024), 16, 0, 0);
             }
         } else {
@@ -216,7 +224,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
             const int64_t toff = (int64_t)u_tap * p.b_ts + (int64_t)u_cc * p.b_cs;
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                const u16* src = b_ok[q] ? b_row[q] + toff + (int64_t)b_sw[q] * p.b_cs : ZP;
+                const u16* src = b_ok[q] ? b_row[q] + toff + (CONV == 1 ? (int64_t)0 : (int64_t)b_sw[q] * p.b_cs) : ZP;
                 __builtin_amdgcn_global_load_lds(GLB_AS(src), LDS_AS(sB + (w * NB + q) * 1024), 16, 0, 0);
             }
         } else {
@@ -404,24 +412,17 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
         const int rc = a3t_gemm_bf16_t256(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc >= 0) return rc;
     }
-    static int forced_st = -1, forced_wm = -1;
+    static int forced_st = -1;
     if (forced_st < 0) {
         const char* e = getenv("A3T_GEMM_STAGES");
         forced_st = e ? (e[0] == '1' ? 1 : 2) : 0;
-        const char* f = getenv("A3T_GEMM_WM");
-        forced_wm = f ? (f[0] == '4' ? 4 : 2) : 0;
     }
-    // Variant choice (measured on MI355X, tools/gemm_bench*.py).  The 256-row tile moves 25 % fewer DMA
-    // bytes per flop but halves the co-resident workgroups (register budget: 2 x 8 waves per CU); it only
-    // wins for the long-K, narrow-N NT shape (FFN w_2 forward: 606 -> 696 TFLOP/s) and loses 5-40 % on
-    // everything else, so it is selected for exactly that shape.  Single LDS buffer + co-resident
-    // workgroups when the grid is large, double buffering inside the workgroup when it is small.
-    const long t128 = (long)p.tiles_n * ((p.M + 127) / 128) * batch * p.splitk;
-    const long t256 = (long)p.tiles_n * ((p.M + 255) / 256) * batch * p.splitk;
-    const bool nt = AK && BKC;
-    int wm = forced_wm ? forced_wm : ((nt && p.N <= 512 && p.K >= 2048 && t256 >= 384) ? 4 : 2);
-    if (!nt) wm = 2;
-    const long tiles = (wm == 4) ? t256 : t128;
+    // Variant choice (measured on MI355X, tools/gemm_bench*.py): single LDS buffer + 3-4 co-resident workgroups per CU
+    // when the grid is large, double buffering inside the workgroup when it is small.  (A 256-row tile, WM = 4, moves
+    // 25 % fewer DMA bytes per flop but halves the co-resident workgroups; it lost 5-40 % on every shape but one and
+    // that one is now faster on the 4-per-CU 128-row variant, so only WM = 2 is instantiated.)
+    constexpr int wm = 2;
+    const long tiles = (long)p.tiles_n * ((p.M + 127) / 128) * batch * p.splitk;
     const int stages = forced_st ? forced_st : (tiles >= 768 ? 1 : 2);
     const int tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
     dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk));
@@ -432,11 +433,10 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
 #define V(LY, ST, WM_, CV)                                   \
     if (ly == LY && stages == ST && wm == WM_ && conv == CV) { \
         launch_variant<LY, ST, WM_, CV>(pv, grid, stream);     \
+        a3t_note_kernel("gemm_bf16_glds_kernel<%d, %d, %d, %d>", LY, ST, WM_, CV); \
         return (int)hipGetLastError();                         \
     }
-    V(L_NT, 1, 2, 0) V(L_NT, 2, 2, 0) V(L_NT, 1, 4, 0) V(L_NT, 2, 4, 0)
-    V(L_NT, 1, 2, 1) V(L_NT, 2, 2, 1) V(L_NT, 1, 4, 1) V(L_NT, 2, 4, 1)
-    V(L_NT, 1, 2, 2) V(L_NT, 2, 2, 2) V(L_NT, 1, 4, 2) V(L_NT, 2, 4, 2)
+    V(L_NT, 1, 2, 0) V(L_NT, 2, 2, 0) V(L_NT, 1, 2, 1) V(L_NT, 2, 2, 1) V(L_NT, 1, 2, 2) V(L_NT, 2, 2, 2)
     V(L_NN, 1, 2, 0) V(L_NN, 2, 2, 0) V(L_NN, 1, 2, 1) V(L_NN, 2, 2, 1) V(L_NN, 1, 2, 2) V(L_NN, 2, 2, 2)
     V(L_TN, 1, 2, 0) V(L_TN, 2, 2, 0) V(L_TN, 1, 2, 2) V(L_TN, 2, 2, 2)
 #undef V

@@ -403,6 +403,7 @@ int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream) {
 #define V(LY, CV)                                 \
     if (ly == LY && conv == CV) {                 \
         launch_t256<LY, CV>(pv, grid, stream);    \
+        a3t_note_kernel("gemm_bf16_t256_kernel<%d, %s>", LY, CV ? "true" : "false"); \
         return (int)hipGetLastError();            \
     }
     V(0, false) V(0, true) V(1, false) V(1, true) V(2, false) V(2, true)

@@ -5,6 +5,10 @@
 #include "../../include/a3t_hip.h"
 #include "dtype_io.h"
 
+// Introspection for bench.py / profilers: a3t_gemm records the name (as rocprofv3 prints it) of the kernel variant
+// its dispatcher picked for the calling thread's last launch; read back with a3t_gemm_last_kernel().
+void a3t_note_kernel(const char* fmt, ...);
+
 struct GP {
     const void* A;
     const void* B;

@@ -16,23 +16,6 @@ __all__ = ["gemm", "linear_fwd", "linear_bwd_data", "linear_bwd_weight", "conv_f
 PROFILE = None
 
 
-def _kernel_name(compute, a_cs, b_cs, A, B, tiles=0, dims=None, conv=False):
-    tn = {torch.float32: "float", torch.bfloat16: "unsigned short"}
-    ak, bk = "true" if a_cs == 1 else "false", "true" if b_cs == 1 else "false"
-    if compute == F32:
-        return f"gemm_f32_kernel<{ak}, {bk}, *>"
-    if A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16:
-        lay = 0 if (a_cs == 1 and b_cs == 1) else (1 if a_cs == 1 else 2)
-        wm = 2                                                     # same rules as a3t_gemm_bf16_glds
-        if dims is not None and lay == 0:
-            M, N, K, batch, splitk = dims
-            t256 = ((M + 255) // 256) * ((N + 127) // 128) * batch * splitk
-            if N <= 512 and K >= 2048 and t256 >= 384:
-                wm, tiles = 4, t256
-        return f"gemm_bf16_glds_kernel<{lay}, {1 if tiles >= 768 else 2}, {wm}, {'true' if conv else 'false'}>"
-    return f"gemm_bf16_kernel<{tn[A.dtype]}, {tn[B.dtype]}, {ak}, {bk}>"
-
-
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -80,8 +63,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
         L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
         e1.record()
-        tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch * splitk
-        PROFILE.append((_kernel_name(compute, a_cs, b_cs, A, B, tiles, (M, N, K, batch, splitk), taps > 1 or Tseq > 0), 2.0 * M * N * K * batch, e0, e1,
+        PROFILE.append((lib.a3t_gemm_last_kernel().decode(), 2.0 * M * N * K * batch, e0, e1,
                         (M, N, K, batch, taps, splitk)))
         return
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")

@@ -227,6 +227,9 @@ int a3t_dropout_bwd_cast(const float* g, void* gm, int gm_dtype, float* colsum, 
                          float p, uint32_t key, void* stream);
 
 const char* a3t_version(void);
+/* Name (as rocprofv3 prints it, without "void " / "(GP)") of the kernel variant a3t_gemm's dispatcher launched last on
+ * the calling thread -- lets a profiler harness attribute event-bracketed launches to kernel-trace rows. */
+const char* a3t_gemm_last_kernel(void);
 
 #ifdef __cplusplus
 }
