@@ -15,6 +15,7 @@ Two numeric modes:
                    optimizer stay fp32  (throughput path, 1e-2)
 """
 import math
+import os
 import zlib
 from typing import Dict
 
@@ -80,6 +81,14 @@ class MLMEngine:
         self.scratch64 = torch.zeros(4 * max(cfg.ff, 3 * cfg.adim, cfg.postnet_chans, 64), dtype=torch.float64,
                                      device=self.dev)
         self.bn_momentum = 0.1
+        # Weight-gradient GEMMs feed nothing until the optimizer, so the backward schedule launches them on a second HIP
+        # stream: they fill the partially empty last round of the data-gradient GEMMs' grids and overlap the HBM-bound
+        # row kernels (LayerNorm / softmax backward).  Scratch tensors they read are double-buffered by sub-layer parity.
+        self.side = None
+        if self.dev.type == "cuda" and os.environ.get("A3T_SIDE_STREAM", "1") != "0":
+            self.side = torch.cuda.Stream(device=self.dev)
+        self._par = 0
+        self._side_ev = [None, None]
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -104,7 +113,7 @@ class MLMEngine:
         dr = self._drop(p, tag)
         if dr is None:
             return (self._g16(g) if self.bf16 else g)
-        gm = self.ws.get("tmp.gm", tuple(g.shape), self.adt)
+        gm = self.ws.get(self._t("tmp.gm"), tuple(g.shape), self.adt)
         ops.dropout_bwd_cast(g, gm, dr[0], dr[1], colsum=bias_grad, colsum_scale=bias_scale)
         return gm
 
@@ -149,6 +158,48 @@ class MLMEngine:
         """bf16 companion of the residual-stream gradient (written by the LayerNorm backward)."""
         return self.ws.get("grad.x16", tuple(g.shape), torch.bfloat16) if self.bf16 else None
 
+    # ---- side-stream protocol -------------------------------------------------------------------
+    def _t(self, name):
+        """Scratch tensor name for the current sub-layer parity (tensors a side-stream GEMM reads)."""
+        return f"{name}.{self._par}"
+
+    def _sub_begin(self):
+        """Start of a sub-layer backward: flip the parity; its scratch set was last read by the side-stream work
+        issued two sub-layers ago, which must have drained before the main stream overwrites it."""
+        self._par ^= 1
+        ev = self._side_ev[self._par]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._side_ev[self._par] = None
+
+    def _sub_end(self):
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self._side_ev[self._par] = ev
+
+    def _side(self, fn):
+        """Run fn (weight-gradient work whose inputs are complete on the main stream NOW) on the side stream."""
+        if self.side is None:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            fn()
+
+    def _side_join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._side_ev = [None, None]
+
+    def _pre_ln(self, ga, g, g16):
+        """The sub-layer's closing LayerNorm backward rewrites g / g16 in place: if the side-stream GEMMs read the
+        gradient from there (no dropout copy), they must finish first."""
+        if self.side is not None and (ga is g or ga is g16):
+            torch.cuda.current_stream().wait_stream(self.side)
+
     # ------------------------------------------------------------------ FFN (MultiLayeredConv1d)
     def _ffn_fwd(self, tag, pre, x, T):
         p, c = self.store.p, self.c
@@ -171,21 +222,24 @@ class MLMEngine:
         y, h = self.sv[tag]
         M = g.shape[0]
         pad = (c.ff_kernel - 1) // 2
+        self._sub_begin()
         g16 = self._g16(g)
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".b2"], 0.5)
-        dh = self._act("tmp.dh", (M, c.ff))
+        self._side(lambda: ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp))
+        dh = self._act(self._t("tmp.dh"), (M, c.ff))
         # (without dropout b2's gradient = 0.5*colsum(g) was accumulated by the LayerNorm backward that
         #  produced g; the dropout on h folds into the relu mask S=h>0 and the 1/(1-p) factor)
         hd = self._drop(c.dropout_rate, tag + ".h")
         ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=0.5 / (1.0 - hd[0]) if hd else 0.5,
                           compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
-        ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp)
+        self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp))
         dy = self._act("tmp.dy", (M, c.adim))
         ops.conv_bwd_data(dh, self.W(pre + ".w1"), dy, T, pad, compute=self.cmp)
-        ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp)
         if not self.bf16:
             self._bias_grad(dh, gr[pre + ".b1"])
+        self._pre_ln(ga, g, g16)
         self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
+        self._sub_end()
         return g
 
     # ------------------------------------------------------------------ rel-pos self-attention
@@ -235,14 +289,15 @@ class MLMEngine:
         cmp = self.cmp
         y, qkv, qu, qv, P, probs, ctx, pos, pdrop = self.sv[tag]
         scale = 1.0 / math.sqrt(dk)
+        self._sub_begin()
         g16 = self._g16(g)
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".bo"], 1.0)
+        self._side(lambda: ops.linear_bwd_weight(ga, ctx, gr[pre + ".wo"], compute=cmp))
         dctx = self._act("tmp.dctx", (M, d))
         ops.linear_bwd_data(ga, self.W(pre + ".wo"), dctx, compute=cmp)
-        ops.linear_bwd_weight(ga, ctx, gr[pre + ".wo"], compute=cmp)
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
-        dqkv = self._act("tmp.dqkv", (M, 3 * d))
+        dqkv = self._act(self._t("tmp.dqkv"), (M, 3 * d))
         dkk = dqkv.view(-1)[d:]
         dvv = dqkv.view(-1)[2 * d:]
         sdt = torch.bfloat16 if self.bf16 else torch.float32
@@ -260,12 +315,22 @@ class MLMEngine:
                  colsum_bs1=dk)
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
-            dbd = self.ws.get("tmp.dbd16", (B, H, T, T), torch.bfloat16)
+            dbd = self.ws.get(self._t("tmp.dbd16"), (B, H, T, T), torch.bfloat16)
         else:
             ds = dpr
-            dbd = self.ws.get("tmp.bd", (B, H, T, T), sdt)
+            dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
         ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=pdrop,
                                drop_p=c.attention_dropout_rate if pdrop is not None else 0.0)
+        def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
+            dP = self.ws.get("tmp.dP", (T, d), zero=True)
+            ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
+                     c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
+            if self.bf16:
+                dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
+                ops.cast_bf16(dP, dP16)
+                dP = dP16
+            ops.linear_bwd_weight(dP, pos, gr[pre + ".wpos"], compute=cmp)
+        self._side(pos_weight_grad)
         dqu = self._act("tmp.dqu", (M, d))
         dqv = self._act("tmp.dqv", (M, d))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
@@ -277,14 +342,6 @@ class MLMEngine:
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
                  c_bs=(T * d, dk), compute=cmp, colsum=gr[pre + ".v"] if fz else None, colsum_bs1=dk)
-        dP = self.ws.get("tmp.dP", (T, d), zero=True)
-        ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                 c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
-        if self.bf16:
-            dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
-            ops.cast_bf16(dP, dP16)
-            dP = dP16
-        ops.linear_bwd_weight(dP, pos, gr[pre + ".wpos"], compute=cmp)
         ops.add_pos_bias_bwd(dqu, dqv, dqkv)
         if fz:   # d b_q = colsum(dq_u + dq_v) = d u + d v (this layer's u/v gradients are complete here)
             ops.axpy(gr[pre + ".u"], gbq[:d], 1.0)
@@ -293,10 +350,12 @@ class MLMEngine:
             self._bias_grad(dqu, gr[pre + ".u"])
             self._bias_grad(dqv, gr[pre + ".v"])
             self._bias_grad(dqkv, gbq)
+        self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp))
         dy = self._act("tmp.dy", (M, d))
         ops.linear_bwd_data(dqkv, self.W(pre + ".wqkv"), dy, compute=cmp)
-        ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp)
+        self._pre_ln(ga, g, g16)
         self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
+        self._sub_end()
         return g
 
     # ------------------------------------------------------------------ convolution module
@@ -347,20 +406,23 @@ class MLMEngine:
         M, d = g.shape
         cmp = self.cmp
         y, g2, glu, s = self.sv[tag]
+        self._sub_begin()
         g16 = self._g16(g)
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".pb2"], 1.0)
+        self._side(lambda: ops.linear_bwd_weight(ga, s, gr[pre + ".pw2"], compute=cmp))
         ds = self.ws.get("tmp.ds", (M, d))
         ops.linear_bwd_data(ga, self.W(pre + ".pw2"), ds, compute=cmp)
-        ops.linear_bwd_weight(ga, s, gr[pre + ".pw2"], compute=cmp)
         dz = self.ws.get("tmp.dz", (M, d))
         self._bn_bwd(tag, ds, pre + ".bn", ACT_SWISH, dz)
-        dg = self._act("tmp.dg", (M, 2 * d))
+        dg = self._act(self._t("tmp.dg"), (M, 2 * d))
         ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T,
                            dgsum=gr[pre + ".pb1"])
+        self._side(lambda: ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp))
         dy = self._act("tmp.dy", (M, d))
         ops.linear_bwd_data(dg, self.W(pre + ".pw1"), dy, compute=cmp)
-        ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp)
+        self._pre_ln(ga, g, g16)
         self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
+        self._sub_end()
         return g
 
     # ------------------------------------------------------------------ one Conformer block
@@ -483,7 +545,11 @@ class MLMEngine:
         """Accumulates d loss / d param (times the gscale given to forward) into store.grad.
         on_group_done(first_param_name) is called each time every parameter at or above that flat
         offset has its final gradient (hook for overlapping the gradient all-reduce)."""
-        done = on_group_done or (lambda name: None)
+        hook = on_group_done or (lambda name: None)
+
+        def done(name):          # every gradient at or above `name` is final once the side stream has drained
+            self._side_join()
+            hook(name)
         c, p, gr, ws = self.c, self.store.p, self.store.g, self.ws
         B, Tm, Tp, T = self.dims
         d = c.adim
