@@ -178,16 +178,22 @@ class MLMEngine:
             ev.record(self.side)
             self._side_ev[self._par] = ev
 
-    def _side(self, fn):
-        """Run fn (weight-gradient work whose inputs are complete on the main stream NOW) on the side stream."""
+    def _side(self, fn, want_event=False):
+        """Run fn (work whose inputs are complete on the main stream NOW) on the side stream; with want_event the
+        returned event marks its completion (for results the main stream consumes later)."""
         if self.side is None:
             fn()
-            return
+            return None
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
             fn()
+            if want_event:
+                done = torch.cuda.Event()
+                done.record()
+                return done
+        return None
 
     def _side_join(self):
         if self.side is not None:
@@ -309,10 +315,10 @@ class MLMEngine:
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
         fz = self.bf16   # bias / pos-bias gradients ride on the GEMM epilogues as column sums
         gbq = gr[pre + ".bqkv"]
-        ops.gemm(pdrop if pdrop is not None else probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H,
-                 batch_inner=H, a_bs=zb,
-                 b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp, colsum=gbq[2 * d:] if fz else None,
-                 colsum_bs1=dk)
+        # (independent of the dprobs -> softmax-backward chain: runs beside it on the side stream)
+        self._side(lambda: ops.gemm(pdrop if pdrop is not None else probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d,
+                                    batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
+                                    compute=cmp, colsum=gbq[2 * d:] if fz else None, colsum_bs1=dk))
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
             dbd = self.ws.get(self._t("tmp.dbd16"), (B, H, T, T), torch.bfloat16)
@@ -337,11 +343,14 @@ class MLMEngine:
         ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
                  b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=gr[pre + ".u"] if fz else None,
                  colsum_bs1=dk)
-        ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                 c_bs=(T * 3 * d, dk), compute=cmp, colsum=gbq[d:] if fz else None, colsum_bs1=dk)
+        dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
+                                              a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
+                                              colsum=gbq[d:] if fz else None, colsum_bs1=dk), want_event=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
                  c_bs=(T * d, dk), compute=cmp, colsum=gr[pre + ".v"] if fz else None, colsum_bs1=dk)
+        if dk_done is not None:      # the dV / dK slices of dqkv come from the side stream
+            torch.cuda.current_stream().wait_event(dk_done)
         ops.add_pos_bias_bwd(dqu, dqv, dqkv)
         if fz:   # d b_q = colsum(dq_u + dq_v) = d u + d v (this layer's u/v gradients are complete here)
             ops.axpy(gr[pre + ".u"], gbq[:d], 1.0)
