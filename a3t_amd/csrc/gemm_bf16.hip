@@ -56,15 +56,18 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware remap (bijective): workgroup b runs on XCD b%8, so give every XCD a contiguous run
-    // of tile ids; neighbours in a run share the A row-panel / B panel in that XCD's private L2.
-    int bid = blockIdx.x;
+    // 1-D grid over (batch / K-split, tile) work items.  Workgroup b runs on XCD b % 8, so every XCD is given a
+    // CONTIGUOUS run of work items (bijective remap), ordered slice-major / tile-minor: the tiles of one batch element
+    // or of one K-split -- which read the same operand slabs -- stay inside one XCD's private L2 instead of being
+    // fetched by all eight (the 2-D grid did that: 5x the algorithmic HBM traffic on the split-K weight gradients).
+    int wi = blockIdx.x;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
+    const int bid = wi % p.ntiles, zy = wi / p.ntiles;
     const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
-    const int ks = blockIdx.y % p.splitk, bz = blockIdx.y / p.splitk;
+    const int ks = zy % p.splitk, bz = zy / p.splitk;
     const int z0 = bz / p.batch_inner, z1 = bz % p.batch_inner;
     const u16* A = (const u16*)p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
     const u16* B = (const u16*)p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
@@ -425,7 +428,8 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     const long tiles = (long)p.tiles_n * ((p.M + 127) / 128) * batch * p.splitk;
     const int stages = forced_st ? forced_st : (tiles >= 768 ? 1 : 2);
     const int tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
-    dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk));
+    pv.ntiles = p.tiles_n * tiles_m;
+    dim3 grid((unsigned)((long)pv.ntiles * batch * p.splitk));
     const int ly = (AK && BKC) ? L_NT : (AK ? L_NN : L_TN);
     int conv = 0;
     if (p.taps > 1 || p.kshift_mode)

@@ -34,7 +34,7 @@ typedef unsigned short u16;
 static __device__ __attribute__((aligned(16))) unsigned int t256_zero_page[16];
 #ifdef T256_TIMING
 __device__ unsigned long long t256_dbg[8192 * 8];
-#define TSTAMP(i) do { if (tid == 0) t256_dbg[(blockIdx.y * gridDim.x + blockIdx.x) % 8192 * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define TSTAMP(i) do { if (tid == 0) t256_dbg[blockIdx.x % 8192 * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int a3t_debug_read(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(t256_dbg), bytes); }
 #else
 #define TSTAMP(i)
@@ -65,13 +65,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(GP p) {
     TSTAMP(0);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = w >> 2, wc = w & 3;          // waves w and w+4 share a SIMD: they form the two ping-pong groups
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap: every XCD gets a contiguous run of tile ids (shared panels stay in its L2)
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // 1-D grid over (batch / K-split, tile) work items.  Workgroup b runs on XCD b % 8, so every XCD is given a
+    // CONTIGUOUS run of work items (bijective remap), ordered slice-major / tile-minor: the tiles of one batch element
+    // or of one K-split -- which read the same operand slabs -- stay inside one XCD's private L2 instead of being
+    // fetched by all eight (the 2-D grid did that: 5x the algorithmic HBM traffic on the split-K weight gradients).
+    int wi = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
-    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;   // (tiles_n counts 256-column tiles here)
-    const int ks = blockIdx.y % p.splitk, bz = blockIdx.y / p.splitk;
+    const int bid = wi % p.ntiles, zy = wi / p.ntiles;
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int ks = zy % p.splitk, bz = zy / p.splitk;
     const int z0 = bz / p.batch_inner, z1 = bz % p.batch_inner;
     const u16* A = (const u16*)p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
     const u16* B = (const u16*)p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(GP p) {
         unsigned int xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        t256_dbg[(blockIdx.y * gridDim.x + blockIdx.x) % 8192 * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
+        t256_dbg[blockIdx.x % 8192 * 8 + 5] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
 }
@@ -399,7 +404,8 @@ int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream) {
     }
     GP pv = p;
     pv.tiles_n = (int)tn;
-    dim3 grid((unsigned)(tm * tn), (unsigned)(batch * p.splitk));
+    pv.ntiles = (int)(tm * tn);
+    dim3 grid((unsigned)(tm * tn * batch * p.splitk));
 #define V(LY, CV)                                 \
     if (ly == LY && conv == CV) {                 \
         launch_t256<LY, CV>(pv, grid, stream);    \

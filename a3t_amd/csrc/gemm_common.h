@@ -23,6 +23,7 @@ struct GP {
     int taps, pad, dil, Tseq, kshift, kshift_mode;
     float alpha;
     int act, accumulate, splitk, c_dtype, tiles_n, s_dtype, epi_vec;
+    int ntiles;   // output tiles per (batch element, K split): 1-D grids of the direct-to-LDS kernels
     float* colsum;
     int64_t colsum_bs1;
     float colsum_scale;
