@@ -41,7 +41,8 @@ _P = c_void_p
 _SIGS = {
     "a3t_gemm": [POINTER(GemmDesc), _P],
     "a3t_layernorm_fwd": [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_float, _P],
-    "a3t_layernorm_bwd": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, _P],
+    "a3t_layernorm_bwd": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_int, c_int, c_float,
+                          ctypes.c_uint32, _P],
     "a3t_col_reduce": [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
     "a3t_f64_to_f32_add": [_P, _P, c_int, c_float, _P],
     "a3t_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P],

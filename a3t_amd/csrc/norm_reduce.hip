@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* dres, float* dx, unsigned short* __restrict__ dx16,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         float* __restrict__ dxsum, float dxsum_scale, int M, int D) {
+                                                         float* __restrict__ dxsum, float dxsum_scale, int M, int D,
+                                                         unsigned int drop_thr, float drop_inv, unsigned int drop_key) {
     __shared__ float red[3][8][32 * 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
     float4 gam[NQ], ag[NQ], ab[NQ], ax[NQ];
@@ -186,6 +187,13 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
                                    rs * (dg[i].z - s1 - xh[i].z * s2), rs * (dg[i].w - s1 - xh[i].w * s2));
             o.x += rr[i].x, o.y += rr[i].y, o.z += rr[i].z, o.w += rr[i].w;
             *(float4*)(dx + ro + c) = o;
+            if (drop_inv > 0.f) {   // the consumer sub-layer's output dropout: its GEMM operand / bias gradient see the masked dx
+                const unsigned int i0 = (unsigned int)(ro + c);
+                o.x = rng_keep(drop_key, i0 + 0, drop_thr) ? o.x * drop_inv : 0.f;
+                o.y = rng_keep(drop_key, i0 + 1, drop_thr) ? o.y * drop_inv : 0.f;
+                o.z = rng_keep(drop_key, i0 + 2, drop_thr) ? o.z * drop_inv : 0.f;
+                o.w = rng_keep(drop_key, i0 + 3, drop_thr) ? o.w * drop_inv : 0.f;
+            }
             if (dx16) {
                 uint2 h;
                 h.x = io_f2bf(o.x) | ((unsigned)io_f2bf(o.y) << 16);
@@ -246,8 +254,11 @@ extern "C" int a3t_layernorm_fwd(const float* x, const float* gamma, const float
 extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                                  const float* mean, const float* rstd, const float* dres, float* dx, void* dx_bf16,
                                  float* dgamma, float* dbeta, float* dx_colsum, float dx_colsum_scale, int M, int D,
-                                 void* stream) {
+                                 float drop_p, uint32_t drop_key, void* stream) {
     if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
+    if (drop_p < 0.f || drop_p >= 1.f) return A3T_EINVAL;
+    const unsigned int drop_thr = (unsigned int)((double)drop_p * 4294967296.0);
+    const float drop_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f;
     if (D % 128 == 0 && D <= 512 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
         (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)gamma % 16 == 0)) {
         int vb = (M + 7) / 8;
@@ -262,7 +273,8 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
         if (vb > vb_max) vb = vb_max;
 #define VCALL(NQ)                                                                                                   \
     hipLaunchKernelGGL(ln_bwd_vec_kernel<NQ>, dim3(vb), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
-                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D)
+                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D,       \
+                       drop_thr, drop_inv, drop_key)
         if (D == 128) VCALL(1);
         else if (D == 256) VCALL(2);
         else if (D == 384) VCALL(3);
@@ -270,6 +282,7 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
 #undef VCALL
         return (int)hipGetLastError();
     }
+    if (drop_p > 0.f) return A3T_EINVAL;   // the fused consumer-dropout output lives in the D % 128 == 0 kernel only
     int blocks = (M + 3) / 4;
     if (blocks > 2048) blocks = 2048;   // 8 blocks/CU: the kernel is latency-bound on its row loads
 #define CALL(V)                                                                                                   \

@@ -89,6 +89,7 @@ class MLMEngine:
             self.side = torch.cuda.Stream(device=self.dev)
         self._par = 0
         self._side_ev = [None, None]
+        self._gm_ready = None
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -114,6 +115,9 @@ class MLMEngine:
         if dr is None:
             return (self._g16(g) if self.bf16 else g)
         gm = self.ws.get(self._t("tmp.gm"), tuple(g.shape), self.adt)
+        if self._gm_ready == tag:       # already produced by the LayerNorm backward that wrote g (fused epilogue)
+            self._gm_ready = None
+            return gm
         ops.dropout_bwd_cast(g, gm, dr[0], dr[1], colsum=bias_grad, colsum_scale=bias_scale)
         return gm
 
@@ -138,12 +142,27 @@ class MLMEngine:
         self.sv[tag] = (x, y, mean, rstd)
         return y
 
-    def _ln_bwd(self, tag, dy, pre, dres, dx, dx16=None, nb=None):
+    def _ln_bwd(self, tag, dy, pre, dres, dx, dx16=None, nb=None, nxt=None):
         """nb = (bias-gradient view, scale) of the layer that produced the residual stream this LN read:
-        its bias gradient is the column sum of dx; fused into the kernel on the bf16 path."""
+        its bias gradient is the column sum of dx; fused into the kernel on the bf16 path.
+        nxt = dropout-site tag of that layer's output dropout (the next sub-layer of the backward schedule): with
+        dropout on, the kernel also emits that sub-layer's masked bf16 gradient operand and masked bias gradient,
+        which replaces the separate dropout_bwd_cast pass over g."""
         p, g = self.store.p, self.store.g
         x, _, mean, rstd = self.sv[tag]
-        if self.dropping and self.c.dropout_rate > 0:
+        dropping = self.dropping and self.c.dropout_rate > 0
+        if dropping and self.bf16 and nb is not None and nxt is not None and x.shape[1] % 128 == 0:
+            dr = self._drop(self.c.dropout_rate, nxt)
+            gm = self.ws.get(f"tmp.gm.{self._par ^ 1}", tuple(dx.shape), self.adt)
+            ev = self._side_ev[self._par ^ 1]          # side-stream readers of that scratch set must have drained
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+                self._side_ev[self._par ^ 1] = None
+            ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=gm,
+                              dxsum=nb[0], dxsum_scale=nb[1], drop=dr)
+            self._gm_ready = nxt
+            return
+        if dropping:
             nb = None          # with dropout the bias gradients come from the masked gradient (_gm)
         fuse = self.bf16 and nb is not None
         ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=dx16,
@@ -221,7 +240,7 @@ class MLMEngine:
         self.sv[tag] = (y, h)
         return xo
 
-    def _ffn_bwd(self, tag, pre, g, T, nb=None):
+    def _ffn_bwd(self, tag, pre, g, T, nb=None, nxt=None):
         """g = grad wrt the sub-layer output (fp32 residual stream, updated in place to the grad wrt
         the sub-layer input); in bf16 mode grad.x16 holds the same values in bf16 on entry and exit."""
         p, gr, c = self.store.p, self.store.g, self.c
@@ -244,7 +263,7 @@ class MLMEngine:
         if not self.bf16:
             self._bias_grad(dh, gr[pre + ".b1"])
         self._pre_ln(ga, g, g16)
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
         self._sub_end()
         return g
 
@@ -288,7 +307,7 @@ class MLMEngine:
         self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos, pdrop)
         return xo
 
-    def _mha_bwd(self, tag, pre, g, B, T, nb=None):
+    def _mha_bwd(self, tag, pre, g, B, T, nb=None, nxt=None):
         p, gr, c = self.store.p, self.store.g, self.c
         d, H, dk = c.adim, c.heads, c.dk
         M = B * T
@@ -363,7 +382,7 @@ class MLMEngine:
         dy = self._act("tmp.dy", (M, d))
         ops.linear_bwd_data(dqkv, self.W(pre + ".wqkv"), dy, compute=cmp)
         self._pre_ln(ga, g, g16)
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
         self._sub_end()
         return g
 
@@ -410,7 +429,7 @@ class MLMEngine:
         self.sv[tag] = (y, g2, glu, s)
         return xo
 
-    def _conv_bwd(self, tag, pre, g, T, nb=None):
+    def _conv_bwd(self, tag, pre, g, T, nb=None, nxt=None):
         p, gr, c = self.store.p, self.store.g, self.c
         M, d = g.shape
         cmp = self.cmp
@@ -430,7 +449,7 @@ class MLMEngine:
         dy = self._act("tmp.dy", (M, d))
         ops.linear_bwd_data(dg, self.W(pre + ".pw1"), dy, compute=cmp)
         self._pre_ln(ga, g, g16)
-        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb)
+        self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
         self._sub_end()
         return g
 
@@ -444,11 +463,12 @@ class MLMEngine:
 
     def block_bwd(self, pre, g, B, T):
         gr = self.store.g
-        # every LayerNorm backward also delivers the bias gradient of the layer whose output it read
-        self._ln_bwd(pre + ".fin", g, pre + ".fin.ln", None, g, self._g16(g), (gr[pre + ".ff.b2"], 0.5))
-        self._ffn_bwd(pre + ".ff", pre + ".ff", g, T, (gr[pre + ".cnv.pb2"], 1.0))
-        self._conv_bwd(pre + ".cnv", pre + ".cnv", g, T, (gr[pre + ".mha.bo"], 1.0))
-        self._mha_bwd(pre + ".mha", pre + ".mha", g, B, T, (gr[pre + ".ffm.b2"], 0.5))
+        # every LayerNorm backward also delivers the bias gradient (and, with dropout, the masked gradient operand) of
+        # the layer whose output it read = the next sub-layer of this schedule
+        self._ln_bwd(pre + ".fin", g, pre + ".fin.ln", None, g, self._g16(g), (gr[pre + ".ff.b2"], 0.5), pre + ".ff.o")
+        self._ffn_bwd(pre + ".ff", pre + ".ff", g, T, (gr[pre + ".cnv.pb2"], 1.0), pre + ".cnv.o")
+        self._conv_bwd(pre + ".cnv", pre + ".cnv", g, T, (gr[pre + ".mha.bo"], 1.0), pre + ".mha.o")
+        self._mha_bwd(pre + ".mha", pre + ".mha", g, B, T, (gr[pre + ".ffm.b2"], 0.5), pre + ".ffm.o")
         self._ffn_bwd(pre + ".ffm", pre + ".ffm", g, T, None)
         return g
 

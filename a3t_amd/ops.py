@@ -152,11 +152,12 @@ def layernorm_fwd(x, g, b, y, mean, rstd, eps):
                                        _stream()), "ln_fwd")
 
 
-def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, dx16=None, dxsum=None, dxsum_scale=1.0):
+def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, dx16=None, dxsum=None, dxsum_scale=1.0, drop=(0.0, 0)):
+    """drop=(p, key): dx16 / dxsum carry the dropout-masked gradient of the consumer sub-layer's branch."""
     M, D = x.shape
     L.check(L.load().a3t_layernorm_bwd(_ptr(dy), _dt(dy), _ptr(x), _ptr(g), _ptr(mean), _ptr(rstd), _ptr(dres),
                                        _ptr(dx), _ptr(dx16), _ptr(dg), _ptr(db), _ptr(dxsum), dxsum_scale, M, D,
-                                       _stream()), "ln_bwd")
+                                       drop[0], drop[1], _stream()), "ln_bwd")
 
 
 def col_reduce(x, out0, out1=None, y=None, rowmask=None, mode=0, ld=None):

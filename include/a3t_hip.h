@@ -97,9 +97,13 @@ int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
  * GEMMs that consume it; dgamma/dbeta are ACCUMULATED (atomicAdd). */
 int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean,
                       const float* rstd, const float* dres, float* dx, void* dx_bf16, float* dgamma,
-                      float* dbeta, float* dx_colsum, float dx_colsum_scale, int M, int D, void* stream);
+                      float* dbeta, float* dx_colsum, float dx_colsum_scale, int M, int D, float drop_p,
+                      uint32_t drop_key, void* stream);
 /* dx_colsum (optional): += dx_colsum_scale * column sums of dx = the bias gradient of the layer whose
- * output gradient dx is. */
+ * output gradient dx is.
+ * drop_p > 0 (D % 128 == 0 only): dx is the gradient w.r.t. the OUTPUT of a "residual + dropout(branch)" sub-layer; the
+ * branch's backward needs mask * dx / (1-p) (torch.nn.Dropout backward, same counter RNG as the forward mask): dx_bf16
+ * and dx_colsum then carry the masked gradient, dx itself (the residual path) stays unmasked. */
 
 /* Column reductions over rows of x[M][C] (row stride ld), accumulated with atomics:
  *   mode 0: out0[c] += sum x            (bias gradients)

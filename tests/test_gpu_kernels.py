@@ -383,3 +383,33 @@ def test_glu_dwconv_bf16_vector_path(B, T, C, K):
     _close(dw, w.grad.view(C, K), atol=1e-2 * scale, rtol=2e-2)   # glu enters the weight gradient bf16-rounded
     _close(dbb, b.grad, atol=1e-3 * float(b.grad.abs().max()) + 1e-4, rtol=1e-4)
     _close(dgs, g.grad.reshape(-1, 2 * C).sum(0), atol=2e-2 * float(g.grad.abs().sum(dim=(0, 1)).max()) / 10, rtol=5e-2)
+
+
+def test_layernorm_bwd_fused_consumer_dropout():
+    """a3t_layernorm_bwd(drop=(p, key)): dx stays unmasked, dx_bf16 / dx_colsum carry exactly what the separate
+    dropout_bwd_cast pass over dx would produce (same counter RNG, same element index)."""
+    ops = _ops()
+    M, D = 517, 384
+    x = _rand(M, D, seed=1).to(DEV)
+    g = _rand(D, seed=2).to(DEV)
+    b = _rand(D, seed=3).to(DEV)
+    y = torch.empty(M, D, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.layernorm_fwd(x, g, b, y, mean, rstd, 1e-12)
+    dy = _rand(M, D, seed=4).to(DEV).bfloat16()
+    dres = _rand(M, D, seed=5).to(DEV)
+    p, key = 0.2, 0xBEEF1234
+    dx_a, dx16_a = torch.empty(M, D, device=DEV), torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dg_a, db_a, cs_a = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dy, x, g, mean, rstd, dres, dx_a, dg_a, db_a, dx16=dx16_a, dxsum=cs_a, dxsum_scale=0.5, drop=(p, key))
+    dx_b, dx16_b = torch.empty(M, D, device=DEV), torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    dg_b, db_b, cs_b = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    ops.layernorm_bwd(dy, x, g, mean, rstd, dres, dx_b, dg_b, db_b, dx16=dx16_b)
+    gm = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    ops.dropout_bwd_cast(dx_b, gm, p, key, colsum=cs_b, colsum_scale=0.5)
+    assert torch.equal(dx_a, dx_b)
+    assert torch.equal(dx16_a, gm)
+    keep = float((gm.float() != 0).float().mean())
+    assert abs(keep - (1 - p)) < 0.01
+    _close(cs_a, cs_b, atol=1e-3, rtol=1e-4)
+    _close(dg_a, dg_b, atol=1e-3, rtol=1e-4)
