@@ -90,6 +90,7 @@ class MLMEngine:
         self._par = 0
         self._side_ev = [None, None]
         self._gm_ready = None
+        self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -151,7 +152,7 @@ class MLMEngine:
         p, g = self.store.p, self.store.g
         x, _, mean, rstd = self.sv[tag]
         dropping = self.dropping and self.c.dropout_rate > 0
-        if dropping and self.bf16 and nb is not None and nxt is not None and x.shape[1] % 128 == 0:
+        if dropping and self.bf16 and self.fuse_ln_dropout and nb is not None and nxt is not None and x.shape[1] % 128 == 0:
             dr = self._drop(self.c.dropout_rate, nxt)
             gm = self.ws.get(f"tmp.gm.{self._par ^ 1}", tuple(dx.shape), self.adt)
             ev = self._side_ev[self._par ^ 1]          # side-stream readers of that scratch set must have drained
