@@ -115,7 +115,8 @@ class A3TTrainer:
     (trainer.py:545,610,631-679; optimizer/scheduler of egs2/vctk/sedit/conf/fsp2_conformer.yaml:77-83)."""
 
     def __init__(self, cfg: A3TConfig, store, compute="bf16", lr=1.0, warmup_steps=4000, grad_clip=1.0,
-                 betas=(0.9, 0.999), eps=1e-8, overlap=True, dropout=True):
+                 betas=(0.9, 0.999), eps=1e-8, overlap=True, dropout=True, force_reducer=False,
+                 bucket_min_elems=16 * 1024 * 1024):
         from .engine import MLMEngine
         self.cfg, self.store = cfg, store
         self.engine = MLMEngine(cfg, store, compute=compute, training=True, dropout=dropout)
@@ -128,14 +129,16 @@ class A3TTrainer:
         self.lr, self.warmup, self.clip, self.betas, self.eps = lr, warmup_steps, grad_clip, betas, eps
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.reducer = None
-        if self.world > 1:
+        if self.world > 1 or (force_reducer and dist.is_available() and dist.is_initialized()):
+            # (force_reducer: run the bucketed, overlapped reduction on a 1-rank group -- test hook for the stream /
+            #  event plumbing on a single GPU)
             dist.broadcast(store.flat, 0)                      # C5
             for b in store.buf.values():                       # C2 (once: BN statistics then stay rank-local)
                 dist.broadcast(b, 0)
             bounds = [store.offsets[f"enc.{i}.ffm.ln.g"][0] for i in range(cfg.enc_blocks)]
             bounds += [store.offsets[f"dec.{i}.ffm.ln.g"][0] for i in range(cfg.dec_blocks)]
             bounds += [store.offsets["sfc.w"][0]]
-            self.ranges = bucket_ranges(store.total, bounds, 16 * 1024 * 1024)   # >= 64 MB fp32 per collective
+            self.ranges = bucket_ranges(store.total, bounds, bucket_min_elems)   # default: >= 64 MB fp32 per collective
             if overlap:
                 self.reducer = FlatAllReduce(store.grad, self.ranges)
 

@@ -278,3 +278,47 @@ def test_bf16_schedule_side_stream_and_fused_dropout_match_serial_schedule():
         err = float((g - ref).abs().max() / ref.abs().max())
         assert err < 2e-4, err          # only the order of fp32 atomics differs
         assert float(torch.nn.functional.cosine_similarity(g, ref, dim=0)) > 0.999999
+
+
+def test_trainer_overlapped_allreduce_plumbing_single_rank_rccl():
+    """The data-parallel step on real RCCL with a 1-rank group: bucketed all-reduce on its own stream, fired from
+    the backward hooks after the engine's side stream has drained.  A 1-rank SUM is the identity, so the reduced
+    gradient of step 1 and the loss of step 2 must equal those of the plain (no process group) trainer (parameters
+    themselves are not compared: Adam's first steps are +-lr*sign(g), so fp32-atomic-order noise on near-zero
+    gradients flips individual updates)."""
+    import torch.distributed as dist
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    from a3t_amd.trainer import A3TTrainer
+    from a3t_amd.collate import synthetic_batch
+    c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=2, postnet_layers=3, postnet_chans=64, vocab=40)
+    batch = synthetic_batch(c, 4, 192, 32, seed=7, device=DEV)
+
+    def run(with_group):
+        store = ParamStore(c, DEV)
+        xavier_init_(store, seed=3, bn_gamma=1.0)
+        tr = A3TTrainer(c, store, compute="bf16", lr=1.0, warmup_steps=10, dropout=True, force_reducer=with_group,
+                        bucket_min_elems=200_000)
+        if with_group:
+            assert tr.reducer is not None and len(tr.reducer.ranges) >= 3      # several buckets, fired from the hooks
+        l1 = float(tr.step(batch))
+        torch.cuda.synchronize()
+        g1 = store.grad.clone()
+        l2 = float(tr.step(batch))
+        torch.cuda.synchronize()
+        return (l1, l2), g1
+
+    ref_l, ref_p = run(False)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
+    try:
+        got_l, got_p = run(True)
+    finally:
+        dist.destroy_process_group()
+    assert abs(got_l[0] - ref_l[0]) < 1e-5 * abs(ref_l[0])
+    assert abs(got_l[1] - ref_l[1]) < 2e-3 * abs(ref_l[1])
+    err = float((got_p - ref_p).abs().max() / ref_p.abs().max())
+    assert err < 2e-4, err
+    assert float(torch.nn.functional.cosine_similarity(got_p, ref_p, dim=0)) > 0.999999
