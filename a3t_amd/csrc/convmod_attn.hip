@@ -525,7 +525,12 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_bf16_kernel(
             *(uint4*)(probs + po + j0) = pack8(o);
             if (pdrop) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rng_keep(key, (unsigned int)(po + j0 + e), thr) ? o[e] * inv : 0.f;
+                for (int e = 0; e < 8; e += 4) {
+                    bool kp[4];
+                    rng_keep4(key, (unsigned int)(po + j0 + e), thr, kp);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) o[e + u] = kp[u] ? o[e + u] * inv : 0.f;
+                }
                 *(uint4*)(pdrop + po + j0) = pack8(o);
             }
         }

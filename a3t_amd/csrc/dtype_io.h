@@ -21,8 +21,19 @@ __device__ __forceinline__ unsigned int rng_fmix32(unsigned int h) {
     h ^= h >> 16;
     return h;
 }
+// One 32-bit hash serves an (even, odd) element pair, 16 random bits each (drop probability resolution 2^-16):
+// the vector kernels, which own 4-8 consecutive elements, pay half the integer work per element.
+__device__ __forceinline__ unsigned int rng_pair(unsigned int key, unsigned int pair) {
+    return rng_fmix32(rng_fmix32(pair * 0x9E3779B1u + key) ^ key);
+}
 __device__ __forceinline__ bool rng_keep(unsigned int key, unsigned int idx, unsigned int thr) {
-    return rng_fmix32(rng_fmix32(idx * 0x9E3779B1u + key) ^ key) >= thr;
+    const unsigned int h = rng_pair(key, idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= (thr >> 16);
+}
+// keep flags of elements i0 .. i0+3, i0 % 2 == 0
+__device__ __forceinline__ void rng_keep4(unsigned int key, unsigned int i0, unsigned int thr, bool* k) {
+    const unsigned int h0 = rng_pair(key, i0 >> 1), h1 = rng_pair(key, (i0 >> 1) + 1), t = thr >> 16;
+    k[0] = (h0 & 0xffffu) >= t, k[1] = (h0 >> 16) >= t, k[2] = (h1 & 0xffffu) >= t, k[3] = (h1 >> 16) >= t;
 }
 __device__ __forceinline__ unsigned int rng_thr(float p) { return (unsigned int)((double)p * 4294967296.0); }
 

@@ -135,10 +135,10 @@ __device__ __forceinline__ void epilogue_vec4(const GP& p, float4 v, int64_t idx
     }
     if (p.drop_inv > 0.f) {
         const unsigned int i0 = (unsigned int)idx;
-        v.x = rng_keep(p.drop_key, i0 + 0, p.drop_thr) ? v.x * p.drop_inv : 0.f;
-        v.y = rng_keep(p.drop_key, i0 + 1, p.drop_thr) ? v.y * p.drop_inv : 0.f;
-        v.z = rng_keep(p.drop_key, i0 + 2, p.drop_thr) ? v.z * p.drop_inv : 0.f;
-        v.w = rng_keep(p.drop_key, i0 + 3, p.drop_thr) ? v.w * p.drop_inv : 0.f;
+        bool kp[4];
+        rng_keep4(p.drop_key, i0, p.drop_thr, kp);       // (idx % 4 == 0: vector epilogue contract)
+        v.x = kp[0] ? v.x * p.drop_inv : 0.f, v.y = kp[1] ? v.y * p.drop_inv : 0.f;
+        v.z = kp[2] ? v.z * p.drop_inv : 0.f, v.w = kp[3] ? v.w * p.drop_inv : 0.f;
     }
     v.x *= p.alpha, v.y *= p.alpha, v.z *= p.alpha, v.w *= p.alpha;
     if (p.R && ks == 0) {

@@ -189,10 +189,10 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
             *(float4*)(dx + ro + c) = o;
             if (drop_inv > 0.f) {   // the consumer sub-layer's output dropout: its GEMM operand / bias gradient see the masked dx
                 const unsigned int i0 = (unsigned int)(ro + c);
-                o.x = rng_keep(drop_key, i0 + 0, drop_thr) ? o.x * drop_inv : 0.f;
-                o.y = rng_keep(drop_key, i0 + 1, drop_thr) ? o.y * drop_inv : 0.f;
-                o.z = rng_keep(drop_key, i0 + 2, drop_thr) ? o.z * drop_inv : 0.f;
-                o.w = rng_keep(drop_key, i0 + 3, drop_thr) ? o.w * drop_inv : 0.f;
+                bool kp[4];
+                rng_keep4(drop_key, i0, drop_thr, kp);
+                o.x = kp[0] ? o.x * drop_inv : 0.f, o.y = kp[1] ? o.y * drop_inv : 0.f;
+                o.z = kp[2] ? o.z * drop_inv : 0.f, o.w = kp[3] ? o.w * drop_inv : 0.f;
             }
             if (dx16) {
                 uint2 h;
