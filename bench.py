@@ -219,7 +219,7 @@ def main():
     log(f"{ms:.1f} ms/step, {value:.0f} frames/s, loss {final_loss:.4f}")
 
     roofline = None
-    if rank == 0 and not a.no_kernel_profile:
+    if not a.no_kernel_profile:      # every rank runs the two extra steps (they contain collectives when world > 1)
         def gemm_profile():
             """One extra, untimed step with every GEMM launch bracketed by HIP events on the stream it is launched
             on; kernel names come from the library (a3t_gemm_last_kernel), as rocprofv3 prints them."""
@@ -240,6 +240,8 @@ def main():
         side, eng.side = eng.side, None            # same step, one stream: every kernel alone on the GPU
         alone = gemm_profile()
         eng.side = side
+        sync()
+    if rank == 0 and not a.no_kernel_profile:
         name, (fl, tt, n) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = fl / tt / 1e12
         peak = MFMA_PEAK["bf16" if "bf16" in name else "f32"]
