@@ -46,8 +46,8 @@ _SIGS = {
     "a3t_col_reduce": [_P, c_int, _P, _P, _P, _P, c_int, c_int, c_int64, c_int, _P],
     "a3t_f64_to_f32_add": [_P, _P, c_int, c_float, _P],
     "a3t_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, c_int, _P],
-    "a3t_bn_act_bwd_a": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
-    "a3t_bn_act_bwd_b": [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "a3t_bn_act_bwd_a": [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "a3t_bn_act_bwd_b": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_glu_dwconv_fwd": [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_glu_dwconv_bwd": [_P, _P, c_int, _P, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_add_pos_bias": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],

@@ -381,7 +381,35 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, void* __restrict__ y,
-                                                         int y_dt, int64_t n, int C, int act) {
+                                                         int y_dt, int64_t n, int C, int act, int vec) {
+    if (vec) {   // C % 4 == 0, 16-byte aligned: 4 consecutive columns per lane
+        const int64_t n4 = n >> 2;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = q << 2;
+            const int c = (int)(i % C);
+            const float4 zv = *(const float4*)(z + i);
+            const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c);
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            float o[4] = {(zv.x - mu.x) * rs.x * g.x + b.x, (zv.y - mu.y) * rs.y * g.y + b.y,
+                          (zv.z - mu.z) * rs.z * g.z + b.z, (zv.w - mu.w) * rs.w * g.w + b.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (act == A3T_ACT_SWISH)
+                    o[e] = o[e] * sigmoidf_(o[e]);
+                else if (act == A3T_ACT_TANH)
+                    o[e] = tanhf(o[e]);
+            }
+            if (y_dt == A3T_BF16) {
+                uint2 h;
+                h.x = io_f2bf(o[0]) | ((unsigned)io_f2bf(o[1]) << 16);
+                h.y = io_f2bf(o[2]) | ((unsigned)io_f2bf(o[3]) << 16);
+                *(uint2*)((unsigned short*)y + i) = h;
+            } else {
+                *(float4*)((float*)y + i) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
         float bn = (z[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
@@ -402,18 +430,34 @@ extern "C" int a3t_bn_act_fwd(const float* z, const double* stats, const float* 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, stats, running_mean, running_var,
                        mean_out, rstd_out, M, C, eps, momentum, training);
     int64_t n = (int64_t)M * C;
-    int blocks = (int)((n + 255) / 256);
+    const int vec = (C % 4 == 0 && ((uintptr_t)z % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)mean_out % 16 == 0) &&
+                     ((uintptr_t)rstd_out % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0)) ? 1 : 0;
+    int blocks = (int)(((vec ? n / 4 : n) + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, s, z, mean_out, rstd_out, gamma, beta, y, y_dtype, n,
-                       C, act);
+                       C, act, vec);
     return (int)hipGetLastError();
 }
 
+// d(bn) = dy * act'(bn): recomputed by both backward steps from (dy, z) instead of being materialised
+__device__ __forceinline__ float bn_dact(float d, float bn, int act) {
+    if (act == A3T_ACT_SWISH) {
+        const float sg = sigmoidf_(bn);
+        return d * sg * (1.f + bn * (1.f - sg));
+    }
+    if (act == A3T_ACT_TANH) {
+        const float t = tanhf(bn);
+        return d * (1.f - t * t);
+    }
+    return d;
+}
+
+// step A (column sums).  Generic: block = 64 columns x 4 row lanes, 4 bytes per lane.
 __global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ z,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ dbn,
+                                                           const float* __restrict__ beta,
                                                            double* sums, int M, int C, int act, int rows_per_block) {
     __shared__ double red[2][4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -427,16 +471,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const void* __restric
         for (int r = r0 + ty; r < r1; r += 4) {
             int64_t i = (int64_t)r * C + c;
             float zh = (z[i] - mu) * rs;
-            float bn = zh * g + b;
-            float d = ldx(dy, dy_dt, i);
-            if (act == A3T_ACT_SWISH) {
-                float sg = sigmoidf_(bn);
-                d *= sg * (1.f + bn * (1.f - sg));
-            } else if (act == A3T_ACT_TANH) {
-                float t = tanhf(bn);
-                d *= (1.f - t * t);
-            }
-            dbn[i] = d;
+            float d = bn_dact(ldx(dy, dy_dt, i), zh * g + b, act);
             f0 += d;
             f1 += d * zh;
             if (++cnt == 32) {
@@ -454,22 +489,65 @@ __global__ __launch_bounds__(256) void bn_act_bwd_a_kernel(const void* __restric
     }
 }
 
+// C % 64 == 0, fp32 dy: block = 64 columns x 16 row lanes, every lane owns 4 consecutive columns (16-byte loads)
+__global__ __launch_bounds__(256) void bn_act_bwd_a_vec_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, double* sums, int M, int C,
+                                                               int act, int rows_per_block) {
+    __shared__ float red[2][16][64];
+    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c);
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+    for (int r = r0 + ry; r < r1; r += 16) {     // <= 16 rows per lane and block: fp32 partials, fp64 across blocks
+        const int64_t i = (int64_t)r * C + c;
+        const float4 zv = *(const float4*)(z + i), dv = *(const float4*)(dy + i);
+        float zh, d;
+        zh = (zv.x - mu.x) * rs.x, d = bn_dact(dv.x, zh * g.x + b.x, act), f0.x += d, f1.x += d * zh;
+        zh = (zv.y - mu.y) * rs.y, d = bn_dact(dv.y, zh * g.y + b.y, act), f0.y += d, f1.y += d * zh;
+        zh = (zv.z - mu.z) * rs.z, d = bn_dact(dv.z, zh * g.z + b.z, act), f0.z += d, f1.z += d * zh;
+        zh = (zv.w - mu.w) * rs.w, d = bn_dact(dv.w, zh * g.w + b.w, act), f0.w += d, f1.w += d * zh;
+    }
+    *(float4*)&red[0][ry][cg * 4] = f0;
+    *(float4*)&red[1][ry][cg * 4] = f1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += (double)red[which][q][cc];
+        atomicAdd(&sums[which * C + blockIdx.x * 64 + cc], a);
+    }
+}
+
 extern "C" int a3t_bn_act_bwd_a(const void* dy, int dy_dtype, const float* z, const float* mean, const float* rstd,
-                                const float* gamma, const float* beta, float* dbn, double* sums, int M, int C,
-                                int act, void* stream) {
+                                const float* gamma, const float* beta, double* sums, int M, int C, int act,
+                                void* stream) {
     int rpb = 256;
     dim3 grid((C + 63) / 64, (M + rpb - 1) / rpb);
+    if (dy_dtype == A3T_F32 && C % 64 == 0 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)z % 16 == 0) &&
+        ((uintptr_t)mean % 16 == 0) && ((uintptr_t)rstd % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+        ((uintptr_t)beta % 16 == 0)) {
+        hipLaunchKernelGGL(bn_act_bwd_a_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)dy, z, mean, rstd,
+                           gamma, beta, sums, M, C, act, rpb);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(bn_act_bwd_a_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, z, mean, rstd, gamma, beta,
-                       dbn, sums, M, C, act, rpb);
+                       sums, M, C, act, rpb);
     return (int)hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_b_kernel(const float* __restrict__ dbn, const float* __restrict__ z,
+__global__ __launch_bounds__(256) void bn_act_bwd_b_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ z,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma, const double* sums,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const double* sums,
                                                            float* __restrict__ dz, float* dgamma, float* dbeta,
-                                                           int M, int C, int training) {
+                                                           int M, int C, int training, int act, int vec) {
     const int64_t n = (int64_t)M * C;
     const double invM = 1.0 / (double)M;
     if (blockIdx.x == 0) {
@@ -478,25 +556,49 @@ __global__ __launch_bounds__(256) void bn_act_bwd_b_kernel(const float* __restri
             dbeta[c] += (float)sums[c];
         }
     }
+    if (vec) {   // C % 4 == 0, fp32 dy, 16-byte aligned: 4 consecutive columns per lane
+        const int64_t n4 = n >> 2;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = q << 2;
+            const int c = (int)(i % C);
+            const float4 zv = *(const float4*)(z + i), dv = *(const float4*)((const float*)dy + i);
+            const float4 mu = *(const float4*)(mean + c), rs = *(const float4*)(rstd + c);
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            const float zz[4] = {zv.x, zv.y, zv.z, zv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float mm[4] = {mu.x, mu.y, mu.z, mu.w}, rr[4] = {rs.x, rs.y, rs.z, rs.w};
+            const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float zh = (zz[e] - mm[e]) * rr[e];
+                float d = bn_dact(dd[e], zh * gg[e] + bb[e], act);
+                if (training) d = d - (float)(sums[c + e] * invM) - zh * (float)(sums[C + c + e] * invM);
+                o[e] = gg[e] * rr[e] * d;
+            }
+            *(float4*)(dz + i) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
         float rs = rstd[c];
-        float d = dbn[i];
-        if (training) {
-            float zh = (z[i] - mean[c]) * rs;
-            d = d - (float)(sums[c] * invM) - zh * (float)(sums[C + c] * invM);
-        }
+        float zh = (z[i] - mean[c]) * rs;
+        float d = bn_dact(ldx(dy, dy_dt, i), zh * gamma[c] + beta[c], act);
+        if (training) d = d - (float)(sums[c] * invM) - zh * (float)(sums[C + c] * invM);
         dz[i] = gamma[c] * rs * d;
     }
 }
 
-extern "C" int a3t_bn_act_bwd_b(const float* dbn, const float* z, const float* mean, const float* rstd,
-                                const float* gamma, const double* sums, float* dz, float* dgamma, float* dbeta, int M,
-                                int C, int training, void* stream) {
+extern "C" int a3t_bn_act_bwd_b(const void* dy, int dy_dtype, const float* z, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, const double* sums, float* dz, float* dgamma,
+                                float* dbeta, int M, int C, int training, int act, void* stream) {
     int64_t n = (int64_t)M * C;
-    int blocks = (int)((n + 255) / 256);
+    const int vec = (dy_dtype == A3T_F32 && C % 4 == 0 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)z % 16 == 0) &&
+                     ((uintptr_t)dz % 16 == 0) && ((uintptr_t)mean % 16 == 0) && ((uintptr_t)rstd % 16 == 0) &&
+                     ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0)) ? 1 : 0;
+    int blocks = (int)(((vec ? n / 4 : n) + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_act_bwd_b_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dbn, z, mean, rstd, gamma,
-                       sums, dz, dgamma, dbeta, M, C, training);
+    hipLaunchKernelGGL(bn_act_bwd_b_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, z, mean, rstd,
+                       gamma, beta, sums, dz, dgamma, dbeta, M, C, training, act, vec);
     return (int)hipGetLastError();
 }

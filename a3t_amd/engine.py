@@ -407,9 +407,8 @@ class MLMEngine:
         p, gr = self.store.p, self.store.g
         z, mean, rstd = self.sv[tag + ".bn"]
         M, C = z.shape
-        dbn = self.ws.get("tmp.dbn", (M, C))
         sums = self.ws.get("tmp.bnsums", (2 * C,), torch.float64)
-        ops.bn_act_bwd(dy, z, mean, rstd, p[pre + ".g"], p[pre + ".b"], dbn, sums, dz, gr[pre + ".g"], gr[pre + ".b"],
+        ops.bn_act_bwd(dy, z, mean, rstd, p[pre + ".g"], p[pre + ".b"], sums, dz, gr[pre + ".g"], gr[pre + ".b"],
                        self.training, act)
 
     def _conv_fwd(self, tag, pre, x, T):

@@ -186,14 +186,14 @@ def bn_act_fwd(z, stats, g, b, rmean, rvar, mean_out, rstd_out, y, eps, momentum
                                     _stream()), "bn_act_fwd")
 
 
-def bn_act_bwd(dy, z, mean, rstd, g, b, dbn, sums, dz, dg, db, training, act):
+def bn_act_bwd(dy, z, mean, rstd, g, b, sums, dz, dg, db, training, act):
     M, C = z.shape
     lib = L.load()
     sums.zero_()
-    L.check(lib.a3t_bn_act_bwd_a(_ptr(dy), _dt(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(dbn),
-                                 _ptr(sums), M, C, act, _stream()), "bn_bwd_a")
-    L.check(lib.a3t_bn_act_bwd_b(_ptr(dbn), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(sums), _ptr(dz), _ptr(dg),
-                                 _ptr(db), M, C, int(training), _stream()), "bn_bwd_b")
+    L.check(lib.a3t_bn_act_bwd_a(_ptr(dy), _dt(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(sums), M, C,
+                                 act, _stream()), "bn_bwd_a")
+    L.check(lib.a3t_bn_act_bwd_b(_ptr(dy), _dt(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(sums),
+                                 _ptr(dz), _ptr(dg), _ptr(db), M, C, int(training), act, _stream()), "bn_bwd_b")
 
 
 def glu_dwconv_fwd(g, wdw, bdw, glu, z, Tseq):

@@ -121,15 +121,14 @@ int a3t_f64_to_f32_add(const double* src, float* dst, int n, float scale, void* 
 int a3t_bn_act_fwd(const float* z, const double* stats, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float* mean_out, float* rstd_out, void* y,
                    int y_dtype, int M, int C, float eps, float momentum, int training, int act, void* stream);
-/* step A: dbn = dy * act'(bn) written to dbn; sums += (sum dbn, sum dbn*zhat) (double[2][C]) */
+/* step A: sums += (sum dbn, sum dbn*zhat) (double[2][C]) with dbn = dy * act'(bn) (recomputed, never stored) */
 int a3t_bn_act_bwd_a(const void* dy, int dy_dtype, const float* z, const float* mean, const float* rstd,
-                     const float* gamma, const float* beta, float* dbn, double* sums, int M, int C, int act,
-                     void* stream);
+                     const float* gamma, const float* beta, double* sums, int M, int C, int act, void* stream);
 /* step B: dz = gamma*rstd*(dbn - sum0/M - zhat*sum1/M) (training) or gamma*rstd*dbn (eval);
  * dgamma += sum1, dbeta += sum0 */
-int a3t_bn_act_bwd_b(const float* dbn, const float* z, const float* mean, const float* rstd,
-                     const float* gamma, const double* sums, float* dz, float* dgamma, float* dbeta, int M,
-                     int C, int training, void* stream);
+int a3t_bn_act_bwd_b(const void* dy, int dy_dtype, const float* z, const float* mean, const float* rstd,
+                     const float* gamma, const float* beta, const double* sums, float* dz, float* dgamma,
+                     float* dbeta, int M, int C, int training, int act, void* stream);
 
 /* GLU + depthwise Conv1d (conformer/convolution.py:66-72): g[M][2C] -> glu[M][C] (saved) and
  * z[m][c] = bdw[c] + sum_k wdw[c][k] * glu[m+k-(K-1)/2][c], zero padded per utterance (Tseq). */
