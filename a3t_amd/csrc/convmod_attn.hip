@@ -321,9 +321,50 @@ __global__ void add_pos_bias_kernel(const void* __restrict__ qkv, const float* _
         stx(qv, dt, i, q + bv[c]);
     }
 }
+// bf16 storage, d % 8 == 0: 8 channels (16 bytes) per lane
+__device__ __forceinline__ void apb_unpack8(const uint4& u, float* f) {
+    f[0] = bf2f_(u.x & 0xffff), f[1] = bf2f_(u.x >> 16), f[2] = bf2f_(u.y & 0xffff), f[3] = bf2f_(u.y >> 16);
+    f[4] = bf2f_(u.z & 0xffff), f[5] = bf2f_(u.z >> 16), f[6] = bf2f_(u.w & 0xffff), f[7] = bf2f_(u.w >> 16);
+}
+__device__ __forceinline__ uint4 apb_pack8(const float* f) {
+    uint4 u;
+    u.x = io_f2bf(f[0]) | ((unsigned)io_f2bf(f[1]) << 16), u.y = io_f2bf(f[2]) | ((unsigned)io_f2bf(f[3]) << 16);
+    u.z = io_f2bf(f[4]) | ((unsigned)io_f2bf(f[5]) << 16), u.w = io_f2bf(f[6]) | ((unsigned)io_f2bf(f[7]) << 16);
+    return u;
+}
+__global__ void add_pos_bias_bf16_kernel(const unsigned short* __restrict__ qkv, const float* __restrict__ bu,
+                                         const float* __restrict__ bv, unsigned short* __restrict__ qu,
+                                         unsigned short* __restrict__ qv, int64_t n8, int d8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / d8;
+        const int c = (int)(i - m * d8) * 8;
+        float q[8], o[8];
+        apb_unpack8(*(const uint4*)(qkv + m * 3 * d8 * 8 + c), q);
+        const float4 u0 = *(const float4*)(bu + c), u1 = *(const float4*)(bu + c + 4);
+        const float4 v0 = *(const float4*)(bv + c), v1 = *(const float4*)(bv + c + 4);
+        const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = q[e] + uu[e];
+        *(uint4*)(qu + i * 8) = apb_pack8(o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = q[e] + vv[e];
+        *(uint4*)(qv + i * 8) = apb_pack8(o);
+    }
+}
+static inline bool apb_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int a3t_add_pos_bias(const void* qkv, const float* bias_u, const float* bias_v, void* qu, void* qv,
                                 int dtype, int M, int d, void* stream) {
     int64_t n = (int64_t)M * d;
+    if (dtype == A3T_BF16 && d % 8 == 0 && apb_al16(qkv) && apb_al16(qu) && apb_al16(qv) && apb_al16(bias_u) &&
+        apb_al16(bias_v)) {
+        int64_t n8 = n / 8;
+        int blocks = (int)((n8 + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(add_pos_bias_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)qkv, bias_u, bias_v, (unsigned short*)qu, (unsigned short*)qv, n8, d / 8);
+        return (int)hipGetLastError();
+    }
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(add_pos_bias_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, bias_u, bias_v, qu,
@@ -338,9 +379,30 @@ __global__ void add_pos_bias_bwd_kernel(const void* __restrict__ dqu, const void
         stx(dqkv, dt, m * 3 * d + c, ldx(dqu, dt, i) + ldx(dqv, dt, i));
     }
 }
+__global__ void add_pos_bias_bwd_bf16_kernel(const unsigned short* __restrict__ dqu, const unsigned short* __restrict__ dqv,
+                                             unsigned short* __restrict__ dqkv, int64_t n8, int d8) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / d8;
+        const int c = (int)(i - m * d8) * 8;
+        float a[8], b[8], o[8];
+        apb_unpack8(*(const uint4*)(dqu + i * 8), a);
+        apb_unpack8(*(const uint4*)(dqv + i * 8), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = a[e] + b[e];
+        *(uint4*)(dqkv + m * 3 * d8 * 8 + c) = apb_pack8(o);
+    }
+}
 extern "C" int a3t_add_pos_bias_bwd(const void* dqu, const void* dqv, void* dqkv, int dtype, int M, int d,
                                     void* stream) {
     int64_t n = (int64_t)M * d;
+    if (dtype == A3T_BF16 && d % 8 == 0 && apb_al16(dqu) && apb_al16(dqv) && apb_al16(dqkv)) {
+        int64_t n8 = n / 8;
+        int blocks = (int)((n8 + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(add_pos_bias_bwd_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)dqu, (const unsigned short*)dqv, (unsigned short*)dqkv, n8, d / 8);
+        return (int)hipGetLastError();
+    }
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(add_pos_bias_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dqu, dqv, dqkv, dtype,

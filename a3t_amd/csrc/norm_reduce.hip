@@ -331,11 +331,50 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const void* __restrict_
     }
 }
 
+// fp32 x, no row mask, C % 64 == 0: block = 64 columns x 16 row lanes, 4 consecutive columns (16 bytes) per lane
+__global__ __launch_bounds__(256) void col_reduce_vec_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             double* out0, double* out1, int M, int C, int64_t ld, int mode,
+                                                             int rows_per_block) {
+    __shared__ float red[2][16][64];
+    const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cg * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+    for (int r = r0 + ry; r < r1; r += 16) {      // <= 16 rows per lane and block in fp32, fp64 across lanes / blocks
+        const float4 v = *(const float4*)(x + (int64_t)r * ld + c);
+        f0.x += v.x, f0.y += v.y, f0.z += v.z, f0.w += v.w;
+        if (mode == 1) {
+            f1.x += v.x * v.x, f1.y += v.y * v.y, f1.z += v.z * v.z, f1.w += v.w * v.w;
+        } else if (mode == 2) {
+            const float4 w = *(const float4*)(y + (int64_t)r * ld + c);
+            f1.x += v.x * w.x, f1.y += v.y * w.y, f1.z += v.z * w.z, f1.w += v.w * w.w;
+        }
+    }
+    *(float4*)&red[0][ry][cg * 4] = f0;
+    *(float4*)&red[1][ry][cg * 4] = f1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        if (which == 0 || mode) {
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a += (double)red[which][q][cc];
+            atomicAdd(&(which ? out1 : out0)[blockIdx.x * 64 + cc], a);
+        }
+    }
+}
+
 extern "C" int a3t_col_reduce(const void* x, int x_dtype, const float* y, const uint8_t* rowmask, double* out0,
                               double* out1, int M, int C, int64_t ld, int mode, void* stream) {
     if (M <= 0 || C <= 0) return A3T_EINVAL;
     int rpb = 256;
     dim3 grid((C + 63) / 64, (M + rpb - 1) / rpb);
+    if (x_dtype == A3T_F32 && !rowmask && C % 64 == 0 && ld % 4 == 0 && ((uintptr_t)x % 16 == 0) &&
+        (mode != 2 || ((uintptr_t)y % 16 == 0))) {
+        hipLaunchKernelGGL(col_reduce_vec_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, y, out0, out1, M,
+                           C, ld, mode, rpb);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(col_reduce_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_dtype, y, rowmask, out0, out1, M,
                        C, ld, mode, rpb);
     return (int)hipGetLastError();

@@ -413,3 +413,39 @@ def test_layernorm_bwd_fused_consumer_dropout():
     assert abs(keep - (1 - p)) < 0.01
     _close(cs_a, cs_b, atol=1e-3, rtol=1e-4)
     _close(dg_a, dg_b, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_add_pos_bias_fwd_bwd(dt):
+    """q + pos_bias_u / q + pos_bias_v out of the fused qkv projection and the backward sum into d(qkv)[:, :d]
+    (attention.py:190-199); bf16 takes the 16-byte vector kernels."""
+    ops = _ops()
+    M, d = 333, 384
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    qkv = _rand(M, 3 * d, seed=1).to(DEV).to(tdt)
+    u, v = _rand(d, seed=2).to(DEV), _rand(d, seed=3).to(DEV)
+    qu, qv = torch.empty(M, d, device=DEV, dtype=tdt), torch.empty(M, d, device=DEV, dtype=tdt)
+    ops.add_pos_bias(qkv, u, v, qu, qv)
+    tol = dict(atol=2e-2, rtol=2e-2) if dt == "bf16" else dict(atol=1e-6, rtol=1e-6)
+    _close(qu, qkv[:, :d].float() + u, **tol)
+    _close(qv, qkv[:, :d].float() + v, **tol)
+    dqu, dqv = _rand(M, d, seed=4).to(DEV).to(tdt), _rand(M, d, seed=5).to(DEV).to(tdt)
+    dqkv = torch.full((M, 3 * d), 7.0, device=DEV, dtype=tdt)
+    ops.add_pos_bias_bwd(dqu, dqv, dqkv)
+    _close(dqkv[:, :d], dqu.float() + dqv.float(), **tol)
+    assert float((dqkv[:, d:].float() - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,C", [(1000, 128), (333, 96)])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_col_reduce_modes(M, C, mode):
+    ops = _ops()
+    x, y = _rand(M, C, seed=1).to(DEV), _rand(M, C, seed=2).to(DEV)
+    o0 = torch.zeros(C, dtype=torch.float64, device=DEV)
+    o1 = torch.zeros(C, dtype=torch.float64, device=DEV)
+    ops.col_reduce(x, o0, o1 if mode else None, y=y if mode == 2 else None, mode=mode)
+    _close(o0, x.double().sum(0), atol=1e-4, rtol=1e-6)
+    if mode == 1:
+        _close(o1, (x.double() ** 2).sum(0), atol=1e-4, rtol=1e-6)
+    if mode == 2:
+        _close(o1, (x.double() * y.double()).sum(0), atol=1e-4, rtol=1e-6)
