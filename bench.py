@@ -91,6 +91,50 @@ def vocoder_rtf(dev, B=8, Tf=1000, reps=3):
                 workload=f"ParallelWaveGAN v1 generator, B={B} x {Tf} frames, hop 300, 24 kHz")
 
 
+def collate_leg(dev, B=32, Tm=1000, Tp=120, reps=3):
+    """the batch construction the reference runs in a DataLoader worker (MLMCollateFn: pad, STFT ->
+    mel -> log10, align -> frames, span masks, segment ids) with the feature extraction on the GPU.  Input = host
+    waveforms (the PCIe copy of 4 B/sample is inside the timed region); CPU figure = the oracle's collate, 1 rep."""
+    import numpy as np
+    from a3t_amd.collate import MLMCollateFn
+    from a3t_amd.features import LogMelFbank
+    rs = np.random.RandomState(5)
+    hop, fs = 300, 24000
+    data = []
+    for i in range(B):
+        n = hop * (Tm - 1)
+        cuts = np.sort(rs.choice(np.arange(1, Tm - 1), Tp - 1, replace=False))
+        st = np.concatenate([[0], cuts]).astype(np.float32) * hop / fs + 1e-4
+        en = np.concatenate([cuts, [Tm - 1]]).astype(np.float32) * hop / fs + 1e-4
+        data.append((f"u{i}", dict(speech=(0.1 * rs.standard_normal(n)).astype(np.float32),
+                                   text=rs.randint(2, 70, size=Tp).astype(np.int64), align_start=st.astype(np.float32),
+                                   align_end=en.astype(np.float32))))
+    fe = LogMelFbank(fs=fs, n_fft=2048, win_length=1200, hop_length=hop, n_mels=80, fmin=80, fmax=7600, device=dev)
+    coll = MLMCollateFn(fe, mlm_prob=0.8, mean_phn_span=8, sega_emb=True)
+    np.random.seed(1)
+    coll(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _, out = coll(data)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    frames = int(out["speech"].shape[0] * out["speech"].shape[1])
+    res = dict(metric="collate mel-frames/s (host waveforms in, batch dict out)", frames_per_s=frames / dt, ms=dt * 1e3,
+               workload=f"B={B} utterances x {Tm} frames (12.5 s at 24 kHz), {Tp} phones each")
+    try:
+        from oracle import a3t_oracle as O
+        np.random.seed(1)
+        t0 = time.perf_counter()
+        O.collate(data, O.A3TConfig())
+        res["cpu_frames_per_s"] = frames / (time.perf_counter() - t0)
+        res["cpu_kind"] = "port (oracle collate, torch.stft on host threads)"
+    except Exception as e:  # noqa: BLE001
+        res["cpu_frames_per_s"] = None
+        res["cpu_note"] = type(e).__name__
+    return res
+
+
 def cpu_baseline_worker(blocks, Tm, Tp, threads, budget_s):
     """Runs in a child process: the oracle (CPU restatement of the reference) fwd+bwd+clip+Adam on
     `threads` host cores over a bounded sample of the same workload.  Prints one JSON line."""
@@ -156,6 +200,7 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--no-dropout", action="store_true", help="disable the recipe's dropout sites (debug only)")
     ap.add_argument("--no-vocoder", action="store_true")
+    ap.add_argument("--no-collate", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--threads", type=int, default=32)
@@ -277,6 +322,9 @@ def main():
         if world == 1 and not a.no_vocoder:
             log("vocoder leg (ParallelWaveGAN v1, 8 x 1000 frames)")
             out["vocoder"] = vocoder_rtf(dev)
+        if world == 1 and not a.no_collate:
+            log("collate leg (on-device log-mel)")
+            out["collate"] = collate_leg(dev)
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle on host cores, child process)")
             out["cpu_baseline"] = cpu_baseline(a.blocks, Tm, Tp, a.budget)
