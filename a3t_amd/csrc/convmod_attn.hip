@@ -328,8 +328,8 @@ __device__ __forceinline__ void apb_unpack8(const uint4& u, float* f) {
 }
 __device__ __forceinline__ uint4 apb_pack8(const float* f) {
     uint4 u;
-    u.x = io_f2bf(f[0]) | ((unsigned)io_f2bf(f[1]) << 16), u.y = io_f2bf(f[2]) | ((unsigned)io_f2bf(f[3]) << 16);
-    u.z = io_f2bf(f[4]) | ((unsigned)io_f2bf(f[5]) << 16), u.w = io_f2bf(f[6]) | ((unsigned)io_f2bf(f[7]) << 16);
+    u.x = io_pack2(f[0], f[1]), u.y = io_pack2(f[2], f[3]);
+    u.z = io_pack2(f[4], f[5]), u.w = io_pack2(f[6], f[7]);
     return u;
 }
 __global__ void add_pos_bias_bf16_kernel(const unsigned short* __restrict__ qkv, const float* __restrict__ bu,
@@ -510,8 +510,8 @@ __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
     uint4 u;
-    u.x = io_f2bf(f[0]) | ((unsigned)io_f2bf(f[1]) << 16), u.y = io_f2bf(f[2]) | ((unsigned)io_f2bf(f[3]) << 16);
-    u.z = io_f2bf(f[4]) | ((unsigned)io_f2bf(f[5]) << 16), u.w = io_f2bf(f[6]) | ((unsigned)io_f2bf(f[7]) << 16);
+    u.x = io_pack2(f[0], f[1]), u.y = io_pack2(f[2], f[3]);
+    u.z = io_pack2(f[4], f[5]), u.w = io_pack2(f[6], f[7]);
     return u;
 }
 

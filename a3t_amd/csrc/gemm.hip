@@ -267,10 +267,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GP p) {
     }
     auto pack8 = [](const float* f) {
         uint4 u;
-        u.x = f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-        u.y = f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-        u.z = f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-        u.w = f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+        u.x = io_pack2(f[0], f[1]);
+        u.y = io_pack2(f[2], f[3]);
+        u.z = io_pack2(f[4], f[5]);
+        u.w = io_pack2(f[6], f[7]);
         return u;
     };
     auto load8 = [&](const float* q) {  // 8 consecutive fp32 -> 8 bf16
@@ -334,14 +334,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GP p) {
             }
         }
         // row j gets (v[0][j], v[1][j], v[2][j], v[3][j]) = 4 consecutive k
-        o01.x = f2bf(v[0][0]) | ((unsigned)f2bf(v[1][0]) << 16);
-        o01.y = f2bf(v[2][0]) | ((unsigned)f2bf(v[3][0]) << 16);
-        o01.z = f2bf(v[0][1]) | ((unsigned)f2bf(v[1][1]) << 16);
-        o01.w = f2bf(v[2][1]) | ((unsigned)f2bf(v[3][1]) << 16);
-        o23.x = f2bf(v[0][2]) | ((unsigned)f2bf(v[1][2]) << 16);
-        o23.y = f2bf(v[2][2]) | ((unsigned)f2bf(v[3][2]) << 16);
-        o23.z = f2bf(v[0][3]) | ((unsigned)f2bf(v[1][3]) << 16);
-        o23.w = f2bf(v[2][3]) | ((unsigned)f2bf(v[3][3]) << 16);
+        o01.x = io_pack2(v[0][0], v[1][0]);
+        o01.y = io_pack2(v[2][0], v[3][0]);
+        o01.z = io_pack2(v[0][1], v[1][1]);
+        o01.w = io_pack2(v[2][1], v[3][1]);
+        o23.x = io_pack2(v[0][2], v[1][2]);
+        o23.y = io_pack2(v[2][2], v[3][2]);
+        o23.z = io_pack2(v[0][3], v[1][3]);
+        o23.w = io_pack2(v[2][3], v[3][3]);
     };
 
     auto load_tiles = [&](int k0) {

@@ -31,11 +31,7 @@ struct GP {
     float drop_inv;   // 1/(1-p), 0 when dropout is off
 };
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (NaN payloads are not preserved)
-    return (unsigned short)(u >> 16);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return io_f2bf(f); }   // hardware RNE conversion
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
 template <typename T>
@@ -148,8 +144,8 @@ __device__ __forceinline__ void epilogue_vec4(const GP& p, float4 v, int64_t idx
     cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
     if (p.c_dtype == A3T_BF16) {
         uint2 o;
-        o.x = f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-        o.y = f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+        o.x = io_pack2(v.x, v.y);
+        o.y = io_pack2(v.z, v.w);
         *(uint2*)((unsigned short*)p.C + idx) = o;
     } else {
         float* C = (float*)p.C + idx;

@@ -131,8 +131,8 @@ __global__ void cast_kernel(const float* __restrict__ x, unsigned short* __restr
     GRID_STRIDE(i, n4) {
         float4 v = ((const float4*)x)[i];
         uint2 o;
-        o.x = io_f2bf(v.x) | ((unsigned)io_f2bf(v.y) << 16);
-        o.y = io_f2bf(v.z) | ((unsigned)io_f2bf(v.w) << 16);
+        o.x = io_pack2(v.x, v.y);
+        o.y = io_pack2(v.z, v.w);
         ((uint2*)y)[i] = o;
     }
 }

@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
             }
             if (dx16) {
                 uint2 h;
-                h.x = io_f2bf(o.x) | ((unsigned)io_f2bf(o.y) << 16);
-                h.y = io_f2bf(o.z) | ((unsigned)io_f2bf(o.w) << 16);
+                h.x = io_pack2(o.x, o.y);
+                h.y = io_pack2(o.z, o.w);
                 *(uint2*)(dx16 + ro + c) = h;
             }
             ax[i].x += o.x, ax[i].y += o.y, ax[i].z += o.z, ax[i].w += o.w;
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
             }
             if (y_dt == A3T_BF16) {
                 uint2 h;
-                h.x = io_f2bf(o[0]) | ((unsigned)io_f2bf(o[1]) << 16);
-                h.y = io_f2bf(o[2]) | ((unsigned)io_f2bf(o[3]) << 16);
+                h.x = io_pack2(o[0], o[1]);
+                h.y = io_pack2(o[2], o[3]);
                 *(uint2*)((unsigned short*)y + i) = h;
             } else {
                 *(float4*)((float*)y + i) = make_float4(o[0], o[1], o[2], o[3]);
