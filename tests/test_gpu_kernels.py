@@ -449,3 +449,32 @@ def test_col_reduce_modes(M, C, mode):
         _close(o1, (x.double() ** 2).sum(0), atol=1e-4, rtol=1e-6)
     if mode == 2:
         _close(o1, (x.double() * y.double()).sum(0), atol=1e-4, rtol=1e-6)
+
+
+@pytest.mark.parametrize("taps,Cin,Cout,T", [(3, 128, 1536, 1030), (5, 64, 1536, 1100), (3, 1536, 128, 6 * 1030)])
+def test_conv_large_grid_single_buffer_variants(taps, Cin, Cout, T):
+    """Conv1d shapes whose grid is in the single-buffer / 4-workgroups-per-CU regime (>= 768 tiles, the production FFN
+    regime; the small shapes above take the double-buffered variants).  T is not a multiple of the 128-row tile, so
+    utterance boundaries fall inside tiles.  Forward (NT, fast-conv) and data gradient (NN, fast-conv)."""
+    ops = _ops()
+    from a3t_amd._lib import BF16, ACT_RELU
+    B = 8 if Cout >= 1536 else 16
+    T = T if Cout >= 1536 else 1030
+    M, pad = B * T, (taps - 1) // 2
+    x = (_rand(B, T, Cin, seed=1) * 0.5).bfloat16().float()
+    Wt = (_rand(Cout, Cin, taps, seed=2) * (Cin * taps) ** -0.5).bfloat16().float()      # torch layout (out, in, k)
+    bias = _rand(Cout, seed=3)
+    ref = F.relu(F.conv1d(x.transpose(1, 2), Wt, bias, padding=pad)).transpose(1, 2).reshape(M, Cout)
+    Wk = Wt.permute(0, 2, 1).contiguous().to(DEV).bfloat16()                              # [out][tap][in]
+    xd = x.reshape(M, Cin).to(DEV).bfloat16()
+    out = torch.empty(M, Cout, device=DEV, dtype=torch.bfloat16)
+    ops.conv_fwd(xd, Wk, out, T, pad, bias=bias.to(DEV), act=ACT_RELU, compute=BF16)
+    _close(out, ref, atol=3e-2, rtol=3e-2)
+    # data gradient: dx[m][c] = sum_tap sum_n dy[m - (tap - pad)][n] W[n][tap][c]
+    dy = (_rand(B, T, Cout, seed=4) * 0.5).bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    F.conv1d(xr.transpose(1, 2), Wt, None, padding=pad).transpose(1, 2).backward(dy)
+    dx = torch.empty(M, Cin, device=DEV, dtype=torch.float32)
+    ops.conv_bwd_data(dy.reshape(M, Cout).to(DEV).bfloat16(), Wk, dx, T, pad, compute=BF16)
+    scale = float(xr.grad.abs().max())
+    _close(dx, xr.grad.reshape(M, Cin), atol=2e-2 * scale, rtol=3e-2)
