@@ -316,7 +316,8 @@ def main():
                                    f"fwd+bwd+clip+Adam, dropout {'off' if a.no_dropout else '0.2/0.2/0.2 + postnet 0.5 (recipe)'}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "params": tr.store.n_params,
                        "masked_fraction": float(batch["masked_position"].float().mean()),
-                       "algorithmic_tflop_per_step": step_flops / 1e12, "final_loss": final_loss},
+                       "algorithmic_tflop_per_step": step_flops / 1e12, "final_loss": final_loss,
+                       "hbm_allocated_gb": torch.cuda.max_memory_allocated(dev) / 1e9},
             "roofline": roofline,
         }
         if world == 1 and not a.no_vocoder:
