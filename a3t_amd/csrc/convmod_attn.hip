@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_fwd_bf16_kernel(
     for (int q = 0; q < NC; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            v[q][e] = (v[q][e] > NEG) ? expf(v[q][e] - mx) : 0.f;
+            v[q][e] = (v[q][e] > NEG) ? __expf(v[q][e] - mx) : 0.f;   // v_exp_f32: bf16 probabilities need no more
             s += v[q][e];
         }
     s = wsum(s);
