@@ -59,6 +59,57 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// D % 128 == 0 fast path: half a wave (32 lanes) per row, NQ float4 per lane (D = 128*NQ): 16-byte loads, 8-byte
+// (bf16) / 16-byte stores, two rows in flight per wave.
+template <int NQ>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ b, void* __restrict__ y, int y_dt,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int M,
+                                                         int D, float eps) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
+    const int row = (blockIdx.x * 4 + wv) * 2 + half;
+    const bool ok = row < M;
+    const int64_t ro = (int64_t)(ok ? row : 0) * D;
+    float4 v[NQ];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        v[i] = *(const float4*)(x + ro + (hl + 32 * i) * 4);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+    const float mu = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const float a = v[i].x - mu, c = v[i].y - mu, d = v[i].z - mu, e = v[i].w - mu;
+        q += a * a + c * c + d * d + e * e;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, WAVE);
+    const float rs = 1.0f / sqrtf(q / (float)D + eps);
+    if (!ok) return;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int c = (hl + 32 * i) * 4;
+        const float4 gg = *(const float4*)(g + c), bb = *(const float4*)(b + c);
+        const float o0 = (v[i].x - mu) * rs * gg.x + bb.x, o1 = (v[i].y - mu) * rs * gg.y + bb.y;
+        const float o2 = (v[i].z - mu) * rs * gg.z + bb.z, o3 = (v[i].w - mu) * rs * gg.w + bb.w;
+        if (y_dt == A3T_BF16) {
+            uint2 h;
+            h.x = io_pack2(o0, o1), h.y = io_pack2(o2, o3);
+            *(uint2*)((unsigned short*)y + ro + c) = h;
+        } else {
+            *(float4*)((float*)y + ro + c) = make_float4(o0, o1, o2, o3);
+        }
+    }
+    if (hl == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
 // dx = dres + LN'(dy); optional bf16 copy; column sums of dy*xhat, dy (and optionally of dx, the
 // bias gradient of whatever produced the residual-stream gradient) reduced per block, then atomics.
 template <int V>
@@ -243,6 +294,18 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
 extern "C" int a3t_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, int y_dtype,
                                  float* mean, float* rstd, int M, int D, float eps, void* stream) {
     if (D > 64 * LN_MAXV || M <= 0) return A3T_EINVAL;
+    if (D % 128 == 0 && D <= 512 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+        ((uintptr_t)beta % 16 == 0)) {
+#define VCALL(NQ)                                                                                                     \
+    hipLaunchKernelGGL(ln_fwd_vec_kernel<NQ>, dim3((M + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, \
+                       y_dtype, mean, rstd, M, D, eps)
+        if (D == 128) VCALL(1);
+        else if (D == 256) VCALL(2);
+        else if (D == 384) VCALL(3);
+        else VCALL(4);
+#undef VCALL
+        return (int)hipGetLastError();
+    }
 #define CALL(V)                                                                                                  \
     hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, \
                        y_dtype, mean, rstd, M, D, eps)
