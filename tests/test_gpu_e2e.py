@@ -401,3 +401,31 @@ def test_full_size_c2_step_is_finite_and_bf16_tracks_fp32():
     e32 = MLMEngine(c, store, compute="f32", training=True, dropout=False)
     loss32 = float(e32.forward(batch, need_grad=False)["loss"])
     assert abs(loss16 - loss32) < 1e-2 * abs(loss32), (loss16, loss32)
+
+
+def test_c4_shape_family_bf16_tracks_fp32():
+    """BASELINE configs[3] architecture family (d=512, H=4 -> d_k=128, ff=2048) at a small batch: every kernel sees
+    shapes different from the recipe's (LayerNorm D=512, attention N=128 tiles, 4 heads per utterance).  The bf16
+    production schedule must track the exact-fp32 engine: loss to 1e-2, flat gradient cosine >= 0.99."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.collate import synthetic_batch
+    from a3t_amd.engine import MLMEngine
+    c = A3TConfig(adim=512, heads=4, ff=2048, enc_blocks=2, dec_blocks=2)
+    store, eng = _engine_for(c, "bf16")
+    batch = synthetic_batch(c, 3, 400, 48, seed=21, device=DEV)
+    eng.refresh_weights()
+    store.zero_grad()
+    l16 = float(eng.forward(batch)["loss"])
+    eng.backward()
+    torch.cuda.synchronize()
+    g16 = store.grad.clone()
+    e32 = MLMEngine(c, store, compute="f32", training=True, dropout=False)
+    store.zero_grad()
+    l32 = float(e32.forward(batch)["loss"])
+    e32.backward()
+    torch.cuda.synchronize()
+    g32 = store.grad.clone()
+    assert abs(l16 - l32) < 1e-2 * abs(l32), (l16, l32)
+    assert bool(torch.isfinite(g16).all())
+    assert float(torch.nn.functional.cosine_similarity(g16, g32, dim=0)) > 0.99
+    assert abs(float(g16.norm() / g32.norm()) - 1.0) < 0.05
