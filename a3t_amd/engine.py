@@ -90,6 +90,8 @@ class MLMEngine:
         self._par = 0
         self._side_ev = [None, None]
         self._gm_ready = None
+        self._arena = {k: dict(buf=None, used=0, slots={}, dtype=dt) for k, dt in
+                       (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
         self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
@@ -177,6 +179,26 @@ class MLMEngine:
     def _g16(self, g):
         """bf16 companion of the residual-stream gradient (written by the LayerNorm backward)."""
         return self.ws.get("grad.x16", tuple(g.shape), torch.bfloat16) if self.bf16 else None
+
+    # ---- small accumulators (BatchNorm sums, rel-pos projection gradient) -------------------------
+    # They must start every pass at zero.  Instead of ~45 tiny fill launches per step they live in two arenas
+    # (fp64 / fp32) that are cleared with ONE fill each at the start of forward and of backward; a slot keeps its
+    # offset for the lifetime of the engine.
+    def _arena_slot(self, kind, name, numel):
+        ar = self._arena[kind]
+        if name not in ar["slots"]:
+            ar["slots"][name] = (ar["used"], numel)
+            ar["used"] += (numel + 63) // 64 * 64
+            if ar["buf"] is None or ar["used"] > ar["buf"].numel():   # grow (first step only): re-create and clear
+                new = torch.zeros(max(2 * ar["used"], 1 << 16), dtype=ar["dtype"], device=self.dev)
+                ar["buf"] = new
+        o, n = ar["slots"][name]
+        return ar["buf"][o:o + n]
+
+    def _arena_clear(self, kind):
+        ar = self._arena[kind]
+        if ar["buf"] is not None and ar["used"]:
+            ar["buf"][:ar["used"]].zero_()
 
     # ---- side-stream protocol -------------------------------------------------------------------
     def _t(self, name):
@@ -348,7 +370,7 @@ class MLMEngine:
         ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=pdrop,
                                drop_p=c.attention_dropout_rate if pdrop is not None else 0.0)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
-            dP = self.ws.get("tmp.dP", (T, d), zero=True)
+            dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
             ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
                      c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
             if self.bf16:
@@ -391,9 +413,8 @@ class MLMEngine:
     def _bn_fwd(self, tag, z, pre, bufpre, act, out):
         p, b = self.store.p, self.store.buf
         M, C = z.shape
-        stats = self.ws.get(tag + ".stats", (2 * C,), torch.float64)
+        stats = self._arena_slot("fwd64", tag + ".stats", 2 * C)      # cleared once per forward
         if self.training:
-            stats.zero_()
             ops.col_reduce(z, stats[:C], stats[C:], mode=1)
         mean = self.ws.get(tag + ".bnmean", (C,))
         rstd = self.ws.get(tag + ".bnrstd", (C,))
@@ -407,9 +428,9 @@ class MLMEngine:
         p, gr = self.store.p, self.store.g
         z, mean, rstd = self.sv[tag + ".bn"]
         M, C = z.shape
-        sums = self.ws.get("tmp.bnsums", (2 * C,), torch.float64)
+        sums = self._arena_slot("bwd64", tag + ".bnsums", 2 * C)      # cleared once per backward
         ops.bn_act_bwd(dy, z, mean, rstd, p[pre + ".g"], p[pre + ".b"], sums, dz, gr[pre + ".g"], gr[pre + ".b"],
-                       self.training, act)
+                       self.training, act, zero=False)
 
     def _conv_fwd(self, tag, pre, x, T):
         p, c = self.store.p, self.c
@@ -486,6 +507,7 @@ class MLMEngine:
         self.dims = (B, Tm, Tp, T)
         self.step_seed += 1
         self.refresh_weights()
+        self._arena_clear("fwd64")
         pp = c.positional_dropout_rate
         masked = batch["masked_position"].contiguous().view(torch.uint8)
         keymask = ws.get("keymask", (B, T), torch.uint8)
@@ -583,6 +605,8 @@ class MLMEngine:
         B, Tm, Tp, T = self.dims
         d = c.adim
         cmp = self.cmp
+        self._arena_clear("bwd64")
+        self._arena_clear("bwd32")
         hs, before, after, db, da = self.sv["head"]
         pad = (c.postnet_filts - 1) // 2
         if c.postnet_layers > 0:

@@ -186,10 +186,11 @@ def bn_act_fwd(z, stats, g, b, rmean, rvar, mean_out, rstd_out, y, eps, momentum
                                     _stream()), "bn_act_fwd")
 
 
-def bn_act_bwd(dy, z, mean, rstd, g, b, sums, dz, dg, db, training, act):
+def bn_act_bwd(dy, z, mean, rstd, g, b, sums, dz, dg, db, training, act, zero=True):
     M, C = z.shape
     lib = L.load()
-    sums.zero_()
+    if zero:
+        sums.zero_()
     L.check(lib.a3t_bn_act_bwd_a(_ptr(dy), _dt(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(sums), M, C,
                                  act, _stream()), "bn_bwd_a")
     L.check(lib.a3t_bn_act_bwd_b(_ptr(dy), _dt(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(g), _ptr(b), _ptr(sums),
