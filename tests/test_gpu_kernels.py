@@ -478,3 +478,33 @@ def test_conv_large_grid_single_buffer_variants(taps, Cin, Cout, T):
     ops.conv_bwd_data(dy.reshape(M, Cout).to(DEV).bfloat16(), Wk, dx, T, pad, compute=BF16)
     scale = float(xr.grad.abs().max())
     _close(dx, xr.grad.reshape(M, Cin), atol=2e-2 * scale, rtol=3e-2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_relpos_softmax_long_rows_generic_three_pass_path(dt):
+    """T > 2048 (a > 25 s utterance): rows no longer fit the register-cached kernels, the generic three-pass kernel
+    runs (fp32 and bf16-typed), including the shifted-BD indexing and a partially padded utterance."""
+    ops = _ops()
+    B, H, T = 2, 1, 2056
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    ac = _rand(B, H, T, T, seed=1, scale=2.0).to(tdt).float().requires_grad_(True)
+    bd = _rand(B, H, T, T, seed=2, scale=2.0).to(tdt).float().requires_grad_(True)
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    mask[1, 0, T - 300:] = False
+    scale = 0.2
+    s = (ac + O.rel_shift_legacy(bd)) * scale
+    m = mask.unsqueeze(1).eq(0)
+    pr = torch.softmax(s.masked_fill(m, float(np.finfo(np.float32).min)), dim=-1).masked_fill(m, 0.0)
+    dp = _rand(B, H, T, T, seed=3).to(tdt).float()
+    pr.backward(dp)
+    probs = torch.empty(B, H, T, T, device=DEV, dtype=tdt)
+    ops.relpos_softmax_fwd(ac.detach().to(DEV).to(tdt), bd.detach().to(DEV).to(tdt), mask.view(B, T).to(DEV).view(torch.uint8),
+                           probs, B, H, T, scale)
+    tol = dict(atol=4e-3, rtol=1e-2) if dt == "bf16" else dict(atol=1e-6, rtol=1e-4)
+    _close(probs, pr, **tol)
+    ds = torch.empty(B, H, T, T, device=DEV, dtype=tdt)
+    dbd = torch.full((B, H, T, T), 7.0, device=DEV, dtype=tdt)
+    ops.relpos_softmax_bwd(probs, dp.to(DEV).to(tdt), ds, dbd, B, H, T, scale)
+    tol = dict(atol=6e-3, rtol=3e-2) if dt == "bf16" else dict(atol=1e-6, rtol=1e-3)
+    _close(ds, ac.grad, **tol)
+    _close(dbd, bd.grad, **tol)
