@@ -91,6 +91,36 @@ def vocoder_rtf(dev, B=8, Tf=1000, reps=3):
                 workload=f"ParallelWaveGAN v1 generator, B={B} x {Tf} frames, hop 300, 24 kHz")
 
 
+def infill_leg(dev, B=8, Tm=1000, Tp=120, span=(400, 600), reps=5):
+    """BASELINE.json configs[4] front half: teacher-forced span infill (ESPnetMLMModel.inference, sedit_model.py:239-284)
+    of B utterances with the reference-yaml model (4+4 blocks), eval-mode engine, bf16 compute; one forward per batch,
+    the predicted span [s, e) replaces the masked frames.  Reported next to the vocoder so that
+    pipeline RTF = (infill + vocoder) / audio seconds."""
+    from a3t_amd.collate import synthetic_batch
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    c = A3TConfig()                                   # reference yaml: 4 + 4 blocks, d = 384
+    store = ParamStore(c, dev)
+    xavier_init_(store, seed=0, bn_gamma=1.0)
+    eng = MLMEngine(c, store, compute="bf16", training=False)
+    batch = synthetic_batch(c, B, Tm, Tp, seed=99, device=dev)
+    batch["masked_position"][:] = False
+    batch["masked_position"][:, span[0]:span[1]] = True
+    eng.forward(batch, need_grad=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = eng.forward(batch, need_grad=False)
+        gen = [torch.cat([batch["speech"][b, :span[0]], out["after"][b, span[0]:span[1]].float(), batch["speech"][b, span[1]:]])
+               for b in range(B)]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return dict(ms=dt * 1e3, utterances=B, frames=B * Tm, finite=bool(torch.isfinite(torch.stack(gen)).all()),
+                workload=f"teacher-forced infill of span [{span[0]}, {span[1]}) in {B} x {Tm} frames, 4+4 blocks, eval")
+
+
 def collate_leg(dev, B=32, Tm=1000, Tp=120, reps=3):
     """the batch construction the reference runs in a DataLoader worker (MLMCollateFn: pad, STFT ->
     mel -> log10, align -> frames, span masks, segment ids) with the feature extraction on the GPU.  Input = host
@@ -323,6 +353,9 @@ def main():
         if world == 1 and not a.no_vocoder:
             log("vocoder leg (ParallelWaveGAN v1, 8 x 1000 frames)")
             out["vocoder"] = vocoder_rtf(dev)
+            inf = infill_leg(dev)
+            out["vocoder"]["infill"] = inf
+            out["vocoder"]["pipeline_rtf"] = (inf["ms"] + out["vocoder"]["ms"]) * 1e-3 / out["vocoder"]["audio_seconds"]
         if world == 1 and not a.no_collate:
             log("collate leg (on-device log-mel)")
             out["collate"] = collate_leg(dev)
