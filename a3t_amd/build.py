@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liba3t_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16_t256.hip", "norm_reduce.hip", "convmod_attn.hip", "dwconv_vec.hip", "misc.hip", "features.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16_t256.hip", "norm_reduce.hip", "convmod_attn.hip", "dwconv_vec.hip", "misc.hip", "pwg_fused.hip", "features.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("A3T_EXTRA_FLAGS", "").split()
 
 

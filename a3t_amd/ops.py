@@ -310,6 +310,12 @@ def pwg_gate(y, c, out):
     L.check(L.load().a3t_pwg_gate(_ptr(y), _ptr(c), _ptr(out), T, H, _stream()), "pwg_gate")
 
 
+def pwg_block(x, cu, wt0, b0, wt1, b1, g, skips, B, Tw, dil):
+    """Fused residual block (a3t_pwg_block): x, skips updated in place."""
+    L.check(L.load().a3t_pwg_block(_ptr(x), _ptr(cu), _ptr(wt0), _ptr(b0), _ptr(wt1), _ptr(b1), _ptr(g), _ptr(skips),
+                                   B, Tw, dil, _stream()), "pwg_block")
+
+
 def pwg_res_skip(o, x, skips):
     T, R = x.shape
     L.check(L.load().a3t_pwg_res_skip(_ptr(o), _ptr(x), _ptr(skips), T, R, skips.shape[1], _stream()), "pwg_res_skip")

@@ -9,6 +9,7 @@ Conv1d (dilated k=3, 1x1) is the shared implicit-im2col MFMA GEMM; the gated act
 skip update and nearest-neighbour upsampling+smoothing are element-wise HIP kernels.
 """
 import math
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -21,7 +22,8 @@ from ._lib import ACT_NONE, ACT_RELU, F32
 class ParallelWaveGANGeneratorHIP:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", layers=30, stacks=3, residual_channels=64,
                  gate_channels=128, skip_channels=64, aux_channels=80, aux_context_window=2,
-                 upsample_scales: Sequence[int] = (4, 5, 3, 5), stats: Optional[Dict[str, np.ndarray]] = None):
+                 upsample_scales: Sequence[int] = (4, 5, 3, 5), stats: Optional[Dict[str, np.ndarray]] = None,
+                 fused: Optional[bool] = None):
         self.dev = torch.device(device)
         self.layers, self.stacks = layers, stacks
         self.R, self.G, self.S, self.A = residual_channels, gate_channels, skip_channels, aux_channels
@@ -44,13 +46,27 @@ class ParallelWaveGANGeneratorHIP:
         self.w_in = conv("upsample_net.conv_in.weight")
         self.w_up = [t(f"upsample_net.upsample.up_layers.{2 * i + 1}.weight").reshape(-1).contiguous()
                      for i in range(len(self.scales))]
+        # fused residual-block kernels (pwg_fused.hip) need the v1 channel plan: 64 residual / 128 gate / 64 skip / 80 aux
+        if fused is None:
+            fused = os.environ.get("A3T_PWG_FUSED", "1") != "0"
+        self.fused = bool(fused) and (self.R, self.G, self.S, self.A) == (64, 128, 64, 80)
+        # stage-0 output column n' holds gate channel c = 32*(n'//64) + n'%32, tanh half for (n'//32)%2 == 0 else sigmoid
+        npr = np.arange(128)
+        perm = torch.as_tensor((npr // 64) * 32 + npr % 32 + 64 * ((npr // 32) % 2), device=self.dev)
         self.blocks = []
         for l in range(layers):
             p = f"conv_layers.{l}."
-            self.blocks.append(dict(w=conv(p + "conv.weight"), b=t(p + "conv.bias"),
-                                    aux=t(p + "conv1x1_aux.weight").reshape(self.G, self.A).contiguous(),
-                                    out=t(p + "conv1x1_out.weight").reshape(self.R + self.S, self.G // 2).contiguous(),
-                                    bout=t(p + "conv1x1_out.bias")))
+            blk = dict(w=conv(p + "conv.weight"), b=t(p + "conv.bias"),
+                       aux=t(p + "conv1x1_aux.weight").reshape(self.G, self.A).contiguous(),
+                       out=t(p + "conv1x1_out.weight").reshape(self.R + self.S, self.G // 2).contiguous(),
+                       bout=t(p + "conv1x1_out.bias"))
+            if self.fused:
+                wk = blk["w"].reshape(self.G, 3 * self.R)                       # [out][tap*64 + in]
+                w0 = torch.cat([wk, blk["aux"]], dim=1)[perm]                   # [n'][272]
+                blk["wt0"] = w0.t().contiguous()                                # [272][128] k-major
+                blk["b0"] = blk["b"][perm].contiguous()
+                blk["wt1"] = blk["out"].t().contiguous()                        # [64][128]
+            self.blocks.append(blk)
         self.w_l1 = t("last_conv_layers.1.weight").reshape(self.S, self.S).contiguous()
         self.b_l1 = t("last_conv_layers.1.bias")
         self.w_l3 = t("last_conv_layers.3.weight").reshape(1, self.S).contiguous()
@@ -98,6 +114,9 @@ class ParallelWaveGANGeneratorHIP:
         lps = self.layers // self.stacks
         for l, blk in enumerate(self.blocks):
             dil = 2 ** (l % lps)
+            if self.fused:
+                ops.pwg_block(x, cu, blk["wt0"], blk["b0"], blk["wt1"], blk["bout"], g, skips, B, Tw, dil)
+                continue
             ops.conv_fwd(x, blk["w"], y, Tw, 1, dil, bias=blk["b"], compute=F32)
             ops.linear_fwd(cu, blk["aux"], ca, compute=F32)
             ops.pwg_gate(y, ca, g)

@@ -229,6 +229,14 @@ int a3t_dropout(const void* x, int x_dtype, void* y, int y_dtype, int64_t n, flo
 int a3t_dropout_bwd_cast(const float* g, void* gm, int gm_dtype, float* colsum, float colsum_scale, int M, int C,
                          float p, uint32_t key, void* stream);
 
+/* One ParallelWaveGAN residual block (residual_block.py:114-169), fused: x and skips updated in place.
+ * x [B*Tw][64], cu [B*Tw][80] (upsampled mel), g scratch [B*Tw][64], skips [B*Tw][64], all fp32 channels-last.
+ * wt0 [272][128]: row k = tap*64 + in_channel (dilated k=3 conv, taps at t-dil, t, t+dil) | 192 + aux channel; column
+ * n' = permuted gate channel: n' = 64*(c/32) + 32*half + c%32 for gate channel c (0..63), half 0 = tanh, 1 = sigmoid;
+ * b0 [128] permuted the same way.  wt1 [64][128] = conv1x1_out.weight^T (columns 0..63 residual, 64..127 skip), b1 [128]. */
+int a3t_pwg_block(float* x, const float* cu, const float* wt0, const float* b0, const float* wt1, const float* b1,
+                  float* g, float* skips, int B, int Tw, int dil, void* stream);
+
 const char* a3t_version(void);
 /* Name (as rocprofv3 prints it, without "void " / "(GP)") of the kernel variant a3t_gemm's dispatcher launched last on
  * the calling thread -- lets a profiler harness attribute event-bracketed launches to kernel-trace rows. */

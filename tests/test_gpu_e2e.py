@@ -229,7 +229,9 @@ def test_dropout_backward_matches_finite_differences():
     store.flat.copy_(theta0)
 
 
-def test_parallel_wavegan_generator_matches_vendored_reference():
+@pytest.mark.parametrize("fused", [True, False])
+def test_parallel_wavegan_generator_matches_vendored_reference(fused):
+    """fused=True: two fp32-MFMA kernels per residual block (pwg_fused.hip); False: layer-by-layer GEMM path."""
     from a3t_amd.vocoder import ParallelWaveGANGeneratorHIP
     g = np.load(os.path.join(G, "pwg.npz"))
     cfg = O.PWGConfig()
@@ -237,7 +239,8 @@ def test_parallel_wavegan_generator_matches_vendored_reference():
     for k in state:
         if "up_layers" in k:
             state[k] = np.abs(state[k]) / np.abs(state[k]).sum()
-    voc = ParallelWaveGANGeneratorHIP(state, device=DEV)
+    voc = ParallelWaveGANGeneratorHIP(state, device=DEV, fused=fused)
+    assert voc.fused == fused
     wav = voc.inference(torch.from_numpy(g["c"]), torch.from_numpy(g["z"]))
     assert wav.shape == (6000, 1)
     np.testing.assert_allclose(wav.cpu().numpy(), g["wav"], atol=2e-5, rtol=1e-4)
