@@ -142,7 +142,9 @@ __global__ __launch_bounds__(512, 2) void pwg_stage_kernel(PwgArgs a) {
                     const int64_t row = (int64_t)b * a.Tw + t;
                     if (STAGE == 0) {
                         const float ya = acc[i][0][r] + bj0, yb = acc[i][1][r] + bj1;
-                        a.g[row * 64 + (wn >> 1) + lr] = tanhf(ya) * (1.f / (1.f + __expf(-yb)));
+                        // tanh(y) = 1 - 2 / (1 + e^{2y}): two v_exp_f32 + two v_rcp_f32 per output (abs error ~1e-7)
+                        const float th = 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * ya));
+                        a.g[row * 64 + (wn >> 1) + lr] = th * __frcp_rn(1.f + __expf(-yb));
                     } else {
                         const float o0 = acc[i][0][r] + bj0, o1 = acc[i][1][r] + bj1;
                         const int64_t i0 = row * 64 + lr;
