@@ -34,47 +34,51 @@ template <int STAGE>
 __global__ __launch_bounds__(512, 2) void pwg_stage_kernel(PwgArgs a) {
     // 8 waves = 4 (rows) x 2 (columns), each a 64 x 64 sub-tile of the 256-sample tile: two waves per SIMD, so one wave's
     // epilogue / LDS latency is covered by its partner's MFMAs (the weights leave room for ONE workgroup per CU only)
-    constexpr int K = STAGE == 0 ? 272 : 64, BK = 8, NCH = K / BK, TILE = 256, LD = TILE + 4;
+    // stage 0: K-chunks of 8 (weights 136 KiB + 16 KiB activation double buffer = 152 KiB of LDS; chunks of 16 with the
+    // last weight rows left in global memory measured 13 % slower); stage 1 (32 KiB of weights): chunks of 16.
+    constexpr int K = STAGE == 0 ? 272 : 64, KL = K, BK = STAGE == 0 ? 8 : 16, NCH = K / BK, TILE = 256, LD = TILE + 4;
+    constexpr int NF = BK / 8;           // float4 per thread and chunk
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wt = lds;                                              // [K][128]
-    float(*As)[BK][LD] = (float(*)[BK][LD])(lds + K * 128);       // [2][BK][LD]
+    float* Wt = lds;                                              // [KL][128]
+    float(*As)[BK][LD] = (float(*)[BK][LD])(lds + KL * 128);      // [2][BK][LD]
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64, lr = lane & 31, lk = lane >> 5;
-    for (int i = tid; i < K * 128 / 4; i += 512) ((float4*)Wt)[i] = ((const float4*)a.wt)[i];
+    for (int i = tid; i < KL * 128 / 4; i += 512) ((float4*)Wt)[i] = ((const float4*)a.wt)[i];
 
     const int ntiles = a.B * a.tiles_t;
-    const int r0 = tid >> 1, kq = (tid & 1) * 4;
+    const int r0 = tid >> 1, kq = (tid & 1) * (BK / 2);
     // The activation chunks are requested TWO chunks ahead of the MFMAs that consume them (register ring P0 / P1): with
-    // one persistent workgroup per CU nothing else hides the HBM latency (one chunk = 1024 MFMA cycles per wave).
-    float4 P0[1], P1[1];
+    // one persistent workgroup per CU nothing else hides the HBM latency (one chunk = 1024 / 2048 MFMA cycles per wave).
+    float4 P0[2], P1[2];
     auto load_chunk = [&](float4* dst, int tile, int kc) {
         const int b = tile / a.tiles_t, t0 = (tile - b * a.tiles_t) * TILE;
         const int k = kc * BK + kq;
-#pragma unroll
-        for (int ps = 0; ps < 1; ++ps) {
-            const int t = t0 + r0;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile < ntiles && t < a.Tw) {
-                if (STAGE == 0) {
-                    if (k < 192) {
-                        const int ts = t + ((k >> 6) - 1) * a.dil;
-                        if (ts >= 0 && ts < a.Tw) v = *(const float4*)(a.x_in + ((int64_t)b * a.Tw + ts) * 64 + (k & 63));
-                    } else {
-                        v = *(const float4*)(a.cu + ((int64_t)b * a.Tw + t) * 80 + (k - 192));
-                    }
+        const int t = t0 + r0;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (tile < ntiles && t < a.Tw) {
+            const float* src = nullptr;
+            if (STAGE == 0) {
+                if (k < 192) {
+                    const int ts = t + ((k >> 6) - 1) * a.dil;
+                    if (ts >= 0 && ts < a.Tw) src = a.x_in + ((int64_t)b * a.Tw + ts) * 64 + (k & 63);
                 } else {
-                    v = *(const float4*)(a.gin + ((int64_t)b * a.Tw + t) * 64 + k);
+                    src = a.cu + ((int64_t)b * a.Tw + t) * 80 + (k - 192);
                 }
+            } else {
+                src = a.gin + ((int64_t)b * a.Tw + t) * 64 + k;
             }
-            dst[ps] = v;
+            if (src) {
+                v0 = *(const float4*)src;
+                if (NF == 2) v1 = *(const float4*)(src + 4);
+            }
         }
+        dst[0] = v0, dst[1] = v1;
     };
     auto store_chunk = [&](const float4* src, int buf) {
-        As[buf][kq + 0][r0] = src[0].x;
-        As[buf][kq + 1][r0] = src[0].y;
-        As[buf][kq + 2][r0] = src[0].z;
-        As[buf][kq + 3][r0] = src[0].w;
+        As[buf][kq + 0][r0] = src[0].x, As[buf][kq + 1][r0] = src[0].y, As[buf][kq + 2][r0] = src[0].z, As[buf][kq + 3][r0] = src[0].w;
+        if (NF == 2)
+            As[buf][kq + 4][r0] = src[1].x, As[buf][kq + 5][r0] = src[1].y, As[buf][kq + 6][r0] = src[1].z, As[buf][kq + 7][r0] = src[1].w;
     };
     auto advance = [&](int& tile, int& kc) {
         if (++kc == NCH) kc = 0, tile += gridDim.x;
@@ -124,8 +128,15 @@ __global__ __launch_bounds__(512, 2) void pwg_stage_kernel(PwgArgs a) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const float a0 = As[buf][kk * 2 + lk][wm + lr], a1 = As[buf][kk * 2 + lk][wm + 32 + lr];
-            const float* wr = Wt + (kc * BK + kk * 2 + lk) * 128 + wn + lr;
-            const float b0 = wr[0], b1 = wr[32];
+            const int kg = kc * BK + kk * 2 + lk;
+            float b0, b1;
+            if (K > KL && kc * BK >= KL) {      // (uniform) weight rows that did not fit the LDS: L1 / L2 hits
+                const float* wr = a.wt + kg * 128 + wn + lr;
+                b0 = wr[0], b1 = wr[32];
+            } else {
+                const float* wr = Wt + kg * 128 + wn + lr;
+                b0 = wr[0], b1 = wr[32];
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void pwg_stage_kernel(PwgArgs a) {
         store_chunk(P0, buf ^ 1);
         __syncthreads();
         buf ^= 1;
-        P0[0] = P1[0];
+        P0[0] = P1[0], P0[1] = P1[1];
         tile = t1, kc = k1;
         t1 = t2, k1 = k2;
     }
@@ -190,7 +201,7 @@ extern "C" int a3t_pwg_block(float* x, const float* cu, const float* wt0, const 
     a.x_in = x, a.cu = cu, a.gin = g, a.g = g, a.x_out = x, a.skips = skips;
     a.B = B, a.Tw = Tw, a.dil = dil, a.tiles_t = (Tw + 255) / 256;
     const int ntiles = B * a.tiles_t;
-    constexpr int lds0 = (272 * 128 + 2 * 8 * 260) * 4, lds1 = (64 * 128 + 2 * 8 * 260) * 4;
+    constexpr int lds0 = (272 * 128 + 2 * 8 * 260) * 4, lds1 = (64 * 128 + 2 * 16 * 260) * 4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)pwg_stage_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds0);
