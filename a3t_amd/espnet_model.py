@@ -118,9 +118,37 @@ class ESPnetMLMEncAsDecoderModel(torch.nn.Module):
 
     def _batch(self, speech, text, masked_position, speech_mask, text_mask, speech_segment_pos, text_segment_pos):
         dev = self.store.device
-        return dict(speech=speech.to(dev, torch.float32), text=text.to(dev), masked_position=masked_position.to(dev),
-                    speech_mask=speech_mask.to(dev), text_mask=text_mask.to(dev),
-                    speech_segment_pos=speech_segment_pos.to(dev), text_segment_pos=text_segment_pos.to(dev))
+        b = dict(speech=speech.to(dev, torch.float32), text=text.to(dev), masked_position=masked_position.to(dev),
+                 speech_mask=speech_mask.to(dev), text_mask=text_mask.to(dev),
+                 speech_segment_pos=speech_segment_pos.to(dev), text_segment_pos=text_segment_pos.to(dev))
+        if self.compute == "bf16":
+            b = self._pad_to_dma_granule(b)
+        return b
+
+    @staticmethod
+    def _pad_to_dma_granule(b):
+        """The bf16 kernels move 16-byte granules, so T_mel and T_mel + T_phn must be multiples of 8.  Real batches are
+        padded to the longest utterance anyway (collate_fn.py:197-214); here the padding is simply extended: extra speech
+        frames are 0 with speech_mask / masked_position False and segment id 0, extra phones are the pad id 0 with
+        text_mask False -- exactly what the reference's collate produces for a batch whose longest utterance is a few
+        frames longer.  (As in the reference, padded positions still enter the BatchNorm statistics.)"""
+        Tm, Tp = b["speech"].shape[1], b["text"].shape[1]
+        pm = (-Tm) % 8
+        pp = (-(Tm + pm + Tp)) % 8
+        if pm == 0 and pp == 0:
+            return b
+        F = torch.nn.functional
+        out = dict(b)
+        if pm:
+            out["speech"] = F.pad(b["speech"], (0, 0, 0, pm))
+            out["masked_position"] = F.pad(b["masked_position"], (0, pm), value=False)
+            out["speech_mask"] = F.pad(b["speech_mask"], (0, pm), value=False)
+            out["speech_segment_pos"] = F.pad(b["speech_segment_pos"], (0, pm), value=0)
+        if pp:
+            out["text"] = F.pad(b["text"], (0, pp), value=0)
+            out["text_mask"] = F.pad(b["text_mask"], (0, pp), value=False)
+            out["text_segment_pos"] = F.pad(b["text_segment_pos"], (0, pp), value=0)
+        return out
 
     def forward(self, speech, text, masked_position, speech_mask, text_mask, speech_segment_pos, text_segment_pos,
                 y_masks=None, speech_lengths=None, text_lengths=None):
@@ -149,5 +177,5 @@ class ESPnetMLMEncAsDecoderModel(torch.nn.Module):
         out = self._engine().forward(batch, need_grad=False)
         zs = out["after"]
         s, e = int(span_boundary[0]), int(span_boundary[1])
-        sp = batch["speech"]
+        sp = batch["speech"][:, :speech.shape[1]]          # (bf16 mode may have extended the padding)
         return dict(feat_gen=[sp[:, :s], zs[0][s:e].clone(), sp[:, e:]])

@@ -432,3 +432,36 @@ def test_c4_shape_family_bf16_tracks_fp32():
     assert bool(torch.isfinite(g16).all())
     assert float(torch.nn.functional.cosine_similarity(g16, g32, dim=0)) > 0.99
     assert abs(float(g16.norm() / g32.norm()) - 1.0) < 0.05
+
+
+def test_plugin_model_bf16_accepts_arbitrary_lengths():
+    """compute='bf16' needs T_mel and T_mel + T_phn to be multiples of 8; the plugin model extends the batch padding
+    itself (masked-out frames / pad phones, as the reference's collate does for a longer batch).  The bf16 model on odd
+    lengths must agree with the fp32 model fed the explicitly padded batch, train and infer."""
+    from a3t_amd.task import MLMTask
+    from a3t_amd.espnet_model import ESPnetMLMEncAsDecoderModel
+    oc = O.A3TConfig(enc_blocks=1, dec_blocks=1)
+    state = O.procedural_state(O.param_shapes(oc), 1)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in state.items()}
+    batch = O.synthetic_batch(oc, B=2, T_mel=203, T_phn=31, seed=11, lengths=[203, 150], text_lengths=[31, 20])
+    m16 = MLMTask.build_model(_task_args(oc), device=DEV, compute="bf16")
+    m16.load_state_dict(sd)
+    m32 = MLMTask.build_model(_task_args(oc), device=DEV, compute="f32")
+    m32.load_state_dict(sd)
+    m16.train(), m32.train()
+    l16, _, w = m16(**batch)
+    l16.backward()
+    padded = ESPnetMLMEncAsDecoderModel._pad_to_dma_granule({k: v.to(DEV) for k, v in batch.items() if k in (
+        "speech", "text", "masked_position", "speech_mask", "text_mask", "speech_segment_pos", "text_segment_pos")})
+    assert padded["speech"].shape[1] == 208 and (208 + padded["text"].shape[1]) % 8 == 0
+    l32, _, _ = m32(**padded)
+    assert abs(float(l16) - float(l32)) < 1e-2 * abs(float(l32)), (float(l16), float(l32))
+    assert bool(torch.isfinite(m16.store.grad).all())
+    m16.load_state_dict(sd), m32.load_state_dict(sd)
+    m16.eval(), m32.eval()
+    b1 = {k: v[:1] for k, v in batch.items()}
+    with torch.no_grad():
+        o16 = m16.inference(**b1, span_boundary=[40, 90], use_teacher_forcing=True)["feat_gen"]
+        o32 = m32.inference(**b1, span_boundary=[40, 90], use_teacher_forcing=True)["feat_gen"]
+    assert o16[0].shape == o32[0].shape and o16[2].shape == o32[2].shape == (1, 203 - 90, oc.odim)
+    np.testing.assert_allclose(o16[1].float().cpu().numpy(), o32[1].cpu().numpy(), atol=0.15, rtol=5e-2)
