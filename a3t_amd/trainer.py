@@ -147,6 +147,9 @@ class A3TTrainer:
         self.step_no += 1
         st = self.store
         st.zero_grad()
+        if self.engine.bf16:           # 16-byte DMA granules: extend the batch padding to T_mel, T % 8 == 0 (no-op if aligned)
+            from .espnet_model import ESPnetMLMEncAsDecoderModel
+            batch = ESPnetMLMEncAsDecoderModel._pad_to_dma_granule(batch)
         out = self.engine.forward(batch, gscale=weight_scale)
         if self.reducer is not None:
             self._backward_overlapped()
