@@ -465,3 +465,26 @@ def test_plugin_model_bf16_accepts_arbitrary_lengths():
         o32 = m32.inference(**b1, span_boundary=[40, 90], use_teacher_forcing=True)["feat_gen"]
     assert o16[0].shape == o32[0].shape and o16[2].shape == o32[2].shape == (1, 203 - 90, oc.odim)
     np.testing.assert_allclose(o16[1].float().cpu().numpy(), o32[1].cpu().numpy(), atol=0.15, rtol=5e-2)
+
+
+def test_training_makes_progress_and_bf16_tracks_fp32_trajectory():
+    """30 optimizer steps (clip + Adam + Noam on the flat buffers) on a fixed batch: the masked-L1 loss must fall
+    substantially and the bf16 trajectory must stay close to the fp32 one (dropout off so both see the same function)."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    from a3t_amd.trainer import A3TTrainer
+    from a3t_amd.collate import synthetic_batch
+    c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=2, postnet_layers=3, postnet_chans=64, vocab=40)
+    batch = synthetic_batch(c, 4, 192, 32, seed=7, device=DEV)
+    traj = {}
+    for compute in ("f32", "bf16"):
+        store = ParamStore(c, DEV)
+        xavier_init_(store, seed=3, bn_gamma=1.0)
+        tr = A3TTrainer(c, store, compute=compute, lr=1.0, warmup_steps=20, grad_clip=1.0, dropout=False)
+        traj[compute] = [float(tr.step(batch)) for _ in range(30)]
+    f, b = traj["f32"], traj["bf16"]
+    assert f[-1] < 0.6 * f[0] and b[-1] < 0.6 * b[0], (f[0], f[-1], b[0], b[-1])
+    assert all(math.isfinite(v) for v in f + b)
+    assert abs(b[0] - f[0]) < 1e-2 * f[0]
+    assert abs(b[-1] - f[-1]) < 0.1 * f[-1], (f[-1], b[-1])
