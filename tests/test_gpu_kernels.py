@@ -508,3 +508,28 @@ def test_relpos_softmax_long_rows_generic_three_pass_path(dt):
     tol = dict(atol=6e-3, rtol=3e-2) if dt == "bf16" else dict(atol=1e-6, rtol=1e-3)
     _close(ds, ac.grad, **tol)
     _close(dbd, bd.grad, **tol)
+
+
+@pytest.mark.parametrize("l2", [False, True])
+@pytest.mark.parametrize("frac", [0.6, 0.0])
+def test_mlm_loss_l1_and_mse_variants(l2, frac):
+    """_calc_mlm_loss (sedit_model.py:320-340): L1 (recipe) or MSE (lsm_weight > 50, :105-108) summed over the 80 bins of
+    the masked frames / (n_masked + 1e-10), before + after terms; frac = 0: no masked frame -> loss 0, zero gradients."""
+    ops = _ops()
+    M, C = 515, 80
+    before = _rand(M, C, seed=1).requires_grad_(True)
+    after = _rand(M, C, seed=2).requires_grad_(True)
+    y = _rand(M, C, seed=3)
+    masked = torch.from_numpy(np.random.RandomState(4).rand(M) < frac)
+    crit = (lambda a, b: (a - b) ** 2) if l2 else (lambda a, b: (a - b).abs())
+    w = masked.float()[:, None]
+    loss = (crit(before, y) * w).sum() / (masked.float().sum() + 1e-10) + (crit(after, y) * w).sum() / (masked.float().sum() + 1e-10)
+    loss.backward()
+    lo = torch.empty(1, device=DEV)
+    db, da = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    scratch = torch.empty(ops.loss_scratch_floats(M), device=DEV)
+    ops.mlm_loss(before.detach().to(DEV), after.detach().to(DEV), y.to(DEV), masked.to(DEV).view(torch.uint8), lo, db, da,
+                 scratch, l2=l2, gscale=1.0)
+    assert abs(float(lo) - float(loss)) < 1e-4 * max(1.0, abs(float(loss)))
+    _close(db, before.grad, atol=1e-7, rtol=1e-4)
+    _close(da, after.grad, atol=1e-7, rtol=1e-4)
