@@ -393,7 +393,8 @@ static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
 
 // returns -1 when the descriptor does not meet the alignment contract of this kernel
 int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t stream) {
-    bool ok = al16(p.A) && al16(p.B) && m8(p.a_bs0) && m8(p.a_bs1) && m8(p.b_bs0) && m8(p.b_bs1) && m8(p.Kc);
+    bool ok = al16(p.A) && al16(p.B) && m8(p.a_bs0) && m8(p.a_bs1) && m8(p.b_bs0) && m8(p.b_bs1);
+    if (AK || BKC) ok = ok && m8(p.Kc);      // (16-byte granules run along k only for k-contiguous operands)
     if (AK)
         ok = ok && m8(p.a_rs) && m8(p.K);
     else
