@@ -540,12 +540,16 @@ def test_gemm_dispatch_randomised_sweep():
     """60 random linear / conv problems (ragged M, N, K, taps 3/5, dilation, batch, every epilogue option) through the
     a3t_gemm dispatcher against fp32 torch math: no call may be rejected and every result must agree to bf16 accuracy;
     the sweep must reach the plain / fast-conv / generic bookkeeping variants of all three layouts."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("gemm_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools",
-                                                                            "gemm_fuzz.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    import fuzz_gemm as mod
     fails, seen = mod.run(seed=3, n_cases=60, verbose=False)
     assert fails == 0
     glds = [k for k in seen if k.startswith("gemm_bf16_glds_kernel")]
     assert len(glds) >= 8, seen
+
+
+def test_row_kernels_randomised_sweep():
+    """75 random problems for the rel-pos softmax (T from 1 to 320 incl. T % 8 != 0, fully / partially padded
+    utterances, fp32 and bf16 storage), LayerNorm (any M, D incl. the 16-byte vector widths) and GLU + depthwise conv
+    (K in 3..31, any C, bf16 vector path and generic path), forward and backward against torch math."""
+    import fuzz_rowkernels as mod
+    assert mod.run(seed=5, n=25, verbose=False) == 0
