@@ -488,3 +488,11 @@ def test_training_makes_progress_and_bf16_tracks_fp32_trajectory():
     assert all(math.isfinite(v) for v in f + b)
     assert abs(b[0] - f[0]) < 1e-2 * f[0]
     assert abs(b[-1] - f[-1]) < 0.1 * f[-1], (f[-1], b[-1])
+
+
+def test_engine_vs_oracle_randomised_architectures():
+    """8 random small architectures (heads 1/2/4, conv-module kernels 3..31, 1-2 + 1-2 blocks, postnet 2-5 layers) on
+    ragged batches: loss, outputs and EVERY parameter gradient of the fp32 HIP engine against the CPU oracle
+    (tests/fuzz_engine.py; `python tests/fuzz_engine.py <seed> <cases>` runs longer sweeps)."""
+    import fuzz_engine as mod
+    assert mod.run(seed=4, n=8, verbose=False) == 0
