@@ -69,6 +69,71 @@ def one_case(rng, verbose=False):
     return len(errs)
 
 
+def one_case_bf16(rng, verbose=False):
+    """bf16 production schedule (two streams, fused epilogues, dropout ON) against the exact-fp32 engine with the same
+    dropout masks, on random mid-size architectures and ragged, 8-aligned batches."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    from a3t_amd.collate import synthetic_batch
+    heads = rng.choice([1, 2, 4])
+    adim = heads * rng.choice([16, 32, 64, 96])
+    c = A3TConfig(adim=adim, heads=heads, ff=64 * rng.randrange(1, 9), enc_blocks=rng.choice([1, 2]),
+                  dec_blocks=rng.choice([1, 2]), enc_kernel=rng.choice([3, 7, 15]), dec_kernel=rng.choice([7, 31]),
+                  postnet_layers=rng.choice([2, 5]), postnet_chans=rng.choice([32, 64, 256]), vocab=rng.randrange(8, 60),
+                  dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
+    B = rng.randrange(1, 5)
+    T_mel = 8 * rng.randrange(4, 40)
+    T_phn = 8 * rng.randrange(1, 6)
+    store = ParamStore(c, DEV)
+    xavier_init_(store, seed=rng.randrange(1000), bn_gamma=1.0)
+    batch = synthetic_batch(c, B, T_mel, T_phn, seed=rng.randrange(1 << 20), device=DEV)
+    if B > 1:                                  # pad the tails of the later utterances
+        for b in range(1, B):
+            L = rng.randrange(T_mel // 2, T_mel + 1)
+            batch["speech_mask"][b, :, L:] = False
+            batch["masked_position"][b, L:] = False
+            batch["speech"][b, L:] = 0
+    res = {}
+    for compute in ("f32", "bf16"):
+        eng = MLMEngine(c, store, compute=compute, training=True, dropout=True)
+        eng.step_seed = 17
+        eng.refresh_weights()
+        store.zero_grad()
+        res[compute] = float(eng.forward(batch)["loss"])
+        eng.backward()
+        torch.cuda.synchronize()
+        res[compute + ".g"] = store.grad.clone()
+    tag = (f"bf16 d{adim} H{heads} ff{c.ff} blocks {c.enc_blocks}+{c.dec_blocks} K{c.enc_kernel}/{c.dec_kernel} "
+           f"post{c.postnet_layers}x{c.postnet_chans} B{B} T{T_mel}+{T_phn}")
+    errs = []
+    if abs(res["bf16"] - res["f32"]) > 1.5e-2 * abs(res["f32"]):
+        errs.append(f"loss {res['bf16']} vs {res['f32']}")
+    cos = float(torch.nn.functional.cosine_similarity(res["bf16.g"], res["f32.g"], dim=0))
+    if not (cos > 0.98) or not bool(torch.isfinite(res["bf16.g"]).all()):
+        errs.append(f"grad cosine {cos}")
+    if errs or verbose:
+        print(("FAIL " if errs else "ok   ") + tag + (f"  (loss {res['bf16']:.4f}/{res['f32']:.4f} cos {cos:.5f})"))
+        for e in errs:
+            print("      " + e)
+    return len(errs)
+
+
+def run_bf16(seed=0, n=10, verbose=True):
+    rng = random.Random(seed)
+    fails = 0
+    for i in range(n):
+        try:
+            fails += 1 if one_case_bf16(rng, verbose) else 0
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print(f"EXC bf16 case {i}: {type(e).__name__}: {e}")
+    if verbose:
+        print(f"{n} bf16 cases, {fails} failures")
+    return fails
+
+
 def run(seed=0, n=10, verbose=True):
     rng = random.Random(seed)
     fails = 0
@@ -84,4 +149,6 @@ def run(seed=0, n=10, verbose=True):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+    _seed, _n = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+    run(_seed, _n)
+    run_bf16(_seed, _n)
