@@ -66,3 +66,62 @@ def test_config_from_espnet_yaml_dicts():
     mc = dict(postnet_layers=5, postnet_chans=256, postnet_filts=5, lsm_weight=0.1, mlm_prob=0.8, mean_phn_span=8)
     c = A3TConfig.from_espnet(enc, dec, mc, input_size=80, odim=80, vocab=73)
     assert (c.enc_kernel, c.dec_kernel, c.ff, c.dk) == (7, 31, 1536, 192)
+
+
+def test_host_index_logic_randomised_against_oracle():
+    """300 random alignments / batch shapes / mask settings: the product's vectorised host index work
+    (a3t_amd.collate: align_to_frames, random_spans_noise_mask, phones_masking, get_segment_pos) must be BIT-EXACT with
+    the oracle's loop-level restatement of collate_fn.py under the same numpy RNG state, and leave the RNG in the same
+    state (the global numpy RNG order is part of the contract)."""
+    import random
+    import torch
+    from a3t_amd import collate as C
+    from oracle import a3t_oracle as O
+    rng = random.Random(0)
+    for case in range(300):
+        B = rng.randrange(1, 5)
+        T_mel = rng.randrange(4, 200)
+        P = rng.randrange(1, min(30, T_mel - 1) + 1)
+        a_s = np.zeros((B, P), dtype=np.int32)
+        a_e = np.zeros((B, P), dtype=np.int32)
+        lens, nonpad = [], np.zeros((B, T_mel), dtype=bool)
+        for b in range(B):
+            L = rng.randrange(max(2, P), T_mel + 1) if b else T_mel
+            pb = rng.randrange(1, P + 1) if b else P
+            cuts = sorted(rng.sample(range(1, L), pb - 1)) if pb > 1 else []
+            bounds = [0] + cuts + [L]
+            a_s[b, :pb], a_e[b, :pb] = bounds[:-1], bounds[1:]
+            lens.append(pb)
+            nonpad[b, :L] = True
+        # (prob, mean span) pairs inside the domain of the reference's T5 segmentation helper: it needs
+        #  n_spans <= min(n_noise, n_non_noise) and raises otherwise, e.g. for prob 0.8 with span 3)
+        prob, span = rng.choice([(0.15, 3), (0.15, 8), (0.5, 3), (0.5, 8), (0.8, 8), (1.0, 3), (1.0, 0), (0.8, 0), (0.5, 0)])
+        if span == 0 and T_mel < 24:
+            span = 8
+        sb = None
+        if rng.random() < 0.2:
+            s0 = rng.randrange(0, T_mel - 1)
+            sb = np.array([[s0, rng.randrange(s0 + 1, T_mel + 1)]] * B)
+        seed = rng.randrange(1 << 30)
+        np.random.seed(seed)
+        ref = O.phones_masking(T_mel, nonpad, a_s, a_e, lens, prob, span, sb)
+        st_ref = np.random.get_state()[1].copy()
+        np.random.seed(seed)
+        got = C.phones_masking(T_mel, nonpad, a_s, a_e, lens, prob, span, sb)
+        st_got = np.random.get_state()[1].copy()
+        assert np.array_equal(got, ref), (case, B, T_mel, P, prob, span)
+        assert np.array_equal(st_got, st_ref), case
+        sp_r, tp_r = O.get_segment_pos(T_mel, P, a_s, a_e, lens, True)
+        sp_g, tp_g = C.get_segment_pos(T_mel, P, a_s, a_e, lens, True)
+        assert np.array_equal(sp_g, sp_r) and np.array_equal(tp_g, tp_r), case
+        # seconds -> frames, incl. stamps sitting exactly on frame boundaries
+        sec = np.array([rng.choice([k * 300 / 24000, k * 300 / 24000 + 1e-4, rng.random() * 12.5]) for k in range(1, 40)],
+                       dtype=np.float32)
+        assert np.array_equal(C.align_to_frames(sec, 24000, 300), O.align_to_frames(torch.from_numpy(sec), 24000, 300).numpy())
+        Ln = rng.randrange(2, 400)
+        np.random.seed(seed)
+        pr2, sp2 = (prob, span) if (prob < 1.0 and span > 0) else (0.8, 8)
+        m_r = O.random_spans_noise_mask(Ln, pr2, sp2)
+        np.random.seed(seed)
+        m_g = C.random_spans_noise_mask(Ln, pr2, sp2)
+        assert np.array_equal(m_g, m_r), (case, Ln)
