@@ -11,7 +11,10 @@ Pinning status
 * Everything except the mel filter matrix is pinned against the reference's own
   Python implementation, imported in the build container by
   ``tests/golden/make_golden.py``; the resulting vectors live in ``tests/golden``
-  and ``tests/test_oracle_golden.py`` checks this file against them.
+  and ``tests/test_oracle_golden.py`` checks this file against them.  The same
+  script's ``--sweep`` mode compared this file with the imported reference on
+  1000 random index cases (bit-exact) and 60 random architectures (loss and all
+  gradients); the record is ``tests/golden/sweep_report.json``.
 * ``slaney_mel`` restates librosa>=0.8 ``filters.mel`` (un-vendored, un-pinned
   dependency of the reference: ``setup.py:32``, call site
   ``espnet2/layers/log_mel.py:49``).  librosa is not installed and there is no

@@ -367,15 +367,136 @@ def gen_pwg(out):
     print("pwg.npz", wav.shape, float(wav.abs().mean()))
 
 
+def sweep(out, n_masks, n_models):
+    """Randomised pinning of the ORACLE to the REFERENCE (container only; the fixed goldens above are what travels).
+
+    * index work: random batch shapes / alignments / mask settings -> the reference's collate_fn.phones_masking and
+      get_segment_pos vs the oracle's, bit-exact, plus the numpy global RNG state left behind;
+    * numerics: random small architectures (width, heads, FFN, block counts, conv-module kernels, postnet) and ragged
+      batches -> the reference model's loss, outputs and EVERY parameter gradient vs the oracle's (fp32, dropout 0).
+    Writes sweep_report.json (counts, worst errors, seed) next to the fixtures."""
+    import json
+    import random
+    import torch
+    from espnet2.train.collate_fn import phones_masking, get_segment_pos, random_spans_noise_mask
+    from oracle import a3t_oracle as O
+
+    rng = random.Random(20260928)
+    rep = dict(seed=20260928, mask_cases=0, mask_mismatches=0, rsnm_cases=0, model_cases=0, model_mismatches=0,
+               worst_loss_rel=0.0, worst_grad_rel=0.0)
+    for case in range(n_masks):
+        B = rng.randrange(1, 5)
+        T = rng.randrange(4, 200)
+        P = rng.randrange(1, min(30, T - 1) + 1)
+        a_s = np.zeros((B, P), np.int32)
+        a_e = np.zeros((B, P), np.int32)
+        lens, nonpad = [], np.zeros((B, T), bool)
+        for b in range(B):
+            L = rng.randrange(max(2, P), T + 1) if b else T
+            pb = rng.randrange(1, P + 1) if b else P
+            cuts = sorted(rng.sample(range(1, L), pb - 1)) if pb > 1 else []
+            bd = [0] + cuts + [L]
+            a_s[b, :pb], a_e[b, :pb] = bd[:-1], bd[1:]
+            lens.append(pb)
+            nonpad[b, :L] = True
+        prob, span = rng.choice([(0.15, 3), (0.15, 8), (0.5, 3), (0.5, 8), (0.8, 8), (1.0, 3), (1.0, 0), (0.8, 0),
+                                 (0.5, 0)])
+        if span == 0 and T < 24:
+            span = 8
+        sb = None
+        if rng.random() < 0.2:
+            s0 = rng.randrange(0, T - 1)
+            sb = np.array([[s0, rng.randrange(s0 + 1, T + 1)]] * B)
+        seed = rng.randrange(1 << 30)
+        xs = torch.zeros(B, T, 80)
+        np.random.seed(seed)
+        mp, _ = phones_masking(xs, torch.from_numpy(nonpad)[:, None], torch.from_numpy(a_s), torch.from_numpy(a_e),
+                               torch.tensor(lens), prob, span, None if sb is None else torch.from_numpy(sb))
+        st_ref = np.random.get_state()[1].copy()
+        sp, tp = get_segment_pos(xs, torch.zeros(B, P, dtype=torch.long), torch.from_numpy(a_s),
+                                 torch.from_numpy(a_e), torch.tensor(lens), True)
+        np.random.seed(seed)
+        got = O.phones_masking(T, nonpad, a_s, a_e, lens, prob, span, sb)
+        st_got = np.random.get_state()[1].copy()
+        sp_o, tp_o = O.get_segment_pos(T, P, a_s, a_e, lens, True)
+        ok = (np.array_equal(np.asarray(got), mp.numpy()) and np.array_equal(st_ref, st_got)
+              and np.array_equal(np.asarray(sp_o), sp.numpy()) and np.array_equal(np.asarray(tp_o), tp.numpy()))
+        rep["mask_cases"] += 1
+        if not ok:
+            rep["mask_mismatches"] += 1
+            print("MASK MISMATCH", case, B, T, P, prob, span, sb)
+        Ln = rng.randrange(2, 400)
+        pr2, sp2 = (prob, span) if (prob < 1.0 and span > 0) else (0.8, 8)
+        np.random.seed(seed)
+        r = random_spans_noise_mask(Ln, pr2, sp2)
+        np.random.seed(seed)
+        o = O.random_spans_noise_mask(Ln, pr2, sp2)
+        rep["rsnm_cases"] += 1
+        if not np.array_equal(np.asarray(r), np.asarray(o)):
+            rep["mask_mismatches"] += 1
+            print("RSNM MISMATCH", case, Ln, pr2, sp2)
+    for case in range(n_models):
+        heads = rng.choice([1, 2, 4])
+        adim = heads * rng.choice([8, 16, 24])
+        oc = O.A3TConfig(adim=adim, heads=heads, ff=rng.choice([24, 48, 64]), enc_blocks=rng.choice([1, 2]),
+                         dec_blocks=rng.choice([1, 2]), enc_kernel=rng.choice([3, 7, 15]),
+                         dec_kernel=rng.choice([7, 31]), postnet_layers=rng.choice([2, 3, 5]),
+                         postnet_chans=rng.choice([16, 24]), vocab=rng.randrange(8, 40))
+        B = rng.randrange(1, 4)
+        T_mel, T_phn = rng.randrange(24, 90), rng.randrange(3, 12)
+        lengths = [T_mel] + [rng.randrange(max(T_phn + 2, T_mel // 2), T_mel + 1) for _ in range(B - 1)]
+        tlens = [T_phn] + [rng.randrange(2, T_phn + 1) for _ in range(B - 1)]
+        seed = rng.randrange(1 << 20)
+        batch = O.synthetic_batch(oc, B, T_mel, T_phn, seed=seed, lengths=lengths, text_lengths=tlens)
+        model, _ = build_ref_model(oc, oc.vocab)
+        state = load_procedural(model, oc, seed % 97)
+        train_bn = rng.random() < 0.8
+        model.train() if train_bn else model.eval()
+        model.zero_grad()
+        loss_r, _ = run_model(model, batch)
+        loss_r.backward()
+        p = O.to_torch_state(state, requires_grad=True)
+        loss_o, before, after = O.forward_loss(p, batch, oc, train_bn)
+        loss_o.backward()
+        lrel = abs(float(loss_o.detach()) - float(loss_r.detach())) / max(abs(float(loss_r.detach())), 1e-12)
+        worst = 0.0
+        # gradients that are mathematically zero (a conv bias feeding train-mode BatchNorm) are rounding noise on
+        # both sides: judge them against the model's largest gradient norm instead of their own
+        gmax = max(float(q.grad.norm()) for q in model.parameters() if q.grad is not None)
+        for n, q in model.named_parameters():
+            g_o = p[n].grad
+            if g_o is None:
+                g_o = torch.zeros_like(q)
+            g_r = q.grad if q.grad is not None else torch.zeros_like(q)
+            den = max(float(g_r.norm()), 1e-3 * gmax)
+            e = float((g_o - g_r).norm()) / den
+            if e > worst:
+                worst, worst_name = e, (n, float(g_r.norm()), float(g_o.norm()))
+        rep["model_cases"] += 1
+        rep["worst_loss_rel"] = max(rep["worst_loss_rel"], lrel)
+        rep["worst_grad_rel"] = max(rep["worst_grad_rel"], worst)
+        if lrel > 1e-5 or worst > 2e-4:
+            rep["model_mismatches"] += 1
+            print("MODEL MISMATCH", case, vars(oc), B, lengths, tlens, lrel, worst, worst_name)
+    rep["criteria"] = dict(index="bit-exact incl. numpy RNG state", loss_rel=1e-5, grad_rel_l2=2e-4)
+    json.dump(rep, open(os.path.join(out, "sweep_report.json"), "w"), indent=1)
+    print("sweep_report.json", rep)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--sweep", type=int, nargs=2, default=None, metavar=("N_MASKS", "N_MODELS"),
+                    help="randomised oracle-vs-reference sweep instead of regenerating the fixtures")
     a = ap.parse_args()
     install_stubs()
     import torch
 
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if a.sweep:
+        sweep(HERE, *a.sweep)
+        sys.exit(0)
     todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg)
     for k, f in todo.items():
         if a.only and k not in a.only.split(","):

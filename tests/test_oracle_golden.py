@@ -214,3 +214,14 @@ def test_noam_and_adam_against_torch():
         for a, b in zip(ps, ref):
             np.testing.assert_allclose(a.numpy(), b.detach().numpy(), atol=1e-6, rtol=1e-5)
     assert abs(O.noam_lr(1, 1.0, 384, 4000) - 384 ** -0.5 * 4000 ** -1.5) < 1e-12
+
+
+def test_reference_sweep_record():
+    """tests/golden/make_golden.py --sweep (container only: it imports the reference) compared this oracle with the
+    reference on random cases; the committed record must show a non-trivial sweep with zero mismatches."""
+    import json
+    rep = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sweep_report.json")))
+    assert rep["mask_cases"] >= 1000 and rep["model_cases"] >= 50
+    assert rep["mask_mismatches"] == 0 and rep["model_mismatches"] == 0
+    assert rep["worst_loss_rel"] <= rep["criteria"]["loss_rel"]
+    assert rep["worst_grad_rel"] <= rep["criteria"]["grad_rel_l2"]
