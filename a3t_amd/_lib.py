@@ -31,9 +31,9 @@ class GemmDesc(ctypes.Structure):
         ("alpha", c_float),
         ("act", c_int32), ("accumulate", c_int32), ("splitk", c_int32),
         ("a_dtype", c_int32), ("b_dtype", c_int32), ("c_dtype", c_int32), ("compute", c_int32),
-        ("s_dtype", c_int32), ("reserved", c_int32),
+        ("s_dtype", c_int32), ("colsum_slots", c_int32),
         ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("drop_key", ctypes.c_uint32),
-        ("drop_p", c_float), ("reserved3", c_int32),
+        ("drop_p", c_float), ("colsum_ss", c_int32),
     ]
 
 
@@ -64,6 +64,7 @@ _SIGS = {
                              ctypes.c_uint32, _P],
     "a3t_scale": [_P, _P, c_int64, c_float, _P],
     "a3t_axpy": [_P, _P, c_int64, c_float, _P],
+    "a3t_attn_bias_fold": [_P, c_int32, c_int32, _P, _P, _P, _P],
     "a3t_scale_dev": [_P, _P, c_int64, _P, _P],
     "a3t_slice_rows": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "a3t_cast_bf16": [_P, _P, c_int64, _P],

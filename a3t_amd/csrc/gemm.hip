@@ -459,6 +459,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.s_dtype = d->s_dtype;
     p.epi_vec = 0;
     p.colsum = d->colsum, p.colsum_bs1 = d->colsum_bs1, p.colsum_scale = d->colsum_scale;
+    p.colsum_slots = d->colsum_slots > 1 ? d->colsum_slots : 1, p.colsum_ss = d->colsum_ss;
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return A3T_EINVAL;
     p.drop_key = d->drop_key;
     p.drop_thr = (unsigned int)((double)d->drop_p * 4294967296.0);

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/a3t_hip.h"
 #include "gemm_common.h"
 
@@ -39,19 +40,22 @@ enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 // single-buffer variant under 128 VGPRs -> 4 workgroups per CU (1024 slots: the 840-tile N = 384 GEMMs run in one round)
 // CONV = 1: conv / data-gradient GEMM whose channel count is a multiple of BK (one tap per K-tile, uniform tracking only);
 // CONV = 2: generic per-lane (tap, channel) tracking, fused conv weight gradient, token-shifted weight gradient.
-template <int LAYOUT, int STAGES, int WM, int CONV>
-__global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGES == 2 ? 2 : (CONV == 2 ? 3 : 4)))) void gemm_bf16_glds_kernel(GP p) {
+// WN = 2: 128 output columns per tile; WN = 3: 192 (each wave 64x96 = 2x3 accumulators, 3 workgroups per CU) for
+// N = 192 operands (attention PV / dV / dK / d(q+v) with d_k = 192): no half-empty second column tile, the A operand
+// (the T x T probabilities) is read once instead of twice.
+template <int LAYOUT, int STAGES, int WM, int CONV, int WN = 2>
+__global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGES == 2 ? 2 : (CONV == 2 ? 3 : 4)))) void gemm_bf16_glds_kernel(GP p) {
     const int TAPS = CONV ? p.taps : 1;
     const int KSM = CONV ? p.kshift_mode : 0;
     constexpr int NW = 2 * WM;                 // waves
-    constexpr int BM = 64 * WM, BN = 128, BK = 64;
+    constexpr int BM = 64 * WM, BN = 64 * WN, BK = 64;
     constexpr bool A_KC = (LAYOUT != L_TN), B_KC = (LAYOUT == L_NT);
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int NA = 4;                      // A DMA instructions per wave per tile (BM*128 B / 1 KiB / NW)
-    constexpr int NB = 8 / WM;                 // B DMA instructions per wave per tile
+    constexpr int NB = (BN / 8) / NW;          // B DMA instructions per wave per tile
     // row-contiguous images: one k-row = (rows*2) bytes; a 1-KiB DMA instruction covers KPI k-rows
     constexpr int A_LPR = BM / 8, A_KPI = 64 / A_LPR;   // lanes per k-row, k-rows per instruction
-    constexpr int B_LPR = BN / 8, B_KPI = 64 / B_LPR;
+    constexpr int B_LPR = BN / 8;                       // (24 for the 192-column image: 2.67 k-rows per instruction)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [STAGES][A image | B image]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -135,8 +139,12 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
             b_row[q] = B + (int64_t)n * p.b_rs;
             b_sw[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         } else {
-            int kr = g * B_KPI + lane / B_LPR;
-            int col = tn * BN + (((lane % B_LPR) ^ ((kr & 3) << 2)) * 8);
+            const int o16 = g * 64 + lane;              // 16-byte slot of this lane in the lane-linear image
+            int kr = o16 / B_LPR, cpos = o16 % B_LPR;
+            // 256-B k-rows: XOR swizzle; 384-B k-rows (natural 128-B stagger): rotate k-rows 2,3 (mod 4) by 64 B
+            int csrc = (B_LPR == 16) ? (cpos ^ ((kr & 3) << 2)) : (cpos - 4 * ((kr >> 1) & 1));
+            if (B_LPR != 16 && csrc < 0) csrc += B_LPR;
+            int col = tn * BN + csrc * 8;
             b_ok[q] = col < p.N;
             b_row[q] = B + col;
             b_sw[q] = kr;
@@ -259,15 +267,15 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][WN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64, lr = lane & 31, lk = lane >> 5;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * (32 * WN), lr = lane & 31, lk = lane >> 5;
     auto frag_kc = [&](const unsigned char* img, int row, int kk) -> bf16x8 {
         int kc = kk * 2 + lk;
         return *(const bf16x8*)(img + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
@@ -278,8 +286,16 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
         const int col = row0 + (g & 1) * 16 + (pp & 3) * 4;
         const int kb = kk * 16 + (g >> 1) * 8 + (pp >> 2);
         const int k1 = kb + 4;
-        const unsigned char* a0 = img + kb * rowbytes + ((((col >> 3) ^ ((kb & 3) << 2))) << 4) + (col & 7) * 2;
-        const unsigned char* a1 = img + k1 * rowbytes + ((((col >> 3) ^ ((k1 & 3) << 2))) << 4) + (col & 7) * 2;
+        int p0, p1;
+        if (rowbytes == 256) {
+            p0 = (col >> 3) ^ ((kb & 3) << 2), p1 = (col >> 3) ^ ((k1 & 3) << 2);
+        } else {   // 384-byte k-rows (kb and kb + 4 get the same rotation)
+            p0 = (col >> 3) + 4 * ((kb >> 1) & 1);
+            p0 = p0 >= 24 ? p0 - 24 : p0;
+            p1 = p0;
+        }
+        const unsigned char* a0 = img + kb * rowbytes + (p0 << 4) + (col & 7) * 2;
+        const unsigned char* a1 = img + k1 * rowbytes + (p1 << 4) + (col & 7) * 2;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a1));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
         const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 a0, a1, b0, b1;
+            bf16x8 a0, a1, bq[WN];
             if (A_KC) {
                 a0 = frag_kc(sA, wm + lr, kk);
                 a1 = frag_kc(sA, wm + 32 + lr, kk);
@@ -307,25 +323,22 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
                 a0 = frag_rc(sA, BM * 2, wm, kk);
                 a1 = frag_rc(sA, BM * 2, wm + 32, kk);
             }
-            if (B_KC) {
-                b0 = frag_kc(sB, wn + lr, kk);
-                b1 = frag_kc(sB, wn + 32 + lr, kk);
-            } else {
-                b0 = frag_rc(sB, BN * 2, wn, kk);
-                b1 = frag_rc(sB, BN * 2, wn + 32, kk);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bq[j] = B_KC ? frag_kc(sB, wn + 32 * j + lr, kk) : frag_rc(sB, BN * 2, wn + 32 * j, kk);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[j], acc[1][j], 0, 0, 0);
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (STAGES == 2) stage ^= 1;
     }
-    if (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC) {   // coalesced 128-B atomic rows straight from the accumulators
+    // (WN = 3 is dispatched with the vector epilogue only: host contract)
+    if (WN == 2 && (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC)) {   // coalesced 128-B atomic rows straight from the accumulators
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int row = tm * BM + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -334,45 +347,51 @@ __global__ __launch_bounds__(128 * WM, (WM == 4 ? (STAGES == 2 ? 2 : 4) : (STAGE
                 }
         return;
     }
-    // Stage each wave's 64x64 fp32 sub-tile through its own slice of the (now idle) LDS, RP rows per pass,
-    // so that every lane finishes 4 consecutive columns: bias / residual / mask reads and the output
-    // stores become 16-byte (8-byte for bf16) accesses, 256 B contiguous per output row segment.
-    constexpr int LDS_PER_WAVE = STAGES * STAGE_BYTES / NW;            // 8/16 KiB (WM=2), 6/12 KiB (WM=4)
-    constexpr int RP = LDS_PER_WAVE >= 16384 ? 64 : (LDS_PER_WAVE >= 8192 ? 32 : 16);   // rows per pass
-    constexpr int NPASS = 64 / RP;
+    // Stage each wave's fp32 sub-tile through its own slice of the (now idle) LDS in panels of 64 (or 32) columns,
+    // RP rows per pass, so that every lane finishes 4 consecutive columns: bias / residual / mask reads and the
+    // output stores become 16-byte (8-byte for bf16) accesses, 256 B (128 B) contiguous per output row segment.
+    constexpr int LDS_PER_WAVE = STAGES * STAGE_BYTES / NW;            // 8/16 KiB (BN = 128), 10/20 KiB (BN = 192)
     __syncthreads();
     float* ct = (float*)(smem + w * LDS_PER_WAVE);
     // (only this wave reads its region back; a wave is lock-step, LDS ops are issued in order)
-    const int c4 = (lane & 15) * 4, r4 = lane >> 4;
-    const int col = tn * BN + wn + c4;
-    const bool col_ok = col < p.N;
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && ks == 0 && col_ok) bias4 = *(const float4*)(p.bias + col);
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto panel = [&](auto njc, auto j0c) {
+        constexpr int NJ = decltype(njc)::value, J0 = decltype(j0c)::value;
+        constexpr int PC = 32 * NJ, LR = PC / 4, RPI = 64 / LR;        // panel columns, lanes per row, rows per sweep
+        constexpr int RP = LDS_PER_WAVE / (PC * 4) >= 64 ? 64 : (LDS_PER_WAVE / (PC * 4) >= 32 ? 32 : 16);   // rows per pass
+        constexpr int NPASS = 64 / RP;
+        const int c4 = (lane % LR) * 4, r4 = lane / LR;
+        const int col = tn * BN + wn + J0 * 32 + c4;
+        const bool col_ok = col < p.N;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && ks == 0 && col_ok) bias4 = *(const float4*)(p.bias + col);
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-        // rows [ps*RP, ps*RP+RP) of the wave tile: MFMA block i = row/32, registers with (r>>2) in the pass
+        for (int ps = 0; ps < NPASS; ++ps) {
+            // rows [ps*RP, ps*RP+RP) of the wave tile: MFMA block i = row/32, registers with (r>>2) in the pass
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lrow = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;   // row inside the wave tile
-                    // (the row range test only depends on i and r>>2: resolved at compile time per register)
-                    if ((i * 32 + 8 * (r >> 2)) / RP == ps) ct[(lrow - ps * RP) * 64 + j * 32 + lr] = acc[i][j][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int lrow = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;   // row inside the wave tile
+                        // (the row range test only depends on i and r>>2: resolved at compile time per register)
+                        if ((i * 32 + 8 * (r >> 2)) / RP == ps) ct[(lrow - ps * RP) * PC + j * 32 + lr] = acc[i][J0 + j][r];
+                    }
 #pragma unroll 4
-        for (int it = 0; it < RP / 4; ++it) {
-            const int srow = it * 4 + r4;
-            const int row = tm * BM + wm + ps * RP + srow;
-            if (row >= p.M || !col_ok) continue;
-            float4 v = *(const float4*)(ct + srow * 64 + c4);
-            const int64_t idx = zoff + (int64_t)row * p.c_rs + col;
-            epilogue_vec4(p, v, idx, bias4, ks, cs);
+            for (int it = 0; it < RP / RPI; ++it) {
+                const int srow = it * RPI + r4;
+                const int row = tm * BM + wm + ps * RP + srow;
+                if (row >= p.M || !col_ok) continue;
+                float4 v = *(const float4*)(ct + srow * PC + c4);
+                const int64_t idx = zoff + (int64_t)row * p.c_rs + col;
+                epilogue_vec4(p, v, idx, bias4, ks, cs);
+            }
         }
-    }
-    if (p.colsum) colsum_flush(p, cs, lane, col_ok, z1, col);
+        if (p.colsum) colsum_flush<LR>(p, cs, lane, col_ok, z1, col, tm + z0);
+    };
+    panel(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    if (WN == 3) panel(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
 }
 
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
@@ -380,15 +399,15 @@ static inline bool m8(int64_t v) { return (v % 8) == 0; }
 
 int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_t256.hip
 
-template <int LY, int ST, int WM, int CV>
+template <int LY, int ST, int WM, int CV, int WN = 2>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
-    constexpr int lds = ST * (64 * WM + 128) * 64 * 2;
+    constexpr int lds = ST * (64 * WM + 64 * WN) * 64 * 2;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<LY, ST, WM, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<LY, ST, WM, CV, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, ST, WM, CV>), grid, dim3(128 * WM), lds, stream, pv);
+    hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, ST, WM, CV, WN>), grid, dim3(128 * WM), lds, stream, pv);
 }
 
 // returns -1 when the descriptor does not meet the alignment contract of this kernel
@@ -426,19 +445,38 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     // 25 % fewer DMA bytes per flop but halves the co-resident workgroups; it lost 5-40 % on every shape but one and
     // that one is now faster on the 4-per-CU 128-row variant, so only WM = 2 is instantiated.)
     constexpr int wm = 2;
-    const long tiles = (long)p.tiles_n * ((p.M + 127) / 128) * batch * p.splitk;
-    const int stages = forced_st ? forced_st : (tiles >= 768 ? 1 : 2);
-    const int tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
-    pv.ntiles = p.tiles_n * tiles_m;
-    dim3 grid((unsigned)((long)pv.ntiles * batch * p.splitk));
     const int ly = (AK && BKC) ? L_NT : (AK ? L_NN : L_TN);
     int conv = 0;
     if (p.taps > 1 || p.kshift_mode)
         conv = (p.taps > 1 && ly != L_TN && p.Kc % 64 == 0 && p.K % 64 == 0 && (ly != L_NT || p.b_ts == p.Kc)) ? 1 : 2;
+    // 192-column tiles when they waste clearly fewer padded columns than 128-column tiles (N = 192: 0 vs 33 %)
+    static int wn_mode = -1;
+    if (wn_mode < 0) {
+        const char* e = getenv("A3T_GEMM_WN3");
+        wn_mode = e ? (e[0] == '0' ? 0 : 2) : 1;
+    }
+    const long pad128 = (long)((p.N + 127) / 128) * 128, pad192 = (long)((p.N + 191) / 192) * 192;
+    const bool wn3 = conv == 0 && pv.epi_vec && p.accumulate != A3T_ACC_ATOMIC && wn_mode != 0 && (wn_mode == 2 || pad192 * 10 <= pad128 * 8);
+    pv.tiles_n = wn3 ? (p.N + 191) / 192 : (p.N + 127) / 128;
+    const int tiles_m = (p.M + 64 * wm - 1) / (64 * wm);
+    const long tiles = (long)pv.tiles_n * tiles_m * batch * p.splitk;
+    const int stages = forced_st ? forced_st : (tiles >= (wn3 ? 512 : 768) ? 1 : 2);
+    pv.ntiles = pv.tiles_n * tiles_m;
+    dim3 grid((unsigned)((long)pv.ntiles * batch * p.splitk));
+    if (wn3) {
+#define V3(LY, ST)                                             \
+    if (ly == LY && stages == ST) {                            \
+        launch_variant<LY, ST, 2, 0, 3>(pv, grid, stream);     \
+        a3t_note_kernel("gemm_bf16_glds_kernel<%d, %d, 2, 0, 3>", LY, ST); \
+        return (int)hipGetLastError();                         \
+    }
+        V3(L_NT, 1) V3(L_NT, 2) V3(L_NN, 1) V3(L_NN, 2) V3(L_TN, 1) V3(L_TN, 2)
+#undef V3
+    }
 #define V(LY, ST, WM_, CV)                                   \
     if (ly == LY && stages == ST && wm == WM_ && conv == CV) { \
         launch_variant<LY, ST, WM_, CV>(pv, grid, stream);     \
-        a3t_note_kernel("gemm_bf16_glds_kernel<%d, %d, %d, %d>", LY, ST, WM_, CV); \
+        a3t_note_kernel("gemm_bf16_glds_kernel<%d, %d, %d, %d, 2>", LY, ST, WM_, CV); \
         return (int)hipGetLastError();                         \
     }
     V(L_NT, 1, 2, 0) V(L_NT, 2, 2, 0) V(L_NT, 1, 2, 1) V(L_NT, 2, 2, 1) V(L_NT, 1, 2, 2) V(L_NT, 2, 2, 2)

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(GP p) {
             epilogue_vec4(p, v, idx, bias4, ks, cs);
         }
     }
-    if (p.colsum) colsum_flush(p, cs, lane, col_ok, z1, col);
+    if (p.colsum) colsum_flush(p, cs, lane, col_ok, z1, col, tm + z0);
     TSTAMP(4);
 #ifdef T256_TIMING
     if (tid == 0) {

@@ -27,6 +27,7 @@ struct GP {
     float* colsum;
     int64_t colsum_bs1;
     float colsum_scale;
+    int colsum_slots, colsum_ss;   // >1: atomics spread over `slots` accumulator copies, `ss` floats apart
     unsigned int drop_key, drop_thr;
     float drop_inv;   // 1/(1-p), 0 when dropout is off
 };
@@ -158,14 +159,17 @@ __device__ __forceinline__ void epilogue_vec4(const GP& p, float4 v, int64_t idx
         }
     }
 }
-// lanes l, l+16, l+32, l+48 of a wave hold the same 4 columns (different rows): reduce, then one atomic per column
-__device__ __forceinline__ void colsum_flush(const GP& p, float4 cs, int lane, bool col_ok, int z1, int col) {
-    cs.x += __shfl_xor(cs.x, 16, 64), cs.y += __shfl_xor(cs.y, 16, 64);
-    cs.z += __shfl_xor(cs.z, 16, 64), cs.w += __shfl_xor(cs.w, 16, 64);
-    cs.x += __shfl_xor(cs.x, 32, 64), cs.y += __shfl_xor(cs.y, 32, 64);
-    cs.z += __shfl_xor(cs.z, 32, 64), cs.w += __shfl_xor(cs.w, 32, 64);
-    if (lane < 16 && col_ok) {
+// lanes l, l+LR, l+2*LR, ... of a wave hold the same 4 columns (different rows): reduce, then one atomic per column
+template <int LR = 16>
+__device__ __forceinline__ void colsum_flush(const GP& p, float4 cs, int lane, bool col_ok, int z1, int col, int spread = 0) {
+#pragma unroll
+    for (int o = LR; o < 64; o <<= 1) {
+        cs.x += __shfl_xor(cs.x, o, 64), cs.y += __shfl_xor(cs.y, o, 64);
+        cs.z += __shfl_xor(cs.z, o, 64), cs.w += __shfl_xor(cs.w, o, 64);
+    }
+    if (lane < LR && col_ok) {
         float* o = p.colsum + z1 * p.colsum_bs1 + col;
+        if (p.colsum_slots > 1) o += (int64_t)(spread % p.colsum_slots) * p.colsum_ss;
         atomicAdd(o + 0, p.colsum_scale * cs.x), atomicAdd(o + 1, p.colsum_scale * cs.y);
         atomicAdd(o + 2, p.colsum_scale * cs.z), atomicAdd(o + 3, p.colsum_scale * cs.w);
     }

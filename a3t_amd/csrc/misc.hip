@@ -127,6 +127,31 @@ extern "C" int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stre
     hipLaunchKernelGGL(axpy_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, a);
     return (int)hipGetLastError();
 }
+// Fold of the slot-spread column sums of the attention data-gradient GEMMs (a3t_gemm_desc::colsum_slots):
+// slots[s][0:d] = colsum(d(q+u)), [d:2d] = colsum(d(q+v)), [2d:3d] = colsum(dK), [3d:4d] = colsum(dV)
+//   -> d pos_bias_u += su, d pos_bias_v += sv, d b_qkv += (su + sv | sk | sV)      (attention.py:190-196: q feeds both)
+__global__ void attn_bias_fold_kernel(const float* __restrict__ slots, int S, int d, float* gu, float* gv, float* gbqkv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * d) return;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += slots[(int64_t)s * 4 * d + i];
+    const int part = i / d, c = i - part * d;
+    if (part == 0) {
+        gu[c] += a;
+        atomicAdd(&gbqkv[c], a);       // (the u and v lanes of one column both add into d b_q)
+    } else if (part == 1) {
+        gv[c] += a;
+        atomicAdd(&gbqkv[c], a);
+    } else {
+        gbqkv[(part - 1) * d + c] += a;
+    }
+}
+extern "C" int a3t_attn_bias_fold(const float* slots, int S, int d, float* gu, float* gv, float* gbqkv, void* stream) {
+    if (S < 1 || d < 1) return A3T_EINVAL;
+    hipLaunchKernelGGL(attn_bias_fold_kernel, dim3((4 * d + 255) / 256), dim3(256), 0, (hipStream_t)stream, slots, S, d, gu,
+                       gv, gbqkv);
+    return (int)hipGetLastError();
+}
 __global__ void cast_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n4) {
     GRID_STRIDE(i, n4) {
         float4 v = ((const float4*)x)[i];

@@ -92,6 +92,7 @@ class MLMEngine:
         self._gm_ready = None
         self._arena = {k: dict(buf=None, used=0, slots={}, dtype=dt) for k, dt in
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
+        self.colsum_slots = int(os.environ.get("A3T_COLSUM_SLOTS", "16"))   # spread of the attention bias-gradient atomics
         self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
@@ -357,10 +358,16 @@ class MLMEngine:
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
         fz = self.bf16   # bias / pos-bias gradients ride on the GEMM epilogues as column sums
         gbq = gr[pre + ".bqkv"]
+        # The four N = d_k GEMMs below run as ONE round of co-resident tiles that all finish together: 576 atomics per
+        # bias column in one burst cost ~40 us per GEMM.  Their column sums are therefore spread over S accumulator
+        # copies (slot = (row tile + utterance) % S; arena slot, zeroed once per backward) and folded by one small kernel.
+        S = self.colsum_slots
+        sl = self._arena_slot("bwd32", tag + ".bsl", S * 4 * d) if fz else None
+        csk = dict(colsum_bs1=dk, colsum_slots=S, colsum_ss=4 * d)
         # (independent of the dprobs -> softmax-backward chain: runs beside it on the side stream)
         self._side(lambda: ops.gemm(pdrop if pdrop is not None else probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                                     batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
-                                    compute=cmp, colsum=gbq[2 * d:] if fz else None, colsum_bs1=dk))
+                                    compute=cmp, colsum=sl[3 * d:] if fz else None, **csk))
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
             dbd = self.ws.get(self._t("tmp.dbd16"), (B, H, T, T), torch.bfloat16)
@@ -383,20 +390,18 @@ class MLMEngine:
         dqv = self._act("tmp.dqv", (M, d))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
         ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=gr[pre + ".u"] if fz else None,
-                 colsum_bs1=dk)
+                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=sl if fz else None, **csk)
         dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
                                               a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
-                                              colsum=gbq[d:] if fz else None, colsum_bs1=dk), want_event=True)
+                                              colsum=sl[2 * d:] if fz else None, **csk), want_event=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
-                 c_bs=(T * d, dk), compute=cmp, colsum=gr[pre + ".v"] if fz else None, colsum_bs1=dk)
+                 c_bs=(T * d, dk), compute=cmp, colsum=sl[d:] if fz else None, **csk)
         if dk_done is not None:      # the dV / dK slices of dqkv come from the side stream
             torch.cuda.current_stream().wait_event(dk_done)
         ops.add_pos_bias_bwd(dqu, dqv, dqkv)
-        if fz:   # d b_q = colsum(dq_u + dq_v) = d u + d v (this layer's u/v gradients are complete here)
-            ops.axpy(gr[pre + ".u"], gbq[:d], 1.0)
-            ops.axpy(gr[pre + ".v"], gbq[:d], 1.0)
+        if fz:   # d u, d v, d b_q = d u + d v, d b_k, d b_v from the slot sums (all four GEMMs have drained here)
+            ops.attn_bias_fold(sl, S, d, gr[pre + ".u"], gr[pre + ".v"], gbq)
         else:
             self._bias_grad(dqu, gr[pre + ".u"])
             self._bias_grad(dqv, gr[pre + ".v"])

@@ -37,7 +37,7 @@ def _dt(t):
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
          act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
-         drop=None):
+         drop=None, colsum_slots=1, colsum_ss=0):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -57,6 +57,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.s_dtype = _dt(S) if S is not None else F32
     d.colsum = colsum.data_ptr() if colsum is not None else None
     d.colsum_bs1, d.colsum_scale = colsum_bs1, colsum_scale
+    d.colsum_slots, d.colsum_ss = colsum_slots, colsum_ss
     d.drop_p, d.drop_key = (drop if drop is not None else (0.0, 0))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -262,6 +263,10 @@ def scale_dev(x, y, s):
 
 def axpy(x, y, a=1.0):
     L.check(L.load().a3t_axpy(_ptr(x), _ptr(y), x.numel(), a, _stream()), "axpy")
+
+
+def attn_bias_fold(slots, S, d, gu, gv, gbqkv):
+    L.check(L.load().a3t_attn_bias_fold(_ptr(slots), S, d, _ptr(gu), _ptr(gv), _ptr(gbqkv), _stream()), "attn_bias_fold")
 
 
 def cast_bf16(x, y):

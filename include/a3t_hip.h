@@ -77,14 +77,17 @@ typedef struct a3t_gemm_desc {
     int32_t compute;                   /* A3T_F32: v_mfma_f32_32x32x2_f32 (exact f32);
                                           A3T_BF16: v_mfma_f32_32x32x16_bf16, fp32 accumulate */
     int32_t s_dtype;                   /* storage type of S (A3T_F32 | A3T_BF16) */
-    int32_t reserved;
+    int32_t colsum_slots;              /* 0/1: one accumulator row; S > 1: output tiles spread their atomics over S
+                                          copies colsum + slot*colsum_ss (slot = (row tile + batch) % S) which the
+                                          caller folds afterwards -- for single-round GEMMs whose tiles all finish
+                                          together (hundreds of same-address atomics in one burst cost 40 us) */
     float* colsum;                     /* optional: colsum[z1*colsum_bs1 + n] += colsum_scale * sum_m C[m][n]
                                           (bias gradients fused into the data-gradient GEMM; bf16 path only) */
     int64_t colsum_bs1;
     float colsum_scale;
     uint32_t drop_key;                 /* dropout fused into the epilogue (after act / mask, before alpha): */
     float drop_p;                      /*   v = keep(drop_key, linear index in C) ? v/(1-p) : 0 ; p = 0 disables */
-    int32_t reserved3;
+    int32_t colsum_ss;                 /* slot stride (floats) of the spread column sums */
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
@@ -177,6 +180,10 @@ int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, 
 /* y = x * s (decoder entry xscale, conformer/encoder.py:585-588) */
 int a3t_scale(const float* x, float* y, int64_t n, float s, void* stream);
 int a3t_axpy(const float* x, float* y, int64_t n, float a, void* stream); /* y += a*x */
+/* Fold of the slot-spread column sums (a3t_gemm_desc::colsum_slots) written by the four attention data-gradient GEMMs:
+ * slots[S][4*d] = per slot (colsum d(q+u) | colsum d(q+v) | colsum dK | colsum dV); adds them into the gradients of
+ * pos_bias_u, pos_bias_v (attention.py:137-140) and of the fused q/k/v bias [3*d] (linear_q/k/v.bias, :63-65). */
+int a3t_attn_bias_fold(const float* slots, int S, int d, float* gu, float* gv, float* gbqkv, void* stream);
 int a3t_scale_dev(const float* x, float* y, int64_t n, const float* s, void* stream); /* y = x * s[0], s on device */
 /* copy rows [b][0:Tm] of x[B][T][D] into y[B][Tm][D] (sedit_model.py:363) and the reverse scatter-add */
 int a3t_slice_rows(const float* x, void* y, int y_dtype, int B, int T, int Tm, int D, int reverse_add,

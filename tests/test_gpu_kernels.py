@@ -318,6 +318,68 @@ def test_gemm_256x256_pingpong_kernel(layout):
     _close(out, ref, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("T,dk", [(200, 192), (72, 192), (328, 160), (1120, 192)])
+def test_gemm_192_column_tile(T, dk):
+    """The 128x192-tile variant of the direct-to-LDS GEMM (d_k = 192 attention operands: one column tile instead of
+    one and a half).  Batched over (utterance, head) with the engine's strided views, all three layouts, ragged row
+    tiles, a ragged column tile (d_k = 160), bf16 and fp32 outputs, fused column sums (the bias-gradient epilogue);
+    checked against fp32 matmuls of the same bf16-rounded operands."""
+    ops = _ops()
+    from a3t_amd import _lib
+    from a3t_amd._lib import BF16
+    lib = _lib.load()
+    B, H = (2, 2) if T > 1000 else (3, 2)
+    d = H * dk
+    bf = lambda t: t.to(DEV).bfloat16()
+    probs = bf(_rand(B, H, T, T, seed=1, scale=T ** -0.5))
+    qkv = bf(_rand(B * T, 3 * d, seed=2))
+    vv = qkv.view(-1)[2 * d:]
+    v4 = qkv.float().view(B, T, 3, H, dk)[:, :, 2].permute(0, 2, 1, 3)            # (B,H,T,dk)
+    # NN: ctx[b,:,h,:] = probs[b,h] V[b,h]
+    ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(probs, vv, ctx, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=(H * T * T, T * T),
+             b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=BF16)
+    assert lib.a3t_gemm_last_kernel().decode().endswith(", 3>"), lib.a3t_gemm_last_kernel()
+    ref = torch.matmul(probs.float(), v4).permute(0, 2, 1, 3).reshape(B * T, d)
+    _close(ctx, ref, atol=2e-2, rtol=2e-2)
+    # TN with fused column sums: dV[b,h] = probs[b,h]^T dctx[b,:,h,:]; colsum over rows and utterances
+    dctx = bf(_rand(B * T, d, seed=3))
+    dqkv = torch.zeros(B * T, 3 * d, device=DEV, dtype=torch.bfloat16)
+    dvv = dqkv.view(-1)[2 * d:]
+    cs = torch.zeros(d, device=DEV)
+    ops.gemm(probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=(H * T * T, T * T),
+             b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=BF16, colsum=cs, colsum_bs1=dk)
+    assert lib.a3t_gemm_last_kernel().decode().endswith(", 3>")
+    d4 = dctx.float().view(B, T, H, dk).permute(0, 2, 1, 3)
+    ref = torch.matmul(probs.float().transpose(2, 3), d4)                          # (B,H,T,dk)
+    _close(dqkv.view(B, T, 3, H, dk)[:, :, 2].permute(0, 2, 1, 3), ref, atol=3e-2, rtol=2e-2)
+    assert float(dqkv.view(B, T, 3, H, dk)[:, :, :2].abs().max()) == 0.0           # q / k slices untouched
+    _close(cs.view(H, dk), ref.sum((0, 2)), atol=0.05 * math.sqrt(B * T), rtol=2e-2)
+    # the same with the column sums spread over S accumulator copies (slot = (row tile + utterance) % S) + the fold
+    S = 4
+    sl = torch.zeros(S, 4 * d, device=DEV)
+    gu, gv, gb = torch.ones(d, device=DEV), torch.zeros(d, device=DEV), torch.zeros(3 * d, device=DEV)
+    for part in (0, 3):     # pretend the same product is d(q+u) (part 0) and dV (part 3)
+        ops.gemm(probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=(H * T * T, T * T),
+                 b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=BF16, colsum=sl[0, part * d:], colsum_bs1=dk,
+                 colsum_slots=S, colsum_ss=4 * d)
+    assert int((sl.abs().sum(1) > 0).sum()) == min(S, (T + 127) // 128 + B - 1)    # slot = (row tile + utterance) % S
+    ops.attn_bias_fold(sl, S, d, gu, gv, gb)
+    tot = ref.sum((0, 2)).reshape(d)
+    tol = dict(atol=0.05 * math.sqrt(B * T), rtol=2e-2)
+    _close(gu, 1.0 + tot, **tol)
+    _close(gv, torch.zeros(d), **tol)
+    _close(gb, torch.cat([tot, torch.zeros(d, device=DEV), tot]), **tol)
+    # NT: plain linear with N = d_k outputs, bias + relu, fp32 output with residual
+    x = bf(_rand(B * T, 136, seed=4))
+    W = bf(_rand(dk, 136, seed=5, scale=136 ** -0.5))
+    bias, R = _rand(dk, seed=6).to(DEV), _rand(B * T, dk, seed=7).to(DEV)
+    out = torch.empty(B * T, dk, device=DEV)
+    ops.linear_fwd(x, W, out, bias=bias, R=R, act=_lib.ACT_RELU, alpha=0.5, compute=BF16)
+    assert lib.a3t_gemm_last_kernel().decode().endswith(", 3>")
+    _close(out, 0.5 * torch.relu(x.float() @ W.float().t() + bias) + R, atol=2e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("B,H,T", [(3, 2, 72), (2, 2, 200), (1, 2, 1120), (2, 2, 37)])
 def test_relpos_softmax_bf16_scores(B, H, T):
     """bf16 compute mode: ac / bd / dprobs / probs / ds / dbd all stored in bf16 (fp32 math inside).  T % 8 == 0
