@@ -12,6 +12,30 @@ SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16_t256.hip", "norm_reduce.hip",
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("A3T_EXTRA_FLAGS", "").split()
 
 
+# The direct-to-LDS GEMM variants are tuned to a register budget (<= 128 VGPRs = 4 workgroups per CU); a harmless
+# looking edit can push one over the edge and cost 30-50 % on that GEMM class.  The build records what the compiler
+# allocated; tests/test_host_logic.py::test_gemm_register_budget checks it.
+RES_SOURCES = ("gemm_bf16.hip",)
+RES_FLAG = ["-Rpass-analysis=kernel-resource-usage"]
+
+
+def _save_resources(report, path):
+    import json
+    import re
+    cur, rows = None, {}
+    for ln in report.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            cur = m.group(1)
+            rows[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([\w \[\]/]+?): (\d+)", ln)
+        if m and cur:
+            rows[cur][m.group(1).strip()] = int(m.group(2))
+    with open(path, "w") as f:
+        json.dump(rows, f, indent=1)
+
+
 def _hipcc():
     for c in ("/opt/rocm/bin/hipcc", "hipcc"):
         if os.path.exists(c) or c == "hipcc":
@@ -33,12 +57,19 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src, hdr, os.path.join(CSRC, "gemm_common.h")]):
-            jobs.append([_hipcc(), *FLAGS, "-c", src, "-o", obj])
+        if force or _stale(obj, [src, hdr, os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "dtype_io.h")]):
+            jobs.append([_hipcc(), *FLAGS, "-c", src, "-o", obj] + (RES_FLAG if s in RES_SOURCES else []))
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
+        if RES_FLAG[0] in cmd:     # keep the compiler's per-kernel register / occupancy report next to the object
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            if r.returncode:
+                sys.stderr.write(r.stderr)
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            _save_resources(r.stderr, cmd[cmd.index("-o") + 1].replace(".o", ".resources.json"))
+            return
         subprocess.check_call(cmd)
 
     with ThreadPoolExecutor(max_workers=4) as ex:

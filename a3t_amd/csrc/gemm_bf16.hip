@@ -139,12 +139,17 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
             b_row[q] = B + (int64_t)n * p.b_rs;
             b_sw[q] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         } else {
-            const int o16 = g * 64 + lane;              // 16-byte slot of this lane in the lane-linear image
-            int kr = o16 / B_LPR, cpos = o16 % B_LPR;
-            // 256-B k-rows: XOR swizzle; 384-B k-rows (natural 128-B stagger): rotate k-rows 2,3 (mod 4) by 64 B
-            int csrc = (B_LPR == 16) ? (cpos ^ ((kr & 3) << 2)) : (cpos - 4 * ((kr >> 1) & 1));
-            if (B_LPR != 16 && csrc < 0) csrc += B_LPR;
-            int col = tn * BN + csrc * 8;
+            int kr, col;
+            if (B_LPR == 16) {   // 256-B k-rows, 4 per DMA instruction: XOR swizzle
+                kr = g * 4 + lane / 16;
+                col = tn * BN + (((lane % 16) ^ ((kr & 3) << 2)) * 8);
+            } else {             // 384-B k-rows (natural 128-B stagger): rotate k-rows 2,3 (mod 4) by 64 B
+                const int o16 = g * 64 + lane;          // 16-byte slot of this lane in the lane-linear image
+                kr = o16 / B_LPR;
+                int csrc = o16 % B_LPR - 4 * ((kr >> 1) & 1);
+                csrc = csrc < 0 ? csrc + B_LPR : csrc;
+                col = tn * BN + csrc * 8;
+            }
             b_ok[q] = col < p.N;
             b_row[q] = B + col;
             b_sw[q] = kr;
@@ -280,27 +285,30 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
         int kc = kk * 2 + lk;
         return *(const bf16x8*)(img + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
     };
-    auto frag_rc = [&](const unsigned char* img, int rowbytes, int row0, int kk) -> bf16x8 {
+    auto frag_rc = [&](const unsigned char* img, auto rbc, int row0, int kk) -> bf16x8 {
         // 16-lane group g: rows row0 + (g&1)*16 .. +15, k = kk*16 + (g>>1)*8 .. +7 (two 4-k transposed reads)
+        constexpr int rowbytes = decltype(rbc)::value;
         const int g = lane >> 4, pp = lane & 15;
         const int col = row0 + (g & 1) * 16 + (pp & 3) * 4;
         const int kb = kk * 16 + (g >> 1) * 8 + (pp >> 2);
         const int k1 = kb + 4;
-        int p0, p1;
+        const unsigned char *a0, *a1;
         if (rowbytes == 256) {
-            p0 = (col >> 3) ^ ((kb & 3) << 2), p1 = (col >> 3) ^ ((k1 & 3) << 2);
-        } else {   // 384-byte k-rows (kb and kb + 4 get the same rotation)
-            p0 = (col >> 3) + 4 * ((kb >> 1) & 1);
+            a0 = img + kb * rowbytes + ((((col >> 3) ^ ((kb & 3) << 2))) << 4) + (col & 7) * 2;
+            a1 = img + k1 * rowbytes + ((((col >> 3) ^ ((k1 & 3) << 2))) << 4) + (col & 7) * 2;
+        } else {   // 384-byte k-rows: k-rows 2,3 (mod 4) are rotated by 64 B (kb and kb + 4 get the same rotation)
+            int p0 = (col >> 3) + 4 * ((kb >> 1) & 1);
             p0 = p0 >= 24 ? p0 - 24 : p0;
-            p1 = p0;
+            a0 = img + kb * rowbytes + (p0 << 4) + (col & 7) * 2;
+            a1 = a0 + 4 * rowbytes;
         }
-        const unsigned char* a0 = img + kb * rowbytes + (p0 << 4) + (col & 7) * 2;
-        const unsigned char* a1 = img + k1 * rowbytes + (p1 << 4) + (col & 7) * 2;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a1));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
+    constexpr std::integral_constant<int, BM * 2> RB_A{};
+    constexpr std::integral_constant<int, BN * 2> RB_B{};
 
     if (STAGES == 2) issue(kt0 * BK, 0);
     int stage = 0;
@@ -320,16 +328,15 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
                 a0 = frag_kc(sA, wm + lr, kk);
                 a1 = frag_kc(sA, wm + 32 + lr, kk);
             } else {
-                a0 = frag_rc(sA, BM * 2, wm, kk);
-                a1 = frag_rc(sA, BM * 2, wm + 32, kk);
+                a0 = frag_rc(sA, RB_A, wm, kk);
+                a1 = frag_rc(sA, RB_A, wm + 32, kk);
             }
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bq[j] = B_KC ? frag_kc(sB, wn + 32 * j + lr, kk) : frag_rc(sB, BN * 2, wn + 32 * j, kk);
+            for (int j = 0; j < WN; ++j) bq[j] = B_KC ? frag_kc(sB, wn + 32 * j + lr, kk) : frag_rc(sB, RB_B, wn + 32 * j, kk);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[j], acc[0][j], 0, 0, 0);
-                acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[j], acc[1][j], 0, 0, 0);
-            }
+            for (int j = 0; j < WN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[j], acc[0][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[j], acc[1][j], 0, 0, 0);
         }
         if (STAGES == 2) stage ^= 1;
     }

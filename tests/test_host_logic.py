@@ -1,6 +1,8 @@
 """CPU tests of the product's host-side logic (collate mirror, init, config translation)."""
 import os
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -125,3 +127,28 @@ def test_host_index_logic_randomised_against_oracle():
         np.random.seed(seed)
         m_g = C.random_spans_noise_mask(Ln, pr2, sp2)
         assert np.array_equal(m_g, m_r), (case, Ln)
+
+
+def test_gemm_register_budget():
+    """The direct-to-LDS GEMM variants are tuned to a register budget: <= 128 VGPRs (4 workgroups per CU) for the plain /
+    fast-conv variants and the fused conv weight gradient, <= 168 (3 per CU) for the generic-conv and 192-column
+    variants, no scratch anywhere.  One innocuous edit once pushed the weight-gradient kernel from 122 to 130 VGPRs and
+    cost 50 % on 9 ms of the step, silently; the build now records the compiler's allocation and this test reads it."""
+    import json
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "a3t_amd", "lib",
+                        "gemm_bf16.resources.json")
+    if not os.path.exists(path):
+        pytest.skip("library not built by a3t_amd.build in this tree")
+    rows = json.load(open(path))
+    seen = 0
+    for name, r in rows.items():
+        m = re.match(r"_Z21gemm_bf16_glds_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)EEv2GP", name)
+        if not m:
+            continue
+        layout, stages, wm, conv, wn = map(int, m.groups())
+        seen += 1
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, name
+        four_per_cu = wn == 2 and (conv in (0, 1) or (conv == 2 and layout == 2))
+        assert r["VGPRs"] <= (128 if four_per_cu else 168), (name, r["VGPRs"])
+    assert seen >= 22

@@ -42,6 +42,8 @@ cases = {
     "NN dqv = dbd P (+colsum) ": lambda: ops.gemm(probs, P, out_d, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk), c_bs=(T * d, dk), compute=BF16, colsum=cs, colsum_bs1=dk),
     "TN dV = probs^T dctx (+cs)": lambda: ops.gemm(probs, qu, out_qkv.view(-1)[2 * d:], T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=BF16, colsum=cs[2 * d:], colsum_bs1=dk),
 }
+dP = torch.zeros(T, d, device=dev)
+cases["TN dP += dbd^T (q+v), atomic"] = lambda: ops.gemm(probs, qu, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(0, dk), acc=_lib.ACC_ATOMIC, compute=BF16)
 sl = torch.zeros(16, 4 * d, device=dev)
 sk = dict(colsum_bs1=dk, colsum_slots=16, colsum_ss=4 * d)
 cases["NN dqu, 16 colsum slots  "] = lambda: ops.gemm(probs, kk, out_d, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=BF16, colsum=sl[0], **sk)
