@@ -719,3 +719,162 @@ def synthetic_batch(c: A3TConfig, B: int, T_mel: int, T_phn: int, seed: int,
         speech_mask=torch.from_numpy(smask)[:, None, :], text_mask=torch.from_numpy(tmask)[:, None, :],
         speech_segment_pos=torch.from_numpy(sp), text_segment_pos=torch.from_numpy(tp),
     )
+
+
+# ----------------------------------------------------------------------------
+# speech-editing inference driver: host-side span arithmetic (espnet2/bin/sedit_inference.py)
+# The forced aligner (HTK), the phoneme dictionary tool and the FastSpeech2 duration predictor are external programs /
+# checkpoints of the reference; their OUTPUTS are the inputs here.
+# ----------------------------------------------------------------------------
+def sedit_masked_mel_boundary(mfa_start, mfa_end, fs: int, hop: int, span):
+    """sedit_inference.py:426-435 -- phone span [a, b) -> mel-frame span; an empty span past the end pins to the end."""
+    a_s = torch.floor(fs * torch.tensor(mfa_start) / hop).int().tolist()
+    a_e = torch.floor(fs * torch.tensor(mfa_end) / hop).int().tolist()
+    if span[0] >= len(mfa_start):
+        return [a_e[-1], a_e[-1]]
+    return [a_s[span[0]], a_e[span[1] - 1]]
+
+
+def sedit_phone_spans(times2, word2phns: Dict[str, str], new_phns: List[str], new_word2phns: Dict[str, List[str]],
+                      old_str: str, new_str: str):
+    """sedit_inference.py:437-504 (get_phns_and_spans) with the aligner output (times2 = [[phn, start, end], ...],
+    word2phns = {"i_WORD": "PH PH"}) and the phonemiser output (new_phns, new_word2phns = {"i_WORD": [PH, ...]})
+    passed in.  Word-level common prefix / suffix -> phone spans to be replaced (old) and added (new)."""
+    append_new = (old_str == new_str[:len(old_str)])
+    old_phns = [t[0] for t in times2]
+    mfa_start = [float(t[1]) for t in times2]
+    mfa_end = [float(t[2]) for t in times2]
+    rep = [0, len(old_phns) - 1]
+    add = [0, len(new_phns) - 1]
+    left_index, left, sp = 0, [], 0
+    for key in word2phns.keys():
+        idx, wrd = key.split("_")
+        if wrd == "sp":
+            sp += 1
+            left.append("sp")
+        else:
+            k2 = str(int(idx) - sp) + "_" + wrd
+            if k2 in new_word2phns:
+                left_index += len(new_word2phns[k2])
+                left.extend(word2phns[key].split())
+            else:
+                rep[0] = len(left)
+                add[0] = len(left)
+                break
+    right_index, right, sp = 0, [], 0
+    wmax = int(list(word2phns.keys())[-1].split("_")[0])
+    nmax = int(list(new_word2phns.keys())[-1].split("_")[0])
+    middle = []
+    if append_new:
+        middle = new_phns[left_index:]
+        rep[0] = len(left)
+        add[0] = len(left)
+        add[1] = len(left) + len(middle)
+        rep[1] = len(old_phns) - len(right)
+    else:
+        for key in list(word2phns.keys())[::-1]:
+            idx, wrd = key.split("_")
+            if wrd == "sp":
+                sp += 1
+                right = ["sp"] + right
+            else:
+                k2 = str(nmax - (wmax - int(idx) - sp)) + "_" + wrd
+                if k2 in new_word2phns:
+                    right_index -= len(new_word2phns[k2])
+                    right = word2phns[key].split() + right
+                else:
+                    rep[1] = len(old_phns) - len(right)
+                    middle = new_phns[left_index:right_index]
+                    add[1] = len(left) + len(middle)
+                    if len(middle) == 0:
+                        add[1] = min(add[1] + 1, len(new_phns))
+                        add[0] = max(0, add[0] - 1)
+                        rep[0] = max(0, rep[0] - 1)
+                        rep[1] = min(rep[1] + 1, len(old_phns))
+                    break
+    return mfa_start, mfa_end, old_phns, left + middle + right, rep, add
+
+
+def sedit_duration_adjust_factor(original_dur, pred_dur, phns) -> float:
+    """sedit_inference.py:506-524 -- trimmed mean (2 lowest / 2 highest dropped) of aligned/predicted duration ratios."""
+    f = []
+    for ori, pred, phn in zip(original_dur, pred_dur, phns):
+        if pred == 0 or phn == "sp":
+            continue
+        f.append(ori / pred)
+    f = np.array(f)
+    f.sort()
+    if len(f) < 5:
+        return 1
+    return np.average(f[2:-2])
+
+
+def sedit_plan_edit(wav_org: np.ndarray, fs: int, hop: int, mfa_start, mfa_end, old_phns, new_phns, rep, add,
+                    duration_fn, new_str: str, mask_reconstruct=False, duration_adjust=True, start_end_sp=False):
+    """sedit_inference.py:526-594 (prepare_features_with_duration) after get_phns_and_spans; duration_fn(phns) stands
+    for the FastSpeech2 duration predictor (:398-424, seconds per phone).  Returns (new_wav, new_phns, new_mfa_start,
+    new_mfa_end, old_span_boundary, new_span_boundary)."""
+    mfa_start, mfa_end, new_phns = list(mfa_start), list(mfa_end), list(new_phns)
+    rep, add = list(rep), list(add)
+    if start_end_sp and new_phns[-1] != "sp":
+        new_phns = new_phns + ["sp"]
+    if "[MASK]" in new_str and mask_reconstruct:
+        ob = sedit_masked_mel_boundary(mfa_start, mfa_end, fs, hop, rep)
+        return wav_org, old_phns, mfa_start, mfa_end, ob, ob
+    old_dur = duration_fn(old_phns)
+    orig = [e - s for e, s in zip(mfa_end, mfa_start)]
+    if "[MASK]" in new_str:
+        new_phns = old_phns
+        add = rep
+        fl = sedit_duration_adjust_factor(orig[:rep[0]], old_dur[:rep[0]], old_phns[:rep[0]])
+        fr = sedit_duration_adjust_factor(orig[rep[1]:], old_dur[rep[1]:], old_phns[rep[1]:])
+        d = (fl + fr) / 2
+        new_dur = [d * i for i in old_dur]
+    else:
+        d = sedit_duration_adjust_factor(orig, old_dur, old_phns) if duration_adjust else 1
+        new_dur = [d * i for i in duration_fn(new_phns)]
+        if rep[0] < len(old_phns) and old_phns[rep[0]] == new_phns[add[0]]:
+            new_dur[add[0]] = orig[rep[0]]
+        if rep[1] < len(old_phns) and add[1] < len(new_phns):
+            if old_phns[rep[1]] == new_phns[add[1]]:
+                new_dur[add[1]] = orig[rep[1]]
+    new_sum = sum(new_dur[add[0]:add[1]])
+    old_sum = sum(orig[rep[0]:rep[1]])
+    off = new_sum - old_sum
+    ns, ne = mfa_start[:rep[0]], mfa_end[:rep[0]]
+    for i in new_dur[add[0]:add[1]]:
+        if len(ne) == 0:
+            ns.append(0)
+            ne.append(i)
+        else:
+            ns.append(ne[-1])
+            ne.append(ne[-1] + i)
+    ns += [i + off for i in mfa_start[rep[1]:]]
+    ne += [i + off for i in mfa_end[rep[1]:]]
+    if rep[0] >= len(mfa_start):
+        li = ri = len(wav_org)
+    else:
+        li = int(np.floor(mfa_start[rep[0]] * fs))
+        ri = int(np.ceil(mfa_end[rep[1] - 1] * fs))
+    blank = np.zeros((int(np.ceil(new_sum * fs)),), dtype=wav_org.dtype)
+    new_wav = np.concatenate([wav_org[:li], blank, wav_org[ri:]])
+    ob = sedit_masked_mel_boundary(mfa_start, mfa_end, fs, hop, rep)
+    nb = sedit_masked_mel_boundary(ns, ne, fs, hop, add)
+    return new_wav, new_phns, ns, ne, ob, nb
+
+
+def sedit_splice_feat_gen(output: List[torch.Tensor]) -> torch.Tensor:
+    """sedit_inference.py:622-629 -- [left (1,s,80) | generated (e-s,80) | right (1,T-e,80)] -> (T,80), empty ends dropped."""
+    if 0 in output[0].shape and 0 not in output[-1].shape:
+        return torch.cat(output[1:-1] + [output[-1].squeeze()], dim=0)
+    if 0 not in output[0].shape and 0 in output[-1].shape:
+        return torch.cat([output[0].squeeze()] + output[1:-1], dim=0)
+    if 0 in output[0].shape and 0 in output[-1].shape:
+        return torch.cat(output[1:-1], dim=0)
+    return torch.cat([output[0].squeeze(0)] + output[1:-1] + [output[-1].squeeze(0)], dim=0)
+
+
+def sedit_replace_waveform(wav_org: np.ndarray, replaced_wav: np.ndarray, hop: int, old_span, new_span) -> np.ndarray:
+    """sedit_inference.py:80-84 -- original audio with the vocoded new span spliced in (sample = frame * hop)."""
+    return np.concatenate([wav_org[:hop * old_span[0]], replaced_wav[hop * new_span[0]:hop * new_span[1]],
+                           wav_org[hop * old_span[1]:]])

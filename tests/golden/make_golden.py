@@ -367,6 +367,155 @@ def gen_pwg(out):
     print("pwg.npz", wav.shape, float(wav.abs().mean()))
 
 
+def fake_phone_duration(phns):
+    """Stand-in for the FastSpeech2 duration predictor of the inference driver (seconds per phone); the sedit
+    fixtures and tests share it."""
+    out = []
+    for ph in phns:
+        h = sum(map(ord, ph))
+        out.append(0.0 if h % 11 == 0 else (0.05 if ph == "sp" else 0.03 + 0.01 * (h % 7)))
+    return out
+
+
+def gen_sedit(out):
+    """Span arithmetic of the speech-editing inference driver (espnet2/bin/sedit_inference.py): the reference's own
+    get_phns_and_spans / prepare_features_with_duration / get_masked_mel_boundary / duration_adjust_factor, with its
+    external programs (HTK aligner, phonemiser, FastSpeech2 duration predictor, librosa.load) replaced by synthetic
+    stand-ins whose outputs are stored as the fixture's inputs."""
+    import json
+    import random
+    import torch
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return True
+
+        def __getattr__(self, k):
+            return _Any()
+
+    for n in ["matplotlib", "matplotlib.pylab", "parallel_wavegan", "parallel_wavegan.utils", "ipywidgets", "IPython",
+              "IPython.display", "espnet2.tasks.tts", "espnet2.bin.align_english"]:
+        m = types.ModuleType(n)
+        m.__spec__ = importlib.machinery.ModuleSpec(n, None)
+        m.__path__ = []
+
+        def _ga(k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Any()
+
+        m.__getattr__ = _ga
+        sys.modules[n] = m
+    import espnet2.bin.sedit_inference as S
+    torch.use_deterministic_algorithms(False)     # (the driver switches it on at import)
+
+    lex = {"THE": ["DH", "AH0"], "CAT": ["K", "AE1", "T"], "SAT": ["S", "AE1", "T"], "ON": ["AA1", "N"],
+           "A": ["AH0"], "MAT": ["M", "AE1", "T"], "DOG": ["D", "AO1", "G"], "RAN": ["R", "AE1", "N"],
+           "FAST": ["F", "AE1", "S", "T"], "HOME": ["HH", "OW1", "M"], "TODAY": ["T", "AH0", "D", "EY1"],
+           "QUIETLY": ["K", "W", "AY1", "AH0", "T", "L", "IY0"], "BLUE": ["B", "L", "UW1"]}
+    words = sorted(lex)
+    rng = random.Random(7)
+    fs, hop = 24000, 300
+    cases = []
+    wavs = {}
+    mlm = types.SimpleNamespace(feats_extract=types.SimpleNamespace(fs=fs, hop_length=hop))
+    tries = 0
+    while len(cases) < 40 and tries < 400:
+        tries += 1
+        n_old = rng.randrange(3, 8)
+        old_words = [rng.choice(words) for _ in range(n_old)]
+        kind = rng.choice(["replace", "insert", "delete", "append", "first", "last", "mask", "mask_rec"])
+        a = rng.randrange(1, n_old - 1) if n_old > 2 else 1
+        b = rng.randrange(a + 1, n_old) if a + 1 < n_old else a + 1
+        fresh = [rng.choice(words) for _ in range(rng.randrange(1, 4))]
+        if kind == "replace":
+            new_words = old_words[:a] + fresh + old_words[b:]
+        elif kind == "insert":
+            new_words = old_words[:a] + fresh + old_words[a:]
+        elif kind == "delete":
+            new_words = old_words[:a] + old_words[b:]
+        elif kind == "append":
+            new_words = old_words + fresh
+        elif kind == "first":
+            new_words = fresh + old_words[1:]
+        elif kind == "last":
+            new_words = old_words[:-1] + fresh
+        else:
+            new_words = old_words[:a] + ["[MASK]"] + old_words[b:]
+        # aligner stand-in: optional silences at the ends and between words
+        t, idx, times2, word2phns = 0.0, 0, [], {}
+        seq = []
+        if rng.random() < 0.5:
+            seq.append("sp")
+        for i, w in enumerate(old_words):
+            seq.append(w)
+            if i + 1 < n_old and rng.random() < 0.3:
+                seq.append("sp")
+        if rng.random() < 0.5:
+            seq.append("sp")
+        for w in seq:
+            phs = ["sp"] if w == "sp" else lex[w]
+            word2phns[f"{idx}_{w}"] = " ".join(phs)
+            idx += 1
+            for ph in phs:
+                d = round(rng.uniform(0.03, 0.2), 4)
+                times2.append([ph, round(t, 4), round(t + d, 4)])
+                t = round(t + d, 4)
+        new_phns, new_w2p = [], {}
+        for i, w in enumerate(new_words):
+            phs = [w] if w == "[MASK]" else lex[w]
+            new_w2p[f"{i}_{w}"] = phs
+            new_phns.extend(phs)
+        old_str, new_str = " ".join(w.lower() for w in old_words), " ".join(
+            w if w == "[MASK]" else w.lower() for w in new_words)
+        wav = (np.arange(int(np.ceil(t * fs)) + rng.randrange(0, 900), dtype=np.float32) % 1000.0) / 1000.0 + 0.001
+        S.alignment = lambda wav_path, txt, _t=times2, _w=word2phns: (_t, _w)
+        S.words2phns_yuan = lambda line, _p=new_phns, _w=new_w2p: (list(_p), _w)
+        S.get_fs2_model = lambda path: (None, None)
+        S.duration_predict = lambda phns, fs_, hop_, m, pr, w, sid=None: fake_phone_duration(phns)
+        S.librosa.load = lambda path, sr=None, _w=wav: (_w, sr)
+        opts = dict(mask_reconstruct=(kind == "mask_rec"), duration_adjust=rng.random() < 0.7,
+                    start_end_sp=rng.random() < 0.3)
+        try:
+            spans = S.get_phns_and_spans("x.wav", old_str, new_str)
+            res = S.prepare_features_with_duration(mlm, old_str, new_str, "x.wav", "fs2.pth", **opts)
+        except Exception as e:      # the driver itself rejects some edits (e.g. nothing left to anchor on)
+            continue
+        mfa_start, mfa_end, old_phns, new_phns_out, rep, add = spans
+        new_wav, phns_o, ns, ne, ob, nb = res
+        key = f"w{len(cases)}"
+        wavs[key + ".in"] = wav
+        wavs[key + ".out"] = np.asarray(new_wav)
+        cases.append(dict(kind=kind, old_str=old_str, new_str=new_str, times2=times2, word2phns=word2phns,
+                          new_phns=new_phns, new_word2phns=new_w2p, opts=opts, wav=key,
+                          spans=dict(mfa_start=mfa_start, mfa_end=mfa_end, old_phns=old_phns, new_phns=new_phns_out,
+                                     replaced=list(rep), added=list(add)),
+                          plan=dict(phns=list(phns_o), mfa_start=[float(x) for x in ns], mfa_end=[float(x) for x in ne],
+                                    old_span_boundary=[int(x) for x in ob], new_span_boundary=[int(x) for x in nb])))
+    # the two leaf helpers on hand-picked boundary inputs
+    leaf = dict(
+        boundary=[dict(args=[[0.0, 0.5, 1.0], [0.5, 1.0, 1.5], fs, hop, [1, 2]]),
+                  dict(args=[[0.0, 0.0125, 0.025], [0.0125, 0.025, 0.0375001], fs, hop, [0, 3]]),
+                  dict(args=[[0.0, 0.5], [0.5, 1.2], fs, hop, [2, 2]])],
+        factor=[dict(args=[[.3, .4, .5, .6, .7, .8, .9], [.3, .4, .4, .7, .7, .9, .9], list("abcdefg")]),
+                dict(args=[[.3, .4, .5, .6], [.3, .4, .4, .7], list("abcd")]),
+                dict(args=[[.3, .4, .5, .6, .7, .8, .9, 1.0], [.3, 0, .4, .7, .7, .9, .9, .5],
+                           ["a", "b", "sp", "d", "e", "f", "g", "h"]])])
+    for d in leaf["boundary"]:
+        d["out"] = [int(x) for x in S.get_masked_mel_boundary(*d["args"])]
+    for d in leaf["factor"]:
+        d["out"] = float(S.duration_adjust_factor(*d["args"]))
+    json.dump(dict(fs=fs, hop=hop, cases=cases, leaf=leaf), open(os.path.join(out, "sedit.json"), "w"))
+    np.savez_compressed(os.path.join(out, "sedit_wav.npz"), **wavs)
+    kinds = {}
+    for c_ in cases:
+        kinds[c_["kind"]] = kinds.get(c_["kind"], 0) + 1
+    print("sedit.json", len(cases), "cases", kinds, "tries", tries)
+
+
 def sweep(out, n_masks, n_models):
     """Randomised pinning of the ORACLE to the REFERENCE (container only; the fixed goldens above are what travels).
 
@@ -497,7 +646,7 @@ if __name__ == "__main__":
     if a.sweep:
         sweep(HERE, *a.sweep)
         sys.exit(0)
-    todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg)
+    todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg, sedit=gen_sedit)
     for k, f in todo.items():
         if a.only and k not in a.only.split(","):
             continue

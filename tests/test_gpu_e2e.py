@@ -522,3 +522,76 @@ def test_parallel_wavegan_fused_block_equals_layerwise_path(B, Tf):
     b = ParallelWaveGANGeneratorHIP(state, device=DEV, fused=False).inference(c, z)
     assert a.shape == (B, Tf * 300, 1)
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["replace", "mask", "append", "delete"])
+def test_speech_editor_end_to_end_against_oracle(kind):
+    """The speech-editing driver on the device path (a3t_amd.sedit.SpeechEditor: plan on the host -> log-mel collate on
+    the GPU -> teacher-forced Conformer infill -> fused ParallelWaveGAN -> splice into the original audio) against the
+    oracle's restatement of the same chain (span arithmetic pinned by the reference driver's own outputs in
+    tests/golden/sedit.json; collate / infill / vocoder pinned by their goldens), on an edit taken from that fixture."""
+    import json
+    import sys
+    from a3t_amd.collate import MLMCollateFn
+    from a3t_amd.features import LogMelFbank
+    from a3t_amd.sedit import SpeechEditor
+    from a3t_amd.task import MLMTask
+    from a3t_amd.vocoder import ParallelWaveGANGeneratorHIP
+    if G not in sys.path:
+        sys.path.insert(0, G)
+    from make_golden import fake_phone_duration
+    fx = json.load(open(os.path.join(G, "sedit.json")))
+    case = [c for c in fx["cases"] if c["kind"] == kind][0]
+    rs = np.random.RandomState(5)
+    wav = np.load(os.path.join(G, "sedit_wav.npz"))[case["wav"] + ".in"]
+    wav = (0.1 * rs.standard_normal(wav.shape[0])).astype(np.float32)            # a signal with a spectrum
+    oc = O.tiny_config()
+    model = MLMTask.build_model(_task_args(oc), device=DEV)
+    state = O.procedural_state(O.param_shapes(oc), 1)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+    model.eval()
+    fe = LogMelFbank(fs=oc.fs, n_fft=oc.n_fft, win_length=oc.win_length, hop_length=oc.hop_length, n_mels=oc.n_mels,
+                     fmin=oc.fmin, fmax=oc.fmax, device=DEV)
+    coll = MLMCollateFn(fe, float_pad_value=0.0, int_pad_value=0, mlm_prob=oc.mlm_prob, mean_phn_span=oc.mean_phn_span,
+                        sega_emb=True)
+    cfg = O.PWGConfig()
+    vstate = O.procedural_state(O.pwg_param_shapes(cfg), seed=4)
+    for k in vstate:
+        if "up_layers" in k:
+            vstate[k] = np.abs(vstate[k]) / np.abs(vstate[k]).sum()
+    voc = ParallelWaveGANGeneratorHIP(vstate, device=DEV)
+    noise = {}
+
+    def vocoder(feat):
+        noise["z"] = torch.from_numpy(np.random.RandomState(9).standard_normal((feat.shape[0] * oc.hop_length, 1)).astype(np.float32))
+        return voc.inference(feat, noise["z"])
+
+    ids = lambda phns: np.array([2 + sum(map(ord, ph)) % (oc.vocab - 4) for ph in phns], dtype=np.int64)
+    ed = SpeechEditor(model, coll, vocoder, ids, fake_phone_duration)
+    args = (case["times2"], case["word2phns"], case["new_phns"], case["new_word2phns"], case["old_str"], case["new_str"])
+    got = ed.edit(wav, *args, **case["opts"])
+
+    # ---- the same chain through the oracle
+    ms, me, op, nph, rep, add = O.sedit_phone_spans(*args)
+    nwav, phns, ns, ne, ob, nb = O.sedit_plan_edit(wav, oc.fs, oc.hop_length, ms, me, op, nph, rep, add, fake_phone_duration,
+                                                   case["new_str"], **case["opts"])
+    assert got["old_span_boundary"] == ob and got["new_span_boundary"] == nb
+    data = [("1", dict(speech=np.asarray(nwav, np.float32), align_start=np.asarray(ns), align_end=np.asarray(ne),
+                       text=ids(phns), span_boundary=np.asarray(nb)))]
+    _, b = O.collate(data, oc)
+    p = O.to_torch_state(state)
+    feat = O.inference_splice(p, b, oc, (nb[0], nb[1]))
+    assert got["feat"].shape == feat.shape
+    np.testing.assert_allclose(got["feat"].cpu().numpy(), feat.numpy(), atol=1e-3, rtol=1e-3)
+    pv = O.to_torch_state(vstate)
+    ref_wav = O.pwg_forward(pv, feat.t()[None], noise["z"].t()[None], cfg)[0, 0].numpy()
+    assert got["prediction"].shape == ref_wav.shape == (feat.shape[0] * oc.hop_length,)
+    np.testing.assert_allclose(got["prediction"], ref_wav, atol=2e-3 * max(1.0, float(np.abs(ref_wav).max())), rtol=0)
+    ref_edit = O.sedit_replace_waveform(wav, ref_wav, oc.hop_length, ob, nb)
+    assert got["orgin_replaced"].shape == ref_edit.shape
+    np.testing.assert_allclose(got["orgin_replaced"], ref_edit, atol=2e-3 * max(1.0, float(np.abs(ref_wav).max())), rtol=0)
+    # outside the edited span the result IS the input audio
+    h = oc.hop_length
+    assert np.array_equal(got["orgin_replaced"][:h * ob[0]], wav[:h * ob[0]])
+    if h * ob[1] < len(wav):
+        assert np.array_equal(got["orgin_replaced"][h * nb[1]:], wav[h * ob[1]:])

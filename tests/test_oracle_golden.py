@@ -225,3 +225,54 @@ def test_reference_sweep_record():
     assert rep["mask_mismatches"] == 0 and rep["model_mismatches"] == 0
     assert rep["worst_loss_rel"] <= rep["criteria"]["loss_rel"]
     assert rep["worst_grad_rel"] <= rep["criteria"]["grad_rel_l2"]
+
+
+def _sedit_fixture():
+    import json
+    import sys
+    g = json.load(open(os.path.join(G, "sedit.json")))
+    w = np.load(os.path.join(G, "sedit_wav.npz"))
+    if G not in sys.path:
+        sys.path.insert(0, G)
+    from make_golden import fake_phone_duration
+    return g, w, fake_phone_duration
+
+
+def check_sedit_impl(phone_spans, plan_edit, boundary, factor):
+    """Shared by the oracle test (here) and the product test (test_host_logic.py): the speech-editing span arithmetic
+    against the reference driver's own outputs on 40 synthetic edits (replace / insert / delete / append / first / last
+    word, [MASK] infill, [MASK] reconstruction; with and without silences, duration adjustment, trailing sp)."""
+    g, w, dur = _sedit_fixture()
+    fs, hop = g["fs"], g["hop"]
+    for c in g["cases"]:
+        sp = c["spans"]
+        got = phone_spans(c["times2"], c["word2phns"], c["new_phns"], c["new_word2phns"], c["old_str"], c["new_str"])
+        assert list(got[0]) == sp["mfa_start"] and list(got[1]) == sp["mfa_end"], c["kind"]
+        assert list(got[2]) == sp["old_phns"] and list(got[3]) == sp["new_phns"], (c["kind"], c["old_str"], c["new_str"])
+        assert list(got[4]) == sp["replaced"] and list(got[5]) == sp["added"], (c["kind"], c["old_str"], c["new_str"])
+        wav = w[c["wav"] + ".in"]
+        new_wav, phns, ns, ne, ob, nb = plan_edit(wav, fs, hop, got[0], got[1], got[2], got[3], got[4], got[5], dur,
+                                                  c["new_str"], **c["opts"])
+        pl = c["plan"]
+        assert list(phns) == pl["phns"], c["kind"]
+        assert [int(x) for x in ob] == pl["old_span_boundary"] and [int(x) for x in nb] == pl["new_span_boundary"], c
+        np.testing.assert_allclose(np.asarray(ns, dtype=np.float64), pl["mfa_start"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.asarray(ne, dtype=np.float64), pl["mfa_end"], rtol=0, atol=1e-12)
+        ref_wav = w[c["wav"] + ".out"]
+        assert np.asarray(new_wav).shape == ref_wav.shape and np.array_equal(np.asarray(new_wav), ref_wav), c["kind"]
+    for d in g["leaf"]["boundary"]:
+        assert [int(x) for x in boundary(*d["args"])] == d["out"]
+    for d in g["leaf"]["factor"]:
+        assert abs(float(factor(*d["args"])) - d["out"]) < 1e-12
+
+
+def test_sedit_span_arithmetic():
+    check_sedit_impl(O.sedit_phone_spans, O.sedit_plan_edit, O.sedit_masked_mel_boundary, O.sedit_duration_adjust_factor)
+    # splice / waveform replacement are pure data movement
+    left, gen, right = torch.zeros(1, 3, 4), torch.ones(2, 4), 2 * torch.ones(1, 5, 4)
+    assert O.sedit_splice_feat_gen([left, gen, right]).shape == (10, 4)
+    assert O.sedit_splice_feat_gen([left[:, :0], gen, right]).shape == (7, 4)
+    assert O.sedit_splice_feat_gen([left, gen, right[:, :0]]).shape == (5, 4)
+    assert O.sedit_splice_feat_gen([left[:, :0], gen, right[:, :0]]).shape == (2, 4)
+    out = O.sedit_replace_waveform(np.arange(3000.0), -np.arange(6000.0), 300, [2, 5], [1, 9])
+    assert out.shape == (600 + 2400 + 1500,) and out[600] == -300.0 and out[-1] == 2999.0
