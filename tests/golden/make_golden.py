@@ -516,6 +516,42 @@ def gen_sedit(out):
     print("sedit.json", len(cases), "cases", kinds, "tries", tries)
 
 
+def gen_average(out):
+    """average_nbest_models (espnet2/main_funcs/average_nbest_models.py) on four small epoch files."""
+    import tempfile
+    from pathlib import Path
+    import torch
+    from espnet2.main_funcs.average_nbest_models import average_nbest_models
+    from espnet2.train.reporter import Reporter
+
+    rs = np.random.RandomState(3)
+    d = {}
+    losses = {1: 0.9, 2: 0.4, 3: 0.7, 4: 0.5, 5: 0.45}
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        for e in losses:
+            st = {"a.weight": torch.from_numpy(rs.standard_normal((3, 4)).astype(np.float32)),
+                  "bn.running_var": torch.from_numpy(rs.rand(5).astype(np.float32)),
+                  "bn.num_batches_tracked": torch.tensor(100 * e, dtype=torch.long)}
+            torch.save(st, td / f"{e}epoch.pth")
+            for k, v in st.items():
+                d[f"in.{e}.{k}"] = v.numpy()
+        rep = Reporter()
+        rep.epoch = 5
+        rep.stats = {e: {"valid": {"loss": v}, "train": {"loss": v * 2}} for e, v in losses.items()}
+        average_nbest_models(td, rep, [("valid", "loss", "min")], [1, 3, 9])
+        files = sorted(p.name for p in td.iterdir())
+        links = {p.name: os.readlink(p) for p in td.iterdir() if p.is_symlink()}
+        ave = torch.load(td / "valid.loss.ave_3best.pth")
+        for k, v in ave.items():
+            d["out.ave3." + k] = v.numpy()
+    d["losses"] = np.array([[e, v] for e, v in losses.items()])
+    d["files"] = np.array(files)
+    d["links"] = np.array([f"{k}->{v}" for k, v in sorted(links.items())])
+    np.savez_compressed(os.path.join(out, "average.npz"), **d)
+    print("average.npz", files, links)
+
+
 def sweep(out, n_masks, n_models):
     """Randomised pinning of the ORACLE to the REFERENCE (container only; the fixed goldens above are what travels).
 
@@ -646,7 +682,7 @@ if __name__ == "__main__":
     if a.sweep:
         sweep(HERE, *a.sweep)
         sys.exit(0)
-    todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg, sedit=gen_sedit)
+    todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg, sedit=gen_sedit, average=gen_average)
     for k, f in todo.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -171,3 +171,51 @@ def test_sedit_driver_span_arithmetic_matches_reference():
         assert torch.equal(sedit.splice_feat_gen(parts), O.sedit_splice_feat_gen(parts))
     a, b = np.arange(3000.0), -np.arange(6000.0)
     assert np.array_equal(sedit.replace_waveform(a, b, 300, [2, 5], [1, 9]), O.sedit_replace_waveform(a, b, 300, [2, 5], [1, 9]))
+
+
+def test_checkpoint_average_nbest_matches_reference(tmp_path):
+    """a3t_amd.checkpoint.average_nbest_models against the reference function's own result on five epoch files
+    (tests/golden/average.npz): the 3-best mean bit-exact (same accumulation order), integer entries summed, the same
+    files and symlinks; then save_checkpoint / resume round trip with the reference's file names."""
+    from a3t_amd import checkpoint as ck
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "average.npz"))
+    rep = ck.EpochReport()
+    for e, v in g["losses"]:
+        e = int(e)
+        st = {k.split(".", 2)[2]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"in.{e}.")}
+        torch.save(st, tmp_path / f"{e}epoch.pth")
+        rep.set_epoch(e)
+        rep.register("valid", {"loss": v})
+        rep.register("train", {"loss": 2 * v})
+    ck.average_nbest_models(tmp_path, rep, [("valid", "loss", "min")], [1, 3, 9])
+    assert sorted(p.name for p in tmp_path.iterdir()) == list(g["files"])
+    links = sorted(f"{p.name}->{os.readlink(p)}" for p in tmp_path.iterdir() if p.is_symlink())
+    assert links == list(g["links"])
+    ave = torch.load(tmp_path / "valid.loss.ave_3best.pth")
+    for k, v in ave.items():
+        ref = g["out.ave3." + k]
+        assert v.numpy().dtype == ref.dtype and np.array_equal(v.numpy(), ref), k
+    assert int(ave["bn.num_batches_tracked"]) == 200 + 500 + 400          # the three best epochs: 2, 5, 4 (summed, not averaged)
+
+    class M:          # anything with the nn.Module state_dict contract
+        def __init__(self):
+            self.s = {"w": torch.arange(4.0)}
+
+        def state_dict(self):
+            return dict(self.s)
+
+        def load_state_dict(self, s):
+            self.s = dict(s)
+
+    m, out = M(), tmp_path / "exp"
+    r2 = ck.EpochReport()
+    for e, loss in ((1, 0.5), (2, 0.3), (3, 0.4)):
+        r2.set_epoch(e)
+        r2.register("valid", {"loss": loss})
+        m.s["w"] = m.s["w"] + 1
+        improved = ck.save_checkpoint(out, m, r2, e)
+        assert improved == (["valid.loss"] if e in (1, 2) else [])
+    assert os.readlink(out / "latest.pth") == "3epoch.pth" and os.readlink(out / "valid.loss.best.pth") == "2epoch.pth"
+    m2, r3 = M(), ck.EpochReport()
+    ck.resume(out / "checkpoint.pth", m2, r3)
+    assert torch.equal(m2.s["w"], m.s["w"]) and r3.get_epoch() == 3 and r3.stats == r2.stats
