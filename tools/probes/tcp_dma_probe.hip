@@ -10,6 +10,7 @@
 // mode 0: every workgroup streams its own 32 KiB per iteration (no reuse possible)
 // mode 1: 16 KiB shared by ALL workgroups (same addresses every iteration) + 16 KiB private
 // mode 2: 16 KiB shared by the 4 workgroups with the same (blockIdx.x & ~3) + 16 KiB private, addresses advance per iteration
+// mode 4: L2-resident working set (2 MiB): the L2 -> LDS DMA ceiling
 // mode 3: 16 KiB shared by the 4 workgroups of one CU (breadth-first dispatch: same XCD, same local index % 32)
 __global__ __launch_bounds__(256, 4) void probe(const unsigned char* src, size_t span, int iters, int mode, unsigned int* hw) {
     extern __shared__ unsigned char smem[];
@@ -31,6 +32,9 @@ __global__ __launch_bounds__(256, 4) void probe(const unsigned char* src, size_t
         } else if (mode == 2) {
             a_off = ((size_t)(blockIdx.x >> 2) * iters + it) * 16384 % (span / 2);
             b_off = span / 2 + ((size_t)blockIdx.x * iters + it) * 16384 % (span / 2);
+        } else if (mode == 4) {   // mode 4: everything hits the L2: 32 KiB per iteration out of a 2 MiB window
+            a_off = (((size_t)blockIdx.x * 7 + it) * 32768) % ((size_t)2 << 20);
+            b_off = a_off + 16384;
         } else {   // mode 3: shared by the workgroups that sit on the same CU: same XCD (blockIdx % 8), same (local index % 32)
             const int xcd = blockIdx.x & 7, cu = (blockIdx.x >> 3) & 31;
             a_off = ((size_t)(xcd * 32 + cu) * iters + it) * 16384 % (span / 2);
