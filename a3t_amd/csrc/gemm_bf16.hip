@@ -36,6 +36,13 @@ __device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 
+// -DGLDS_TIMING (A3T_EXTRA_FLAGS): per-workgroup phase times of the single-buffer K loop (tools/glds_timing.py)
+#ifdef GLDS_TIMING
+__device__ unsigned long long glds_dbg[16384 * 8];
+extern "C" int a3t_debug_read_glds(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glds_dbg), bytes); }
+#define GT_NOW() __builtin_readcyclecounter()
+#endif
+
 // CONV = 0: plain GEMM (taps == 1, no token shift): the im2col / shift bookkeeping is compiled out, which brings the
 // single-buffer variant under 128 VGPRs -> 4 workgroups per CU (1024 slots: the 840-tile N = 384 GEMMs run in one round)
 // CONV = 1: conv / data-gradient GEMM whose channel count is a multiple of BK (one tap per K-tile, uniform tracking only);
@@ -312,12 +319,32 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
 
     if (STAGES == 2) issue(kt0 * BK, 0);
     int stage = 0;
+#ifdef GLDS_TIMING
+    unsigned long long gt_war = 0, gt_iss = 0, gt_dma = 0, gt_bar = 0, gt_mma = 0, gt_start = GT_NOW(), gt_t = gt_start;
+#define GT_LAP(acc) do { __builtin_amdgcn_sched_barrier(0); unsigned long long n_ = GT_NOW(); acc += n_ - gt_t; gt_t = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
     for (int kt = kt0; kt < kt1; ++kt) {
+#ifdef GLDS_TIMING
+        if (STAGES == 1) {
+            GT_LAP(gt_mma);                   // ds_reads + MFMA issue of the previous tile
+            if (kt > kt0) asm volatile("s_barrier" ::: "memory");
+            GT_LAP(gt_war);
+            issue(kt * BK, 0);
+            GT_LAP(gt_iss);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            GT_LAP(gt_dma);
+            asm volatile("s_barrier" ::: "memory");
+            GT_LAP(gt_bar);
+        } else {
+            __syncthreads();
+        }
+#else
         if (STAGES == 1) {
             if (kt > kt0) __syncthreads();   // WAR: every wave is done reading the previous tile
             issue(kt * BK, 0);
         }
         __syncthreads();  // drains this tile's DMA (vmcnt(0) precedes the barrier) + WAR on the other stage
+#endif
         if (STAGES == 2 && kt + 1 < kt1) issue((kt + 1) * BK, stage ^ 1);
         const unsigned char* sA = smem + stage * STAGE_BYTES;
         const unsigned char* sB = sA + A_BYTES;
@@ -340,6 +367,15 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
         }
         if (STAGES == 2) stage ^= 1;
     }
+#ifdef GLDS_TIMING
+    if (STAGES == 1) {
+        GT_LAP(gt_mma);
+        if (tid == 0) {
+            unsigned long long* d = glds_dbg + (blockIdx.x % 16384) * 8;
+            d[0] = gt_war, d[1] = gt_iss, d[2] = gt_dma, d[3] = gt_bar, d[4] = gt_mma, d[5] = gt_start, d[6] = gt_t, d[7] = kt1 - kt0;
+        }
+    }
+#endif
     // (WN = 3 is dispatched with the vector epilogue only: host contract)
     if (WN == 2 && (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC)) {   // coalesced 128-B atomic rows straight from the accumulators
 #pragma unroll

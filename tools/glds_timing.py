@@ -1,5 +1,6 @@
 """Where a K-step of the single-buffer direct-to-LDS GEMM spends its time (needs a build with -DGLDS_TIMING:
-A3T_EXTRA_FLAGS=-DGLDS_TIMING python a3t_amd/build.py --force).  s_memtime ticks at 100 MHz."""
+A3T_EXTRA_FLAGS=-DGLDS_TIMING python a3t_amd/build.py --force).  The tick unit of the cycle counter is not calibrated:
+read the PERCENTAGES (measured: DMA issue 39 %, DMA wait 18 %, barriers 8 %, ds_read + MFMA issue 35 % of a K-step)."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
