@@ -2,7 +2,7 @@
 missing: there is no CPU fallback anywhere in the product path."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 # torch ships its own libamdhip64.so; it must be the HIP runtime already resident in the process
 # when liba3t_hip.so is dlopen'ed, otherwise the kernels would launch on a second, device-less

@@ -6,8 +6,7 @@ numpy global RNG, segment ids) is inherently host-side in the reference too (Dat
 it is restated here in vectorised numpy.  Feature extraction (STFT -> mel -> log10) runs on the
 GPU through liba3t_hip (a3t_amd/features.py) when a device is given.
 """
-import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch

@@ -1,8 +1,8 @@
 """Hyper-parameters of the A3T masked-mel model (host-side mirror of what
 MLMTask.build_model reads from the recipe yaml: espnet2/tasks/mlm.py:328-443,
 egs2/vctk/sedit/conf/fsp2_conformer.yaml:27-75)."""
-from dataclasses import dataclass, field
-from typing import Any, Dict, Tuple
+from dataclasses import dataclass
+from typing import Any, Dict
 
 
 @dataclass

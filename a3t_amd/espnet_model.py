@@ -10,7 +10,7 @@ espnet2/train/abs_espnet_model.py:9-42), same ``state_dict`` keys/shapes, so
 There is no CPU execution path: calling forward without the HIP library / a GPU raises.
 """
 from collections import OrderedDict
-from typing import Dict, List, Optional, Tuple, Union
+from typing import Dict, List, Tuple, Union
 
 import torch
 

@@ -8,9 +8,8 @@ mirrored is the generic AbsTask control plane (samplers, scp readers, reporters)
 import argparse
 import logging
 from pathlib import Path
-from typing import Callable, Collection, Dict, List, Optional, Tuple, Union
+from typing import Callable, Tuple, Union
 
-import numpy as np
 import torch
 import yaml
 

@@ -10,9 +10,7 @@ hooks, the flat fp32 gradient buffer is reduced in a few large contiguous bucket
 stream as soon as the backward schedule has finished the parameter range each one covers
 (decoder blocks first), so the xGMI transfer overlaps the rest of the backward pass.
 """
-import math
-import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Sequence
 
 import torch
 import torch.distributed as dist

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import ACT_NONE, ACT_RELU, F32
+from ._lib import ACT_RELU, F32
 
 
 class ParallelWaveGANGeneratorHIP:

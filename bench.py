@@ -11,7 +11,6 @@ Prints ONE JSON line on rank 0.  The CPU oracle is imported only for the cpu_bas
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
