@@ -365,7 +365,7 @@ static void launch_t256(const GP& pv, dim3 grid, hipStream_t stream) {
     constexpr int lds = 2 * 4 * 128 * 64 * 2;   // 128 KiB
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)gemm_bf16_t256_kernel<LY, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_t256_kernel<LY, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr = true;
     }
     hipLaunchKernelGGL((gemm_bf16_t256_kernel<LY, CV>), grid, dim3(512), lds, stream, pv);
