@@ -56,6 +56,8 @@ _SIGS = {
                                c_float, ctypes.c_uint32, _P],
     "a3t_relpos_softmax_bwd": [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
                                c_float, _P],
+    "a3t_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
+                     c_float, c_float, ctypes.c_uint32, _P],
     "a3t_pwg_block": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_mask_fill": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint32,
@@ -76,6 +78,8 @@ _SIGS = {
     "a3t_sumsq": [_P, c_int64, _P, _P],
     "a3t_clip_adam": [_P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int, c_float, c_float,
                       _P],
+    "a3t_clip_adam_noam": [_P, _P, _P, _P, _P, _P, c_int64, _P, c_float, c_float, c_float, c_float, c_float, c_float,
+                           c_float, c_float, _P],
     "a3t_pwg_gate": [_P, _P, _P, c_int64, c_int, _P],
     "a3t_pwg_res_skip": [_P, _P, _P, c_int64, c_int, c_int, _P],
     "a3t_pwg_upsample": [_P, _P, _P, c_int64, c_int, c_int, _P],

@@ -204,8 +204,12 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(const float* __restri
         cnt += 1.f;
         for (int c = lane; c < C; c += 64) {
             int64_t i = (int64_t)row * C + c;
-            float y = target[i], d0 = before[i] - y, d1 = after[i] - y;
-            s += l2 ? (d0 * d0 + d1 * d1) : (fabsf(d0) + fabsf(d1));
+            float y = target[i], d0 = before[i] - y;
+            s += l2 ? d0 * d0 : fabsf(d0);
+            if (after) {   // (sedit_model.py:333-337: the after-postnet term only exists when there is a postnet)
+                float d1 = after[i] - y;
+                s += l2 ? d1 * d1 : fabsf(d1);
+            }
         }
     }
 #pragma unroll
@@ -254,7 +258,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ before, const float* 
         int64_t r = i / C;
         float g0 = 0.f, g1 = 0.f;
         if (masked[r]) {
-            float y = target[i], d0 = before[i] - y, d1 = after[i] - y;
+            float y = target[i], d0 = before[i] - y, d1 = after ? after[i] - y : 0.f;
             if (l2) {
                 g0 = 2.f * d0 * k;
                 g1 = 2.f * d1 * k;
@@ -264,7 +268,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ before, const float* 
             }
         }
         db[i] = g0;
-        da[i] = g1;
+        if (da) da[i] = g1;
     }
 }
 extern "C" int a3t_mlm_loss_scratch_floats(int M) {
@@ -280,7 +284,7 @@ extern "C" int a3t_mlm_loss(const float* before, const float* after, const float
     hipLaunchKernelGGL(loss_partial_kernel, dim3(nblk), dim3(256), 0, s, before, after, target, masked, scratch, M, C,
                        l2);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, scratch, loss_out, nblk);
-    if (d_before && d_after) {
+    if (d_before && (d_after || !after)) {
         int64_t n = (int64_t)M * C;
         hipLaunchKernelGGL(loss_grad_kernel, dim3(nblocks(n)), dim3(256), 0, s, before, after, target, masked, scratch,
                            d_before, d_after, n, C, l2, gscale);
@@ -351,6 +355,57 @@ extern "C" int a3t_clip_adam(float* p, const float* g, float* m, float* v, const
     float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(clip_adam_kernel, dim3(nblocks(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, partial,
                        norm_out, n, lr, beta1, beta2, eps, bc1, bc2s, clip, gscale);
+    return (int)hipGetLastError();
+}
+
+// Same update with the optimizer step count and the Noam learning rate kept ON THE DEVICE: state[0] = number of updates
+// applied so far, state[1] = number of skipped (non-finite gradient norm) steps.  A skipped step advances neither Adam's
+// bias correction nor the LR schedule (trainer.py:640-679: optimizer.step() and scheduler.step() are both skipped), and
+// the host never has to read the norm back.
+__global__ __launch_bounds__(256) void clip_adam_noam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ m, float* __restrict__ v,
+                                                             const double* partial, float* norm_out, int64_t n,
+                                                             const int* state, float base_lr, float model_size,
+                                                             float warmup, float b1, float b2, float eps, float clip,
+                                                             float gscale) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < SUMSQ_BLOCKS; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float norm = (float)sqrt(red[0]) * fabsf(gscale);
+    if (blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+    if (!isfinite(norm)) return;
+    const double t = (double)(state[0] + 1);
+    // NoamLR.get_lr (schedulers/noam_lr.py:58-65), torch.optim.Adam bias corrections
+    const float lr = (float)((double)base_lr * pow((double)model_size, -0.5) * fmin(pow(t, -0.5), t * pow((double)warmup, -1.5)));
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float bc2s = (float)sqrt(1.0 - pow((double)b2, t));
+    float coef = clip > 0.f ? clip / (norm + 1e-6f) : 1.f;
+    coef = (coef > 1.f ? 1.f : coef) * gscale;
+    const float step_size = lr / bc1;
+    GRID_STRIDE(i, n) {
+        float gi = g[i] * coef;
+        float mi = m[i] * b1 + (1.f - b1) * gi;
+        float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+__global__ void adam_state_advance_kernel(const float* norm, int* state) {
+    if (isfinite(norm[0])) state[0] += 1; else state[1] += 1;
+}
+extern "C" int a3t_clip_adam_noam(float* p, const float* g, float* m, float* v, const double* partial, float* norm_out,
+                                  int64_t n, int* state, float base_lr, float model_size, float warmup, float beta1,
+                                  float beta2, float eps, float clip, float gscale, void* stream) {
+    hipLaunchKernelGGL(clip_adam_noam_kernel, dim3(nblocks(n, 2048)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       partial, norm_out, n, state, base_lr, model_size, warmup, beta1, beta2, eps, clip, gscale);
+    hipLaunchKernelGGL(adam_state_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, norm_out, state);
     return (int)hipGetLastError();
 }
 

@@ -94,6 +94,10 @@ class MLMEngine:
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
         self.colsum_slots = int(os.environ.get("A3T_COLSUM_SLOTS", "16"))   # spread of the attention bias-gradient atomics
         self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
+        # bf16 mode: the first postnet conv reads `before` (log-mel scale, |x| ~ 4: one bf16 ulp = 0.03) -- running that
+        # one K = 5*80 GEMM (and its two gradients) on the exact-fp32 MFMA keeps the BatchNorm-amplified rounding of the
+        # postnet input out of `after` for ~0.1 ms per step
+        self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -566,16 +570,18 @@ class MLMEngine:
         before = ws.get("head.before", (B * Tm, c.odim))
         ops.linear_fwd(hs, self.W("sfc.w"), before, bias=p["sfc.b"], compute=self.cmp)
         y = before
-        if self.bf16 and c.postnet_layers > 0:
+        f32_first = self.bf16 and self.post_f32_first
+        if self.bf16 and c.postnet_layers > 0 and not f32_first:
             y = ws.get("head.before16", (B * Tm, c.odim), torch.bfloat16)
             ops.cast_bf16(before, y)
         pad = (c.postnet_filts - 1) // 2
         for l in range(c.postnet_layers):
-            W = self.W(f"post.{l}.w")
+            f32l = f32_first and l == 0
+            W = p[f"post.{l}.w"] if f32l else self.W(f"post.{l}.w")
             oc = W.shape[0]
             last = (l == c.postnet_layers - 1)
             z = ws.get(f"post.{l}.z", (B * Tm, oc))
-            ops.conv_fwd(y, W, z, Tm, pad, compute=self.cmp)
+            ops.conv_fwd(y, W, z, Tm, pad, compute=F32 if f32l else self.cmp)
             o = ws.get(f"post.{l}.o", (B * Tm, oc), torch.float32 if last else self.adt)
             self._bn_fwd(f"post.{l}", z, f"post.{l}.bn", f"post.{l}.bn", ACT_NONE if last else ACT_TANH, o)
             pdr = self._drop(c.postnet_dropout_rate, f"post.{l}")
@@ -588,14 +594,15 @@ class MLMEngine:
             after.copy_(before)
             ops.axpy(y, after, 1.0)
         else:
-            after = before
+            after = None          # no postnet: the loss has no after-term (sedit_model.py:333-337), after_outs = before_outs
         loss = ws.get("head.loss", (1,))
         scratch = ws.get("head.lscratch", (ops.loss_scratch_floats(B * Tm),))
         db = ws.get("head.dbefore", (B * Tm, c.odim)) if need_grad else None
-        da = ws.get("head.dafter", (B * Tm, c.odim)) if need_grad else None
+        da = ws.get("head.dafter", (B * Tm, c.odim)) if (need_grad and after is not None) else None
         ops.mlm_loss(before, after, speech2, masked, loss, db, da, scratch, l2=c.lsm_weight > 50, gscale=gscale)
         self.sv["head"] = (hs, before, after, db, da)
-        return dict(loss=loss, before=before.view(B, Tm, c.odim), after=after.view(B, Tm, c.odim))
+        return dict(loss=loss, before=before.view(B, Tm, c.odim),
+                    after=(after if after is not None else before).view(B, Tm, c.odim))
 
     def backward(self, on_group_done=None):
         """Accumulates d loss / d param (times the gscale given to forward) into store.grad.
@@ -617,7 +624,8 @@ class MLMEngine:
         if c.postnet_layers > 0:
             g = da                                    # grad wrt last BN output (fp32)
             for l in reversed(range(c.postnet_layers)):
-                W = self.W(f"post.{l}.w")
+                f32l = self.bf16 and self.post_f32_first and l == 0
+                W = p[f"post.{l}.w"] if f32l else self.W(f"post.{l}.w")
                 oc = W.shape[0]
                 last = (l == c.postnet_layers - 1)
                 dz = ws.get(f"tmp.post.dz{oc}", (B * Tm, oc))
@@ -627,15 +635,16 @@ class MLMEngine:
                     ops.dropout(g, gd, *pdr)
                     g = gd
                 self._bn_bwd(f"post.{l}", g, f"post.{l}.bn", ACT_NONE if last else ACT_TANH, dz)
-                if self.bf16:
+                if self.bf16 and not f32l:
                     dz16 = ws.get(f"tmp.post.dz16.{oc}", (B * Tm, oc), torch.bfloat16)
                     ops.cast_bf16(dz, dz16)
                     dz = dz16
                 yin = self.sv[f"post.{l}"]
                 ic = yin.shape[1]
-                ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=cmp)
+                lc = F32 if f32l else cmp
+                ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=lc)
                 gi = ws.get(f"tmp.post.g{l % 2}.{ic}", (B * Tm, ic))
-                ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=cmp)
+                ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=lc)
                 g = gi
             ops.axpy(da, db, 1.0)                     # after = before + postnet(before)
             ops.axpy(g, db, 1.0)

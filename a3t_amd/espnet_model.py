@@ -55,6 +55,9 @@ class ESPnetMLMEncAsDecoderModel(torch.nn.Module):
         self.normalize = normalize            # stored, never applied (sedit_model.py:79)
         self.cfg = config
         self.compute = compute
+        # torch.nn.Dropout semantics: the recipe's dropout sites are active in train() mode, off in eval() mode
+        # (dropout=False builds a deterministic training engine: parity tests, finite-difference checks)
+        self.dropout = bool(model_conf.get("dropout", True))
         self.mlm_prob = model_conf.get("mlm_prob", config.mlm_prob)
         self.mean_phn_span = model_conf.get("mean_phn_span", config.mean_phn_span)
         self.masking_schema = model_conf.get("masking_schema", "phn_span")
@@ -95,7 +98,8 @@ class ESPnetMLMEncAsDecoderModel(torch.nn.Module):
         from .engine import MLMEngine
         key = self.training
         if key not in self._eng:
-            self._eng[key] = MLMEngine(self.cfg, self.store, compute=self.compute, training=self.training)
+            self._eng[key] = MLMEngine(self.cfg, self.store, compute=self.compute, training=self.training,
+                                       dropout=self.dropout and self.training)
             if (not key) in self._eng:       # share activation buffers between train / eval schedules
                 self._eng[key].ws = self._eng[not key].ws
         return self._eng[key]

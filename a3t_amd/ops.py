@@ -236,6 +236,21 @@ def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, 
             "softmax_bwd")
 
 
+def attn_fused_supported(dk, T):
+    return dk % 32 == 0 and dk <= 192 and dk != 160 and T % 8 == 0
+
+
+def attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=(0.0, 0)):
+    """Fused legacy rel-pos attention forward: ctx[b, :, h, :] = dropout(softmax(((q+u) k^T + shift((q+v) P^T)) * scale)) v.
+    qu / qv / ctx [B*T][d], qkv [B*T][3d] (q | k | v), P [T][d], all bf16; lse [B][H][T] fp32."""
+    d = qu.shape[1]
+    dk = d // H
+    kk = qkv.view(-1)[d:]
+    vv = qkv.view(-1)[2 * d:]
+    L.check(L.load().a3t_attn_fwd(_ptr(qu), _ptr(qv), _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(ctx), _ptr(lse),
+                                  B, H, T, dk, d, 3 * d, d, d, scale, drop[0], drop[1], _stream()), "attn_fwd")
+
+
 def mask_fill(speech, masked, mask_feature, out):
     M, C = out.shape
     L.check(L.load().a3t_mask_fill(_ptr(speech), _ptr(masked), _ptr(mask_feature), _ptr(out), _dt(out), M, C,
@@ -308,6 +323,14 @@ def sumsq(g, partial):
 def clip_adam(p, g, m, v, partial, norm_out, lr, step, clip=1.0, gscale=1.0, betas=(0.9, 0.999), eps=1e-8):
     L.check(L.load().a3t_clip_adam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(partial), _ptr(norm_out), p.numel(), lr,
                                    betas[0], betas[1], eps, step, clip, gscale, _stream()), "clip_adam")
+
+
+def clip_adam_noam(p, g, m, v, partial, norm_out, state, base_lr, model_size, warmup, clip=1.0, gscale=1.0,
+                   betas=(0.9, 0.999), eps=1e-8):
+    """clip + Adam + NoamLR with the step counter on the device (state int32[2]: applied, skipped)."""
+    L.check(L.load().a3t_clip_adam_noam(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(partial), _ptr(norm_out), p.numel(),
+                                        _ptr(state), base_lr, float(model_size), float(warmup), betas[0], betas[1], eps,
+                                        clip, gscale, _stream()), "clip_adam_noam")
 
 
 def pwg_gate(y, c, out):

@@ -76,14 +76,31 @@ def bucket_ranges(total: int, boundaries: Sequence[int], min_elems: int) -> List
 
 
 class FlatAllReduce:
-    """Bucketed all-reduce of one flat gradient buffer on a side stream."""
+    """Bucketed all-reduce of one flat gradient buffer on a side stream.
 
-    def __init__(self, flat_grad: torch.Tensor, ranges: List[tuple]):
+    comm_dtype=torch.bfloat16 halves the bytes on the xGMI links: each bucket is cast into a bf16 staging buffer,
+    reduced, and cast back into the fp32 gradient (the optimizer state stays fp32).  The sum over ranks is then
+    carried out in bf16 by RCCL, so this is an opt-in throughput knob, not the default."""
+
+    def __init__(self, flat_grad: torch.Tensor, ranges: List[tuple], comm_dtype=torch.float32):
         self.g = flat_grad
         self.ranges = ranges
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         self.works = []
+        self.comm_dtype = comm_dtype
+        self.stage = None
+        if comm_dtype != torch.float32:
+            self.stage = torch.empty(flat_grad.numel(), dtype=comm_dtype, device=flat_grad.device)
+        self.bytes_per_step = sum(hi - lo for lo, hi in ranges) * (2 if comm_dtype == torch.bfloat16 else 4)
+
+    def _reduce(self, lo, hi):
+        if self.stage is None:
+            self.works.append((dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True), None))
+        else:
+            st = self.stage[lo:hi]
+            st.copy_(self.g[lo:hi])
+            self.works.append((dist.all_reduce(st, op=dist.ReduceOp.SUM, async_op=True), (lo, hi)))
 
     def reduce_range(self, i: int):
         """Call when backward has finished writing range i (on the current stream)."""
@@ -93,13 +110,19 @@ class FlatAllReduce:
             ev.record()
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                self._reduce(lo, hi)
         else:
-            self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._reduce(lo, hi)
 
     def wait(self):
-        for w in self.works:
+        for w, rng in self.works:
             w.wait()
+            if rng is not None:            # cast the reduced bucket back into the fp32 gradient
+                if self.cuda:
+                    with torch.cuda.stream(self.stream):
+                        self.g[rng[0]:rng[1]].copy_(self.stage[rng[0]:rng[1]])
+                else:
+                    self.g[rng[0]:rng[1]].copy_(self.stage[rng[0]:rng[1]])
         self.works = []
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -114,7 +137,7 @@ class A3TTrainer:
 
     def __init__(self, cfg: A3TConfig, store, compute="bf16", lr=1.0, warmup_steps=4000, grad_clip=1.0,
                  betas=(0.9, 0.999), eps=1e-8, overlap=True, dropout=True, force_reducer=False,
-                 bucket_min_elems=16 * 1024 * 1024):
+                 bucket_min_elems=16 * 1024 * 1024, comm_dtype=torch.float32):
         from .engine import MLMEngine
         self.cfg, self.store = cfg, store
         self.engine = MLMEngine(cfg, store, compute=compute, training=True, dropout=dropout)
@@ -123,7 +146,11 @@ class A3TTrainer:
         self.v = torch.zeros_like(store.flat)
         self.partial = torch.zeros(1024, dtype=torch.float64, device=dev)
         self.norm = torch.zeros(1, device=dev)
-        self.step_no = 0
+        self.step_no = 0          # host mirror = number of step() calls that reached the optimizer
+        # device-resident optimizer clock: [updates applied, steps skipped for a non-finite gradient norm].  Adam's bias
+        # correction and the Noam schedule advance only with applied updates (trainer.py:640-679), without a host sync.
+        self.opt_state = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.comm_dtype = comm_dtype
         self.lr, self.warmup, self.clip, self.betas, self.eps = lr, warmup_steps, grad_clip, betas, eps
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.reducer = None
@@ -138,28 +165,53 @@ class A3TTrainer:
             bounds += [store.offsets["sfc.w"][0]]
             self.ranges = bucket_ranges(store.total, bounds, bucket_min_elems)   # default: >= 64 MB fp32 per collective
             if overlap:
-                self.reducer = FlatAllReduce(store.grad, self.ranges)
+                self.reducer = FlatAllReduce(store.grad, self.ranges, comm_dtype)
 
-    def step(self, batch: Dict[str, torch.Tensor], weight_scale: float = 1.0) -> torch.Tensor:
+    def step(self, batch: Dict[str, torch.Tensor], total_weight: float = None, accum_grad: int = 1,
+             accum_index: int = 0) -> torch.Tensor:
+        """One iteration of the trainer loop body.
+
+        total_weight: sum over ALL ranks of the batch weights (= utterance counts, AbsESPnetModel contract) of this
+        global mini-batch.  Every rank iterates the same global batch list and takes ``batch[rank::world]``
+        (abs_task.py:1504-1513), so the total is known on the host without a collective; the loss of this rank is
+        scaled by w_r / total * world before backward and the summed gradient divided by world afterwards
+        (trainer.py:583-595 + DDP averaging).  None = equal weights on every rank (scale 1).
+        accum_grad / accum_index: gradient accumulation (trainer.py:597, 610-679): micro-step 0 clears the gradient
+        buffer, every micro-step adds loss/accum_grad gradients, only the last one all-reduces and updates."""
         from . import ops
-        self.step_no += 1
         st = self.store
-        st.zero_grad()
+        if accum_index == 0:
+            st.zero_grad()
         if self.engine.bf16:           # 16-byte DMA granules: extend the batch padding to T_mel, T % 8 == 0 (no-op if aligned)
             from .espnet_model import ESPnetMLMEncAsDecoderModel
             batch = ESPnetMLMEncAsDecoderModel._pad_to_dma_granule(batch)
-        out = self.engine.forward(batch, gscale=weight_scale)
-        if self.reducer is not None:
+        w = 1.0
+        if total_weight is not None:
+            w = grad_scale(float(batch["speech"].shape[0]), float(total_weight), self.world)
+        out = self.engine.forward(batch, gscale=w / accum_grad)
+        last = (accum_index == accum_grad - 1)
+        if self.reducer is not None and last:
             self._backward_overlapped()
         else:
             self.engine.backward()
-            if self.world > 1:
+            if self.world > 1 and last:
                 dist.all_reduce(st.grad)
-        lr = noam_lr(self.step_no, self.lr, self.cfg.adim, self.warmup)
+        if not last:
+            return out["loss"]
+        self.step_no += 1
         ops.sumsq(st.grad, self.partial)
-        ops.clip_adam(st.flat, st.grad, self.m, self.v, self.partial, self.norm, lr, self.step_no, clip=self.clip,
-                      gscale=1.0 / self.world, betas=self.betas, eps=self.eps)
+        ops.clip_adam_noam(st.flat, st.grad, self.m, self.v, self.partial, self.norm, self.opt_state, self.lr,
+                           self.cfg.adim, self.warmup, clip=self.clip, gscale=1.0 / self.world, betas=self.betas,
+                           eps=self.eps)
         return out["loss"]
+
+    def optimizer_steps(self):
+        """(updates applied, steps skipped because the gradient norm was not finite) -- reads the device clock (syncs)."""
+        a, sk = self.opt_state.tolist()
+        if sk:
+            import logging
+            logging.warning(f"{sk} step(s) had a non-finite gradient norm and were skipped (trainer.py:640-645)")
+        return a, sk
 
     def _backward_overlapped(self):
         """Backward with per-range all-reduce hooks: a range is reduced once the schedule has moved
@@ -183,8 +235,9 @@ class A3TTrainer:
 
     # ---- checkpoint (trainer.py:366-388: checkpoint.pth = {model, optimizers, schedulers, ...}) ----
     def state(self):
-        return dict(model=self.store.state_dict(), optimizers=[dict(m=self.m.cpu(), v=self.v.cpu(), step=self.step_no)],
-                    schedulers=[dict(step=self.step_no, warmup_steps=self.warmup)], reporter=None, scaler=None)
+        applied = int(self.opt_state[0])
+        return dict(model=self.store.state_dict(), optimizers=[dict(m=self.m.cpu(), v=self.v.cpu(), step=applied)],
+                    schedulers=[dict(step=applied, warmup_steps=self.warmup)], reporter=None, scaler=None)
 
     def load_state(self, st):
         self.store.load_state_dict(st["model"])
@@ -192,3 +245,5 @@ class A3TTrainer:
         self.m.copy_(o["m"])
         self.v.copy_(o["v"])
         self.step_no = int(o["step"])
+        self.opt_state[0] = self.step_no
+        self.opt_state[1] = 0

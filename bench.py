@@ -1,6 +1,8 @@
 """bench.py -- A3T masked-mel training-step throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]         (N=1)
+    python bench.py [--gpus N --steps K --warmup W]         (N=1; N>1 without a launcher: bench.py starts the N
+                                                             ranks itself, one process per GPU, like the reference's
+                                                             mp.spawn in espnet2/tasks/abs_task.py:1026-1045)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = forward + loss + full backward + (RCCL gradient all-reduce if N>1) + grad-norm/clip/Adam
@@ -41,7 +43,7 @@ def fwd_flops_per_step(c, B, Tm, Tp):
     return blocks + head
 
 
-def build_trainer(cfg, device, compute, world, dropout=True):
+def build_trainer(cfg, device, compute, world, dropout=True, comm_dtype=torch.float32):
     """A3TTrainer = the step body of Trainer.train_one_epoch (espnet2/train/trainer.py:528-703) on flat
     buffers; recipe init except BatchNorm gamma = 1 so that no GEMM runs on an all-zero operand."""
     from a3t_amd.init import xavier_init_
@@ -49,7 +51,8 @@ def build_trainer(cfg, device, compute, world, dropout=True):
     from a3t_amd.trainer import A3TTrainer
     store = ParamStore(cfg, device)
     xavier_init_(store, seed=0, bn_gamma=1.0)
-    return A3TTrainer(cfg, store, compute=compute, lr=1.0, warmup_steps=4000, grad_clip=1.0, dropout=dropout)
+    return A3TTrainer(cfg, store, compute=compute, lr=1.0, warmup_steps=4000, grad_clip=1.0, dropout=dropout,
+                      comm_dtype=comm_dtype)
 
 
 def vocoder_rtf(dev, B=8, Tf=1000, reps=3):
@@ -215,6 +218,45 @@ def cpu_baseline(blocks, Tm, Tp, budget_s=20.0, hard_timeout_s=150.0):
                     sample=f"cpu baseline did not finish within {hard_timeout_s:.0f}s ({type(e).__name__})")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _spawned_rank(local_rank, n, port, argv):
+    """Entry of one self-launched rank (torch.multiprocessing.spawn): the same environment a launcher would set."""
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.argv = argv
+    main()
+
+
+def fake_cpu_rank(a, rank, world):
+    """--fake-cpu: the launch / rendezvous / max-over-ranks / JSON plumbing of an N-rank run on the gloo backend with
+    a trivial step (one SUM all-reduce of a small CPU tensor).  No kernels, no oracle: a CPU test of the N>1 launch path
+    only (tests/test_distributed_cpu.py); its numbers mean nothing and the line says so."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.full((1024,), float(rank + 1))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dist.all_reduce(g.clone())
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    chk = torch.tensor([float(rank + 1)])
+    dist.all_reduce(chk)
+    if rank == 0:
+        print(json.dumps({"metric": "mel-frames/sec (train)", "value": None, "unit": "mel-frames/s",
+                          "n_gpus": world, "dist_world_size": dist.get_world_size(), "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": float(t) / max(a.steps, 1) * 1e3, "fake_cpu": True,
+                          "rank_sum": float(chk), "data": "none (launch-path test, gloo, no kernels)"}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,6 +274,8 @@ def main():
     ap.add_argument("--no-collate", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--fake-cpu", action="store_true", help="N-rank launch-path test on gloo/CPU (no kernels)")
+    ap.add_argument("--comm-dtype", default="f32", choices=["f32", "bf16"], help="gradient all-reduce bucket dtype")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -242,11 +286,21 @@ def main():
         print(json.dumps(cpu_baseline(a.blocks, a.tmel, a.tphn, a.budget)))
         return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N ranks here (one process per GPU), rank 0 prints the JSON line
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned_rank, args=(a.gpus, _free_port(), list(sys.argv)), nprocs=a.gpus, join=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.fake_cpu:
+        fake_cpu_rank(a, rank, world)
+        return
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -263,7 +317,8 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     log("building trainer")
-    tr = build_trainer(cfg, dev, a.compute, world, dropout=not a.no_dropout)
+    tr = build_trainer(cfg, dev, a.compute, world, dropout=not a.no_dropout,
+                       comm_dtype=torch.bfloat16 if a.comm_dtype == "bf16" else torch.float32)
     batch = synthetic_batch(cfg, B, Tm, Tp, seed=1234 + rank, device=dev)
     log(f"params {tr.store.n_params}; warm-up")
 
@@ -292,6 +347,27 @@ def main():
     final_loss = float(loss)
     log(f"{ms:.1f} ms/step, {value:.0f} frames/s, loss {final_loss:.4f}")
 
+    comm = None
+    if world > 1:
+        # the gradient exchange alone: the flat buffer in the trainer's buckets, 3 repetitions; bus bandwidth as
+        # RCCL defines it for all-reduce: 2 (N-1)/N x bytes / time (what each xGMI link pair has to carry)
+        gbuf = torch.zeros_like(tr.store.grad) if tr.comm_dtype == torch.float32 else \
+            torch.zeros(tr.store.grad.numel(), dtype=tr.comm_dtype, device=dev)
+        rngs = getattr(tr, "ranges", [(0, gbuf.numel())])
+        for lo, hi in rngs:
+            dist.all_reduce(gbuf[lo:hi])
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            for lo, hi in rngs:
+                dist.all_reduce(gbuf[lo:hi])
+        sync()
+        tc = (time.perf_counter() - t1) / 3
+        nbytes = gbuf.numel() * gbuf.element_size()
+        comm = dict(backend=dist.get_backend(), dist_world_size=dist.get_world_size(), bytes_per_step=nbytes,
+                    buckets=len(rngs), dtype=a.comm_dtype, allreduce_ms_alone=tc * 1e3,
+                    algbw_GBps=nbytes / tc / 1e9, busbw_GBps=2.0 * (world - 1) / world * nbytes / tc / 1e9)
+        del gbuf
     roofline = None
     if not a.no_kernel_profile:      # every rank runs the two extra steps (they contain collectives when world > 1)
         def gemm_profile():
@@ -349,6 +425,8 @@ def main():
                        "hbm_allocated_gb": torch.cuda.max_memory_allocated(dev) / 1e9},
             "roofline": roofline,
         }
+        if comm is not None:
+            out["comm"] = comm
         if world == 1 and not a.no_vocoder:
             log("vocoder leg (ParallelWaveGAN v1, 8 x 1000 frames)")
             out["vocoder"] = vocoder_rtf(dev)

@@ -167,6 +167,18 @@ int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprob
                            void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
                            float scale, const void* probs_drop, float drop_p, void* stream);
 
+/* Fused legacy relative-position attention, bf16 operands (LegacyRelPositionMultiHeadedAttention.forward,
+ * transformer/attention.py:167-209 incl. rel_shift :145-165 and forward_attention :64-96): one launch replaces the
+ * ac / bd GEMMs, a3t_relpos_softmax_fwd and the probs @ V GEMM; no (T, T) tensor is written.
+ *   qu, qv [B*T][ldq] = q + pos_bias_{u,v};  k, v [B*T][ldkv];  pos [T][ldp] = linear_pos(pos_emb);  head h occupies
+ *   columns h*dk .. h*dk+dk-1 of every operand;  keymask uint8 [B][T];  ctx out [B*T][ldo] (bf16);
+ *   lse out [B][H][T] fp32: log sum_j exp(scaled score) per query (+inf for a fully masked row), kept for backward.
+ * drop_p / drop_key: attention dropout with the same counter RNG and element index ((b*H+h)*T+i)*T+j as
+ * a3t_relpos_softmax_fwd's probs_drop.  dk in {32, 64, 96, 128, 192}, T % 8 == 0; A3T_EINVAL otherwise. */
+int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos, const uint8_t* keymask,
+                 void* ctx, float* lse, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo,
+                 float scale, float drop_p, uint32_t drop_key, void* stream);
+
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
 int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,
                   int out_dtype, int M, int C, void* stream);
@@ -200,7 +212,8 @@ int a3t_logmel_finish(float* mel, const int64_t* olens, int B, int F, int C, voi
 
 /* Masked L1/L2 loss (sedit_model.py:320-340).  scratch: float[2 + nblk*2].
  * loss_out[0] = sum_masked(|before-y|+|after-y|)/(n_masked+1e-10); d_before/d_after = gradients
- * times gscale (may be NULL for no-grad). */
+ * times gscale (may be NULL for no-grad).  after == NULL: model without a postnet -- the second term is absent
+ * (sedit_model.py:333-337) and d_after is not written. */
 int a3t_mlm_loss(const float* before, const float* after, const float* target, const uint8_t* masked,
                  float* loss_out, float* d_before, float* d_after, float* scratch, int M, int C, int l2,
                  float gscale, void* stream);
@@ -213,6 +226,13 @@ int a3t_sumsq(const float* g, int64_t n, double* partial /*[1024]*/, void* strea
 int a3t_clip_adam(float* p, const float* g, float* m, float* v, const double* partial, float* norm_out,
                   int64_t n, float lr, float beta1, float beta2, float eps, int step, float clip,
                   float gscale, void* stream);
+
+/* The same update with the step count on the device: state = int32[2] {updates applied, steps skipped}; the Noam
+ * learning rate (base_lr * model_size^-0.5 * min(t^-0.5, t * warmup^-1.5), t = state[0]+1) and Adam's bias corrections
+ * are evaluated on the device, and a step whose gradient norm is not finite advances neither (trainer.py:640-679). */
+int a3t_clip_adam_noam(float* p, const float* g, float* m, float* v, const double* partial, float* norm_out, int64_t n,
+                       int32_t* state, float base_lr, float model_size, float warmup, float beta1, float beta2,
+                       float eps, float clip, float gscale, void* stream);
 
 /* ParallelWaveGAN helpers (espnet2/gan_tts/wavenet/residual_block.py:114-169,
  * parallel_wavegan/upsample.py:22-189), channels-last [T][C]. */

@@ -531,6 +531,8 @@ def model_forward(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], c:
     Tm = batch["speech"].shape[1]
     hs = xs[:, :Tm].contiguous()
     before = F.linear(hs, p["sfc.weight"], p["sfc.bias"])
+    if c.postnet_layers == 0:     # sedit_model.py:111-122, :369-374: no Postnet module -> after_outs is None
+        return before, None
     # Postnet (tacotron2/decoder.py:150-267), dropout p=0
     y = before.transpose(1, 2)
     for l in range(c.postnet_layers):
@@ -544,11 +546,12 @@ def model_forward(p: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], c:
 
 
 def mlm_loss(before, after, target, masked_position, c: A3TConfig):
-    """ESPnetMLMModel._calc_mlm_loss (sedit_model.py:320-340)."""
-    if c.lsm_weight > 50:
-        l = ((before - target) ** 2).sum(-1) + ((after - target) ** 2).sum(-1)
-    else:
-        l = (before - target).abs().sum(-1) + (after - target).abs().sum(-1)
+    """ESPnetMLMModel._calc_mlm_loss (sedit_model.py:320-340); the after-postnet term exists only when there is a
+    postnet (:331-333)."""
+    sq = c.lsm_weight > 50
+    l = ((before - target) ** 2).sum(-1) if sq else (before - target).abs().sum(-1)
+    if after is not None:
+        l = l + (((after - target) ** 2).sum(-1) if sq else (after - target).abs().sum(-1))
     m = masked_position.to(l.dtype)
     return (l * m).sum() / (m.sum() + 1e-10)
 

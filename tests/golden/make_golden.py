@@ -552,6 +552,69 @@ def gen_average(out):
     print("average.npz", files, links)
 
 
+def grad_sample_index(name, numel, n=256):
+    """Deterministic sample of flat indices of one parameter (shared with tests/test_gpu_parity_r2.py)."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return rs.randint(0, numel, size=min(n, numel))
+
+
+def _fwd_parts(model, batch):
+    return model._forward(dict(speech_pad=batch["speech"], text_pad=batch["text"],
+                               masked_position=batch["masked_position"], speech_mask=batch["speech_mask"],
+                               text_mask=batch["text_mask"], speech_segment_pos=batch["speech_segment_pos"],
+                               text_segment_pos=batch["text_segment_pos"]), batch["speech_segment_pos"])
+
+
+def gen_extra(out):
+    """Round-2 fixtures (e2e_extra.npz): a model WITHOUT a postnet (after_outs is None, sedit_model.py:369-374),
+    BASELINE configs[0] exactly (C1: 1+1 blocks, d=128, H=2, ff=512, postnet 5x256x5, B=2, T_mel=200, T_phn=30), the
+    d=512 / H=4 shape family of configs[3] at a size the CPU runs, and SAMPLED elements of every parameter gradient of
+    the reference-yaml (4+4, d=384) step whose e2e_refyaml.npz only keeps norms (full gradients would be 270 MB)."""
+    import torch
+    from oracle.a3t_oracle import A3TConfig, tiny_config, synthetic_batch
+    d = {}
+
+    def run(tag, c, seed, batch, full_grads):
+        model, _ = build_ref_model(c, c.vocab)
+        load_procedural(model, c, seed=seed)
+        model.train()
+        with torch.no_grad():
+            before, after, _, _ = _fwd_parts(model, batch)
+        load_procedural(model, c, seed=seed)
+        model.train()
+        model.zero_grad()
+        loss, _ = run_model(model, batch)
+        loss.backward()
+        d[tag + ".loss"] = loss.detach().numpy()
+        d[tag + ".before"] = before.numpy().astype(np.float32)
+        if after is not None:
+            d[tag + ".after"] = after.numpy().astype(np.float32)
+        names = [n for n, _ in model.named_parameters()]
+        d[tag + ".grad_names"] = np.array(names)
+        d[tag + ".grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+        for n, p in model.named_parameters():
+            g = p.grad.numpy().reshape(-1)
+            if full_grads:
+                d[f"{tag}.grad.{n}"] = p.grad.numpy().copy()
+            else:
+                d[f"{tag}.gsample.{n}"] = g[grad_sample_index(n, g.size)].copy()
+        print(tag, "loss", float(loss), "params", sum(p.numel() for p in model.parameters()))
+
+    c0 = tiny_config(postnet_layers=0, postnet_chans=0, postnet_filts=0)
+    run("nopost", c0, 1, synthetic_batch(c0, B=2, T_mel=48, T_phn=8, seed=11, lengths=[48, 37], text_lengths=[8, 6]), True)
+    c1 = A3TConfig(adim=128, heads=2, ff=512, enc_blocks=1, dec_blocks=1)
+    run("c1", c1, 4, synthetic_batch(c1, B=2, T_mel=200, T_phn=30, seed=13, lengths=[200, 171], text_lengths=[30, 22]), False)
+    c4 = A3TConfig(adim=512, heads=4, ff=2048, enc_blocks=1, dec_blocks=1)
+    run("c4s", c4, 5, synthetic_batch(c4, B=2, T_mel=96, T_phn=16, seed=14, lengths=[96, 70], text_lengths=[16, 11]), False)
+    c2 = A3TConfig()
+    run("refyaml", c2, 3, synthetic_batch(c2, B=2, T_mel=200, T_phn=30, seed=12, lengths=[200, 163], text_lengths=[30, 24]), False)
+    for k in [k for k in d if k.startswith("refyaml.") and not k.startswith("refyaml.gsample.")]:
+        del d[k]          # loss / outputs / norms of this step are already in e2e_refyaml.npz
+    np.savez_compressed(os.path.join(out, "e2e_extra.npz"), **d)
+    print("e2e_extra.npz", len(d), "arrays")
+
+
 def sweep(out, n_masks, n_models):
     """Randomised pinning of the ORACLE to the REFERENCE (container only; the fixed goldens above are what travels).
 
@@ -682,7 +745,8 @@ if __name__ == "__main__":
     if a.sweep:
         sweep(HERE, *a.sweep)
         sys.exit(0)
-    todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg, sedit=gen_sedit, average=gen_average)
+    todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg, sedit=gen_sedit, average=gen_average,
+                extra=gen_extra)
     for k, f in todo.items():
         if a.only and k not in a.only.split(","):
             continue

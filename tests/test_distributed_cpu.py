@@ -106,3 +106,65 @@ def test_overlapped_bucket_reduction_covers_flat_buffer_once():
         mp.spawn(_overlap_worker, args=(2, init, out), nprocs=2, join=True)
         r = torch.load(out)
     assert r["ok"] and r["nranges"] >= 2
+
+
+def test_bench_launches_n_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment must start 2 ranks (mp.spawn, one per GPU like
+    abs_task.py:1026-1045) and report n_gpus = the RCCL/gloo world size; --fake-cpu swaps the kernels for a gloo
+    all-reduce so the launch path is testable without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--fake-cpu", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                       # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dist_world_size"] == 2 and out["rank_sum"] == 3.0 and out["steps"] == 3
+    # --gpus must agree with a launcher's WORLD_SIZE
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--fake-cpu"],
+                       capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="4", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def _bf16_bucket_worker(rank, world, init_file, out_file):
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    n = 4096
+    g = torch.from_numpy(np.random.RandomState(rank).standard_normal(n).astype(np.float32))
+    ref = g.clone()
+    dist.all_reduce(ref)
+    red = T.FlatAllReduce(g, T.bucket_ranges(n, [1000, 3000], 1000), comm_dtype=torch.bfloat16)
+    for i in range(len(red.ranges)):
+        red.reduce_range(i)
+    red.wait()
+    if rank == 0:
+        torch.save(dict(err=float((g - ref).abs().max()), scale=float(ref.abs().max()), nbytes=red.bytes_per_step), out_file)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_bucket_allreduce_matches_fp32_within_bf16_rounding():
+    with tempfile.TemporaryDirectory() as d:
+        init, out = os.path.join(d, "init"), os.path.join(d, "out.pt")
+        mp.spawn(_bf16_bucket_worker, args=(2, init, out), nprocs=2, join=True)
+        r = torch.load(out)
+    assert r["err"] <= 2.0 ** -7 * r["scale"] and r["nbytes"] == 4096 * 2
+
+
+def test_loss_weight_and_accumulation_contract():
+    """trainer.py:583-597: loss_r * w_r / sum(w) * world / accum_grad; summed over ranks and divided by world this is
+    the global-batch mean -- with unequal shards (3 + 2 utterances) and two accumulation micro-steps."""
+    world, accum = 2, 2
+    per_utt = [np.random.RandomState(k).standard_normal(8) for k in range(10)]
+    micro = [list(range(0, 5)), list(range(5, 10))]
+    total = np.zeros(8)
+    for mb in micro:
+        for rank in range(world):
+            mine = T.shard_batches([mb], rank, world)[0]
+            g_local = np.mean([per_utt[k] for k in mine], axis=0)          # rank-local mean loss gradient
+            total += g_local * T.grad_scale(len(mine), len(mb), world) / accum
+    total /= world
+    np.testing.assert_allclose(total, np.mean([np.mean([per_utt[k] for k in mb], axis=0) for mb in micro], axis=0), atol=1e-12)

@@ -132,7 +132,7 @@ def _task_args(oc):
     dec = dict(cnn_module_kernel=oc.dec_kernel, attention_dim=oc.adim, attention_heads=oc.heads, linear_units=oc.ff,
                num_blocks=oc.dec_blocks, selfattention_layer_type="rel_selfattn", pos_enc_layer_type="rel_pos")
     mc = dict(lsm_weight=0.1, mean_phn_span=8, mlm_prob=0.8, postnet_layers=oc.postnet_layers, postnet_filts=5,
-              postnet_chans=oc.postnet_chans)
+              postnet_chans=oc.postnet_chans, dropout=False)   # parity tests: deterministic train-mode engine
     return argparse.Namespace(token_list=[f"t{i}" for i in range(oc.vocab)], odim=80, input_size=80,
                               feats_extract="fbank", feats_extract_conf=dict(n_fft=2048, hop_length=300,
                                                                              win_length=1200, fs=24000, fmin=80,

@@ -276,3 +276,58 @@ def test_sedit_span_arithmetic():
     assert O.sedit_splice_feat_gen([left[:, :0], gen, right[:, :0]]).shape == (2, 4)
     out = O.sedit_replace_waveform(np.arange(3000.0), -np.arange(6000.0), 300, [2, 5], [1, 9])
     assert out.shape == (600 + 2400 + 1500,) and out[600] == -300.0 and out[-1] == 2999.0
+
+
+def _extra_case(tag):
+    cfgs = dict(nopost=(O.tiny_config(postnet_layers=0, postnet_chans=0, postnet_filts=0), 1,
+                        dict(B=2, T_mel=48, T_phn=8, seed=11, lengths=[48, 37], text_lengths=[8, 6])),
+                c1=(O.A3TConfig(adim=128, heads=2, ff=512, enc_blocks=1, dec_blocks=1), 4,
+                    dict(B=2, T_mel=200, T_phn=30, seed=13, lengths=[200, 171], text_lengths=[30, 22])),
+                c4s=(O.A3TConfig(adim=512, heads=4, ff=2048, enc_blocks=1, dec_blocks=1), 5,
+                     dict(B=2, T_mel=96, T_phn=16, seed=14, lengths=[96, 70], text_lengths=[16, 11])),
+                refyaml=(O.A3TConfig(), 3,
+                         dict(B=2, T_mel=200, T_phn=30, seed=12, lengths=[200, 163], text_lengths=[30, 24])))
+    c, seed, bk = cfgs[tag]
+    return c, seed, O.synthetic_batch(c, **bk)
+
+
+def grad_sample_index(name, numel, n=256):
+    """Same deterministic element sample as tests/golden/make_golden.py::grad_sample_index."""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return rs.randint(0, numel, size=min(n, numel))
+
+
+@pytest.mark.parametrize("tag", ["nopost", "c1", "c4s", "refyaml"])
+def test_round2_reference_fixtures(tag):
+    """e2e_extra.npz (make_golden.py --only extra, the imported reference): a model without a postnet (no after-term
+    in the loss), BASELINE configs[0] exactly, the d=512/H=4 family of configs[3], and sampled elements of EVERY
+    parameter gradient of the reference-yaml step."""
+    g = _load("e2e_extra.npz")
+    c, seed, batch = _extra_case(tag)
+    p = O.to_torch_state(O.procedural_state(O.param_shapes(c), seed=seed), requires_grad=True)
+    loss, before, after = O.forward_loss(p, batch, c, True)
+    if tag != "refyaml":
+        assert abs(float(loss) - float(g[tag + ".loss"])) < 1e-4 * abs(float(g[tag + ".loss"]))
+        np.testing.assert_allclose(before.detach().numpy(), g[tag + ".before"], atol=1e-4, rtol=1e-4)
+        if tag == "nopost":
+            assert after is None and (tag + ".after") not in g.files
+        else:
+            np.testing.assert_allclose(after.detach().numpy(), g[tag + ".after"], atol=1e-4, rtol=1e-4)
+    loss.backward()
+    for k in g.files:
+        if k.startswith(tag + ".grad."):
+            n = k[len(tag) + 6:]
+            ref = g[k]
+            np.testing.assert_allclose(p[n].grad.numpy(), ref, atol=2e-4 * max(1.0, float(np.abs(ref).max())), rtol=2e-3, err_msg=n)
+        elif k.startswith(tag + ".gsample."):
+            n = k[len(tag) + 9:]
+            ref = g[k]
+            got = p[n].grad.numpy().reshape(-1)[grad_sample_index(n, p[n].numel())]
+            # (an L1 loss has sign gradients: a prediction within fp32 rounding of its target may take the other sign in
+            #  a different summation order, which moves single elements by a few 1e-4 -> judge the sample as a vector)
+            if n.endswith("linear_k.bias") or n.endswith("depthwise_conv.bias"):
+                continue      # analytically zero gradients (softmax shift invariance / a bias in front of BatchNorm): noise
+            err = float(np.linalg.norm(got.astype(np.float64) - ref)) / max(float(np.linalg.norm(ref)), 1e-6)
+            assert err < 2e-3, (n, err)
+            np.testing.assert_allclose(got, ref, atol=2e-3 * max(1e-3, float(np.abs(ref).max())), rtol=2e-2, err_msg=n)
