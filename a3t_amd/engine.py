@@ -46,11 +46,12 @@ class Workspace:
         self.device = device
         self.bufs: Dict[tuple, torch.Tensor] = {}
 
-    def get(self, name, shape, dtype=torch.float32, zero=False):
+    def get(self, name, shape, dtype=torch.float32, zero=False, zero_once=False):
+        """zero: cleared on every call; zero_once: cleared when allocated only (buffers with entries nobody writes)."""
         key = (name, tuple(shape), dtype)
         t = self.bufs.get(key)
         if t is None:
-            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            t = (torch.zeros if (zero or zero_once) else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
             self.bufs[key] = t
         elif zero:
             t.zero_()
@@ -98,6 +99,10 @@ class MLMEngine:
         # one K = 5*80 GEMM (and its two gradients) on the exact-fp32 MFMA keeps the BatchNorm-amplified rounding of the
         # postnet input out of `after` for ~0.1 ms per step
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
+        # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
+        # dBD on the backward pass).  Opt-in: on MI355X the forward kernel beats the materialised forward (291 vs 429 us per
+        # layer at the benchmark shape) but the two-pass backward does not yet, so the step is slower with it.
+        self.fused_attn = self.bf16 and os.environ.get("A3T_FUSED_ATTN", "0") == "1"
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -309,6 +314,18 @@ class MLMEngine:
         ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
         P = self._act(tag + ".P", (T, d))
         ops.linear_fwd(pos, self.W(pre + ".wpos"), P, compute=cmp)
+        if self.fused_attn and ops.attn_fused_supported(dk, T):
+            adr = self._drop(c.attention_dropout_rate, tag + ".att")
+            ctx = self._act(tag + ".ctx", (M, d))
+            lse = self.ws.get(tag + ".lse", (B, H, T))
+            ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=adr or (0.0, 0))
+            xo = self.ws.get(tag + ".xo", (M, d))
+            ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
+                           drop=self._drop(c.dropout_rate, tag + ".o"))
+            self.sv[tag] = (y, qkv, qu, qv, P, None, ctx, pos, None)
+            self.sv[tag + ".fused"] = (keymask, lse, adr)
+            return xo
+        self.sv.pop(tag + ".fused", None)
         # score-sized scratch: fp32 in fp32 mode; bf16 logits (fp32 softmax math) in bf16 mode
         sdt = torch.bfloat16 if self.bf16 else torch.float32
         ac = self.ws.get("tmp.ac", (B, H, T, T), sdt)
@@ -351,6 +368,35 @@ class MLMEngine:
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
         dqkv = self._act(self._t("tmp.dqkv"), (M, 3 * d))
+        if (tag + ".fused") in self.sv:
+            keymask, lse, adr = self.sv[tag + ".fused"]
+            delta = self.ws.get("tmp.attn.delta", (B, H, T))
+            ops.attn_delta(dctx, ctx, delta, B, H, T)
+            dqu = self._act("tmp.dqu", (M, d))
+            dqvl = self._act("tmp.dqv", (M, d))
+            dqvu = self._act("tmp.dqvu", (M, d))
+            # compact dBD: every entry is written by the kernel except row 0, columns 0..T-2 (never reaches the scores)
+            dbd = self.ws.get(self._t("tmp.dbdf16"), (B, H, T, T), torch.bfloat16, zero_once=True)
+            ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale,
+                         drop=adr or (0.0, 0))
+            zbf = (H * T * T, T * T)
+
+            def pos_weight_grad_fused():
+                dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)
+                ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zbf, b_bs=(T * d, dk),
+                         c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
+                dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
+                ops.cast_bf16(dP, dP16)
+                ops.linear_bwd_weight(dP16, pos, gr[pre + ".wpos"], compute=cmp)
+            self._side(pos_weight_grad_fused)
+            ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gr[pre + ".u"], gr[pre + ".v"], gr[pre + ".bqkv"])
+            self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp))
+            dy = self._act("tmp.dy", (M, d))
+            ops.linear_bwd_data(dqkv, self.W(pre + ".wqkv"), dy, compute=cmp)
+            self._pre_ln(ga, g, g16)
+            self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
+            self._sub_end()
+            return g
         dkk = dqkv.view(-1)[d:]
         dvv = dqkv.view(-1)[2 * d:]
         sdt = torch.bfloat16 if self.bf16 else torch.float32

@@ -130,3 +130,156 @@ def test_fused_forward_dropout_uses_the_same_mask_as_the_materialised_path(B, H,
     err_mat = float((mat.float().cpu().double() - ref).abs().max()) / scale
     print(f"[B{B} H{H} T{T} dk{dk}] dropout: fused {err:.2e}, materialised {err_mat:.2e}")
     assert err < 1.5e-2 and err <= max(1.5 * err_mat, 8e-3)
+
+
+def _exact_bwd(qkv, qu, qv, P, keymask, dctx, B, H, T, dk, keep=None, pdrop=0.0):
+    """fp64 autograd of the reference formula on the same bf16 operands -> d(q+u), d(q+v), dK, dV, d linear_pos(pos)."""
+    d = H * dk
+    f = lambda t: t.double().cpu().clone().requires_grad_(True)
+    qu_, qv_, k_, v_, p_ = f(qu), f(qv), f(qkv[:, d:2 * d]), f(qkv[:, 2 * d:]), f(P)
+    hv = lambda t: t.view(B, T, H, dk).transpose(1, 2)
+    ac = hv(qu_) @ hv(k_).transpose(-1, -2)
+    bd = O.rel_shift_legacy(hv(qv_) @ p_.view(T, H, dk).transpose(0, 1)[None].transpose(-1, -2))
+    sc = (ac + bd) / math.sqrt(dk)
+    m = keymask.cpu().bool()[:, None, None, :]
+    sc = sc.masked_fill(~m, -1e300)
+    pr = torch.softmax(sc, dim=-1).masked_fill(~m, 0.0)
+    if keep is not None:
+        pr = pr * keep / (1.0 - pdrop)
+    ctx = (pr @ hv(v_)).transpose(1, 2).reshape(B * T, d)
+    ctx.backward(dctx.double().cpu())
+    return dict(ctx=ctx.detach(), dqu=qu_.grad, dqv=qv_.grad, dk=k_.grad, dv=v_.grad, dpos=p_.grad)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.2])
+@pytest.mark.parametrize("B,H,T,dk,lengths", CASES)
+def test_fused_backward_against_fp64_autograd(B, H, T, dk, lengths, drop_p):
+    from a3t_amd import ops
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=7 * T + dk, lengths=lengths)
+    d, M = H * dk, B * T
+    rs = np.random.RandomState(T)
+    dctx = torch.from_numpy(rs.standard_normal((M, d)).astype(np.float32)).to(DEV).bfloat16()
+    drop = (drop_p, 0x51ED270B) if drop_p > 0 else (0.0, 0)
+    scale = 1.0 / math.sqrt(dk)
+    ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=DEV)
+    ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=drop)
+    delta = torch.zeros(B, H, T, device=DEV)
+    ops.attn_delta(dctx, ctx, delta, B, H, T)
+    z = lambda: torch.full((M, d), 3.0, device=DEV, dtype=torch.bfloat16)      # poisoned outputs
+    dqu, dqvl, dqvu = z(), z(), z()
+    dqkv = torch.full((M, 3 * d), 3.0, device=DEV, dtype=torch.bfloat16)
+    dbd = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale, drop=drop)
+    gu, gv, gb = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), torch.zeros(3 * d, device=DEV)
+    ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gu, gv, gb)
+    torch.cuda.synchronize()
+    keep = None
+    _, probs, pdrop = _materialised(qkv, qu, qv, P, keymask, B, H, T, dk, drop)
+    if drop_p > 0:
+        keep = ((pdrop.float().cpu() != 0) | (probs.float().cpu() == 0)).double()
+    ref = _exact_bwd(qkv, qu, qv, P, keymask, dctx, B, H, T, dk, keep, drop_p)
+    # delta = rowsum(dO * O)
+    dref = (dctx.double().cpu() * ctx.double().cpu()).view(B, T, H, dk).sum(-1).transpose(1, 2)
+    assert float((delta.cpu().double() - dref).abs().max()) < 1e-3 * max(1.0, float(dref.abs().max()))
+    got = dict(dqu=dqu.float().cpu(), dqv=(dqvl.float() + dqvu.float()).cpu(), dk=dqkv[:, d:2 * d].float().cpu(),
+               dv=dqkv[:, 2 * d:].float().cpu())
+    errs = {k: _rel(got[k], ref[k]) for k in got}
+    # d linear_pos(pos) through the compact dBD: dP_h[x] = sum_b sum_i dBD[b,h,i,x] (q+v)[b,i,h]
+    qvh = qv.float().view(B, T, H, dk).permute(0, 2, 1, 3)                     # [B][H][T][dk]
+    dpos = torch.einsum("bhix,bhid->xhd", dbd.float(), qvh).reshape(T, d).cpu()
+    errs["dpos"] = _rel(dpos, ref["dpos"])
+    print(f"[B{B} H{H} T{T} dk{dk} p{drop_p}] relative L2 errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 2e-2, (k, v)                                                # bf16 operands / outputs
+    # the finish kernel: dq = dqu + dqvl + dqvu and the five bias gradients
+    dq = dqkv[:, :d].float().cpu()
+    assert _rel(dq, ref["dqu"] + ref["dqv"]) < 2e-2
+    np.testing.assert_allclose(gu.cpu().numpy(), dqu.float().sum(0).cpu().numpy(), rtol=2e-2, atol=2e-2 * float(dqu.float().abs().sum(0).max()))
+    np.testing.assert_allclose(gv.cpu().numpy(), (dqvl.float() + dqvu.float()).sum(0).cpu().numpy(), rtol=2e-2,
+                               atol=2e-2 * float(dqvl.float().abs().sum(0).max() + 1e-3))
+    np.testing.assert_allclose(gb[d:].cpu().numpy(), dqkv[:, d:].float().sum(0).cpu().numpy(), rtol=2e-2,
+                               atol=2e-2 * float(dqkv[:, d:].float().abs().sum(0).max()))
+    # rows of padded / fully masked utterances still get their (zero-probability) gradients written: nothing poisoned
+    for t in (dqu, dqvl, dqvu, dqkv):
+        assert bool(torch.isfinite(t.float()).all())
+    assert float(dqvu.view(B, T, d)[:, 0].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,T,dk,lengths", CASES[:3])
+def test_fused_dbd_matches_materialised_softmax_backward_elementwise(B, H, T, dk, lengths):
+    """The compact dBD written by the fused query pass against a3t_relpos_softmax_bwd's (same layout, same meaning)."""
+    from a3t_amd import ops
+    from a3t_amd._lib import BF16
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=11 * T + dk, lengths=lengths)
+    d, M = H * dk, B * T
+    dctx = torch.randn(M, d, device=DEV).bfloat16()
+    scale = 1.0 / math.sqrt(dk)
+    ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=DEV)
+    ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale)
+    delta = torch.zeros(B, H, T, device=DEV)
+    ops.attn_delta(dctx, ctx, delta, B, H, T)
+    dqu, dqvl, dqvu = (torch.zeros(M, d, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    dqkv = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
+    dbd = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale, which=1)
+    _, probs, _ = _materialised(qkv, qu, qv, P, keymask, B, H, T, dk, (0.0, 0))
+    vv = qkv.view(-1)[2 * d:]
+    dpr = torch.empty(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(T * 3 * d, dk),
+             c_bs=(H * T * T, T * T), compute=BF16)
+    ds = torch.empty_like(dpr)
+    dbd_m = torch.empty_like(dpr)
+    ops.relpos_softmax_bwd(probs, dpr, ds, dbd_m, B, H, T, scale)
+    torch.cuda.synchronize()
+    a, b_ = dbd.float().cpu(), dbd_m.float().cpu()
+    sc = float(b_.abs().max())
+    assert float((a - b_).abs().max()) < 3e-2 * sc, float((a - b_).abs().max()) / sc
+    assert _rel(a, b_) < 1.5e-2
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_engine_with_fused_attention_matches_materialised_engine(dropout, monkeypatch):
+    """The bf16 engine with A3T_FUSED_ATTN=1 (fused attention forward + backward, compact dBD -> d linear_pos GEMM, bias
+    gradients from the finish kernel) against the same engine on the materialised path: same loss, same gradients (same
+    counter-RNG masks with dropout on), d = 128 / H = 2 (d_k = 64), ragged batch."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.params import ParamStore
+    oc = O.A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
+    c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab,
+                  dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
+    state = O.procedural_state(O.param_shapes(oc), 5)
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(oc, B=3, T_mel=200, T_phn=24, seed=9, lengths=[200, 141, 77],
+                                                        text_lengths=[24, 17, 9]).items()}
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("A3T_FUSED_ATTN", fused)
+        store = ParamStore(c, DEV)
+        store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+        eng = MLMEngine(c, store, compute="bf16", training=True, dropout=dropout)
+        assert eng.fused_attn == (fused == "1")
+        loss = float(eng.forward(batch)["loss"])
+        store.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        res[fused] = (loss, store.state_dict(grads=True))
+    l0, g0 = res["0"]
+    l1, g1 = res["1"]
+    assert abs(l0 - l1) < 5e-3 * abs(l0), (l0, l1)
+    bad = []
+    for k in g0:
+        a, b_ = g1[k].double().flatten(), g0[k].double().flatten()
+        nb = float(b_.norm())
+        if nb < 1e-6 or k.endswith("depthwise_conv.bias") or k.endswith("linear_k.bias"):
+            continue
+        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
+        ratio = float(a.norm()) / nb
+        if cos < 0.985 or not (0.93 < ratio < 1.07):
+            bad.append((k, round(cos, 4), round(ratio, 4)))
+    assert not bad, bad[:10]
