@@ -74,6 +74,7 @@ _SIGS = {
     "a3t_scale_dev": [_P, _P, c_int64, _P, _P],
     "a3t_slice_rows": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "a3t_cast_bf16": [_P, _P, c_int64, _P],
+    "a3t_split_bf16": [_P, _P, _P, c_int64, _P],
     "a3t_reflect_pad": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_stft_amp": [_P, _P, c_int64, c_int, c_int, _P],
     "a3t_logmel_finish": [_P, _P, c_int, c_int, c_int, _P],

@@ -77,7 +77,14 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
         wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
     const int bid = wi % p.ntiles, zy = wi / p.ntiles;
-    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    if (p.cgroup > 0) {   // L2 blocking: the co-resident tiles of an XCD cover few column tiles (a small slab of B) and many rows
+        const int tiles_m = p.ntiles / p.tiles_n, per = tiles_m * p.cgroup;
+        const int cg = bid / per, rem = bid - cg * per;
+        const int gw = min(p.cgroup, p.tiles_n - cg * p.cgroup);
+        tm = rem / gw;
+        tn = cg * p.cgroup + (rem - tm * gw);
+    }
     const int ks = zy % p.splitk, bz = zy / p.splitk;
     const int z0 = bz / p.batch_inner, z1 = bz % p.batch_inner;
     const u16* A = (const u16*)p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
@@ -441,6 +448,7 @@ static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 static inline bool m8(int64_t v) { return (v % 8) == 0; }
 
 int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_t256.hip
+int a3t_gemm_bf16_w4(const GP& p, int batch, int ly, hipStream_t stream);     // gemm_bf16_w4.hip
 
 template <int LY, int ST, int WM, int CV, int WN = 2>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
@@ -474,6 +482,10 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
                  al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
     if (p.colsum && !pv.epi_vec) return -1;
 
+    {   // large k-contiguous-A GEMMs: 256x128 4-wave kernel, two workgroups per CU (returns -1 when it does not qualify)
+        const int rc = a3t_gemm_bf16_w4(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
+        if (rc >= 0) return rc;
+    }
     {   // large GEMMs: 256x256 ping-pong kernel (returns -1 when the shape does not qualify)
         const int rc = a3t_gemm_bf16_t256(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc >= 0) return rc;
@@ -505,6 +517,14 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     const long tiles = (long)pv.tiles_n * tiles_m * batch * p.splitk;
     const int stages = forced_st ? forced_st : (tiles >= (wn3 ? 512 : 768) ? 1 : 2);
     pv.ntiles = pv.tiles_n * tiles_m;
+    {
+        static int cg = -1;
+        if (cg < 0) {
+            const char* e = getenv("A3T_GEMM_COLGROUP");
+            cg = e ? atoi(e) : 0;
+        }
+        pv.cgroup = (cg > 0 && pv.tiles_n > cg && tiles_m >= 64) ? cg : 0;
+    }
     dim3 grid((unsigned)((long)pv.ntiles * batch * p.splitk));
     if (wn3) {
 #define V3(LY, ST)                                             \

@@ -167,6 +167,26 @@ extern "C" int a3t_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
                        (unsigned short*)y, n / 4);
     return (int)hipGetLastError();
 }
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 GEMMs on (hi, lo) reproduce the fp32 operand to ~2^-17
+__global__ void split_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
+                                  int64_t n4) {
+    GRID_STRIDE(i, n4) {
+        const float4 v = ((const float4*)x)[i];
+        uint2 h, l;
+        h.x = io_pack2(v.x, v.y);
+        h.y = io_pack2(v.z, v.w);
+        l.x = io_pack2(v.x - io_bf2f(h.x & 0xffff), v.y - io_bf2f(h.x >> 16));
+        l.y = io_pack2(v.z - io_bf2f(h.y & 0xffff), v.w - io_bf2f(h.y >> 16));
+        ((uint2*)hi)[i] = h;
+        ((uint2*)lo)[i] = l;
+    }
+}
+extern "C" int a3t_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+    if (n % 4 || ((uintptr_t)x & 15) || ((uintptr_t)hi & 7) || ((uintptr_t)lo & 7)) return A3T_EINVAL;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(nblocks(n / 4, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                       (unsigned short*)hi, (unsigned short*)lo, n / 4);
+    return (int)hipGetLastError();
+}
 __global__ void slice_rows_kernel(const float* x, void* y, int y_dt, int B, int T, int Tm, int D, int reverse) {
     const int64_t n = (int64_t)B * Tm * D;
     GRID_STRIDE(i, n) {

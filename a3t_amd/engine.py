@@ -95,9 +95,10 @@ class MLMEngine:
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
         self.colsum_slots = int(os.environ.get("A3T_COLSUM_SLOTS", "16"))   # spread of the attention bias-gradient atomics
         self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
-        # bf16 mode: the first postnet conv reads `before` (log-mel scale, |x| ~ 4: one bf16 ulp = 0.03) -- running that
-        # one K = 5*80 GEMM (and its two gradients) on the exact-fp32 MFMA keeps the BatchNorm-amplified rounding of the
-        # postnet input out of `after` for ~0.1 ms per step
+        # bf16 mode: the first postnet conv reads `before` (log-mel scale, |x| ~ 4: one bf16 ulp = 0.03) whose rounding the
+        # five BatchNorm'ed postnet layers amplify.  Its forward therefore runs on (hi, lo) = (bf16(x), bf16(x - hi)): two
+        # K = 5*80 bf16 GEMMs carry `before` to ~2^-17 (max error of `after` 6.2e-2 -> 4.3e-2 of scale) for ~0.05 ms per step
+        # (the exact-fp32 MFMA for that layer and its two gradients cost 0.55 ms); gradients use hi only.
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
         # dBD on the backward pass).  Opt-in: on MI355X the forward kernel beats the materialised forward (291 vs 429 us per
@@ -617,17 +618,23 @@ class MLMEngine:
         ops.linear_fwd(hs, self.W("sfc.w"), before, bias=p["sfc.b"], compute=self.cmp)
         y = before
         f32_first = self.bf16 and self.post_f32_first
-        if self.bf16 and c.postnet_layers > 0 and not f32_first:
+        ylo = None
+        if self.bf16 and c.postnet_layers > 0:
             y = ws.get("head.before16", (B * Tm, c.odim), torch.bfloat16)
-            ops.cast_bf16(before, y)
+            if f32_first:
+                ylo = ws.get("head.before16lo", (B * Tm, c.odim), torch.bfloat16)
+                ops.split_bf16(before, y, ylo)
+            else:
+                ops.cast_bf16(before, y)
         pad = (c.postnet_filts - 1) // 2
         for l in range(c.postnet_layers):
-            f32l = f32_first and l == 0
-            W = p[f"post.{l}.w"] if f32l else self.W(f"post.{l}.w")
+            W = self.W(f"post.{l}.w")
             oc = W.shape[0]
             last = (l == c.postnet_layers - 1)
             z = ws.get(f"post.{l}.z", (B * Tm, oc))
-            ops.conv_fwd(y, W, z, Tm, pad, compute=F32 if f32l else self.cmp)
+            ops.conv_fwd(y, W, z, Tm, pad, compute=self.cmp)
+            if l == 0 and ylo is not None:
+                ops.conv_fwd(ylo, W, z, Tm, pad, R=z, compute=self.cmp)        # z += conv(lo)
             o = ws.get(f"post.{l}.o", (B * Tm, oc), torch.float32 if last else self.adt)
             self._bn_fwd(f"post.{l}", z, f"post.{l}.bn", f"post.{l}.bn", ACT_NONE if last else ACT_TANH, o)
             pdr = self._drop(c.postnet_dropout_rate, f"post.{l}")
@@ -670,8 +677,7 @@ class MLMEngine:
         if c.postnet_layers > 0:
             g = da                                    # grad wrt last BN output (fp32)
             for l in reversed(range(c.postnet_layers)):
-                f32l = self.bf16 and self.post_f32_first and l == 0
-                W = p[f"post.{l}.w"] if f32l else self.W(f"post.{l}.w")
+                W = self.W(f"post.{l}.w")
                 oc = W.shape[0]
                 last = (l == c.postnet_layers - 1)
                 dz = ws.get(f"tmp.post.dz{oc}", (B * Tm, oc))
@@ -681,16 +687,15 @@ class MLMEngine:
                     ops.dropout(g, gd, *pdr)
                     g = gd
                 self._bn_bwd(f"post.{l}", g, f"post.{l}.bn", ACT_NONE if last else ACT_TANH, dz)
-                if self.bf16 and not f32l:
+                if self.bf16:
                     dz16 = ws.get(f"tmp.post.dz16.{oc}", (B * Tm, oc), torch.bfloat16)
                     ops.cast_bf16(dz, dz16)
                     dz = dz16
                 yin = self.sv[f"post.{l}"]
                 ic = yin.shape[1]
-                lc = F32 if f32l else cmp
-                ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=lc)
+                ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=cmp)
                 gi = ws.get(f"tmp.post.g{l % 2}.{ic}", (B * Tm, ic))
-                ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=lc)
+                ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=cmp)
                 g = gi
             ops.axpy(da, db, 1.0)                     # after = before + postnet(before)
             ops.axpy(g, db, 1.0)

@@ -310,6 +310,10 @@ def cast_bf16(x, y):
     L.check(L.load().a3t_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "cast_bf16")
 
 
+def split_bf16(x, hi, lo):
+    L.check(L.load().a3t_split_bf16(_ptr(x), _ptr(hi), _ptr(lo), x.numel(), _stream()), "split_bf16")
+
+
 def slice_rows(x, y, B, T, Tm, D, reverse_add=False):
     L.check(L.load().a3t_slice_rows(_ptr(x), _ptr(y), _dt(y), B, T, Tm, D, int(reverse_add), _stream()), "slice_rows")
 

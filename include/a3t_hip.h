@@ -220,6 +220,10 @@ int a3t_slice_rows(const float* x, void* y, int y_dtype, int B, int T, int Tm, i
                    void* stream);
 /* fp32 -> bf16 (round to nearest even); n % 4 == 0 (the flat parameter buffer once per step) */
 int a3t_cast_bf16(const float* x, void* y, int64_t n, void* stream);
+/* hi = bf16(x), lo = bf16(x - hi): a pair of bf16 GEMM operands that carries an fp32 tensor to ~2^-17 relative (the first
+ * postnet conv reads the log-mel-scale `before`, tacotron2/decoder.py:165-267, whose bf16 ulp would otherwise be amplified
+ * by five BatchNorm layers); n % 4 == 0 */
+int a3t_split_bf16(const float* x, void* hi, void* lo, int64_t n, void* stream);
 
 /* Log-mel front end on the device (espnet2/layers/stft.py:56-124, log_mel.py:56-83,
  * tts/feats_extract/log_mel_fbank.py:88-106).  The STFT is a GEMM of overlapping frames
