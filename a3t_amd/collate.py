@@ -37,9 +37,14 @@ def random_spans_noise_mask(length: int, mlm_prob: float, mean_span: float) -> n
 
 
 def align_to_frames(align_sec: np.ndarray, fs: int, hop: int) -> np.ndarray:
-    """collate_fn.py:236-237 -- float32 arithmetic in the reference's order (fs*t first, then /hop)."""
-    a = np.asarray(align_sec, dtype=np.float32)
-    return np.floor((np.float32(fs) * a) / np.float32(hop)).astype(np.int32)
+    """collate_fn.py:236-237 -- `floor(fs * t / hop)` in the dtype of the alignment array and the reference's order
+    (fs*t first, then /hop): float32 for dataset arrays, float64 for the arrays sedit_inference.py:603-604 builds from
+    Python floats (boundaries a hair below a frame edge land one frame apart in the two precisions)."""
+    a = np.asarray(align_sec)
+    if a.dtype != np.float64:
+        a = a.astype(np.float32)
+    ft = a.dtype.type
+    return np.floor((ft(fs) * a) / ft(hop)).astype(np.int32)
 
 
 def phones_masking(T_mel: int, speech_nonpad: np.ndarray, align_start: np.ndarray, align_end: np.ndarray,

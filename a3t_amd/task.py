@@ -123,6 +123,19 @@ class MLMTask:
             if args.init != "xavier_uniform":
                 raise NotImplementedError(f"init={args.init}")
             xavier_init_(model.store, seed=getattr(args, "seed", 0))
+        else:
+            # init=None: the reference keeps torch's default module initialisation; the flat store starts at zero (a dead
+            # model: LayerNorm / BatchNorm gamma = 0).  Give norm scales their torch default (1) so that a checkpoint-less
+            # model is at least alive, and say so -- weights are expected to come from load_state_dict (the
+            # build_model_from_file path) or from `init: xavier_uniform` (the recipe).
+            n = 0
+            for k, v in model.store.p.items():
+                if k.endswith(".g"):
+                    v.fill_(1.0)
+                    n += 1
+            logging.warning("MLMTask.build_model(init=None): weights are zero until load_state_dict(); %d norm scales set to 1 "
+                            "(the reference would apply torch's default init here). BatchNorm running statistics are plain "
+                            "per-rank buffers of the flat store: a DDP wrapper does not broadcast them", n)
         return model
 
     @classmethod

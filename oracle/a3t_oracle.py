@@ -264,8 +264,11 @@ def logmel_fbank(wav: torch.Tensor, ilens: torch.Tensor, c: A3TConfig,
 # H5-H8: alignment -> frames, span masks, segment ids
 # ----------------------------------------------------------------------------
 def align_to_frames(align_sec: torch.Tensor, fs: int, hop: int) -> torch.Tensor:
-    """collate_fn.py:236-237: floor(fs*align/hop).int() in float32 tensor math."""
-    return torch.floor(fs * align_sec.to(torch.float32) / hop).int()
+    """collate_fn.py:236-237: floor(fs*align/hop).int() in the tensor's own floating dtype (float32 from the dataset,
+    float64 when sedit_inference.py:603-604 hands over np.array(list of Python floats))."""
+    if align_sec.dtype != torch.float64:
+        align_sec = align_sec.to(torch.float32)
+    return torch.floor(fs * align_sec / hop).int()
 
 
 def random_spans_noise_mask(length: int, mlm_prob: float, mean_span: float) -> np.ndarray:

@@ -614,6 +614,31 @@ def gen_extra(out):
     np.savez_compressed(os.path.join(out, "e2e_extra.npz"), **d)
     print("e2e_extra.npz", len(d), "arrays")
 
+    # ---- alignment dtype (collate_fn.py:236-237): the collate keeps the dtype of the alignment arrays it is handed --
+    # float32 from the dataset, float64 from sedit_inference.py:603-604 (np.array of Python floats) -- and
+    # floor(fs * t / hop) differs between the two for boundaries a hair below a frame edge.  Same utterance, both dtypes.
+    c3 = tiny_config()
+    _, collate = build_ref_model(c3, c3.vocab)
+    rs = np.random.RandomState(41)
+    n = 9000
+    wav = (0.1 * rs.standard_normal(n)).astype(np.float32)
+    F_ = n // 300 + 1
+    cuts = np.sort(rs.choice(np.arange(2, F_ - 1), size=5, replace=False))
+    bd = np.concatenate([[0], cuts, [F_ - 1]]).astype(np.float64)
+    st64, en64 = bd[:-1] * 300 / 24000 - 1e-8, bd[1:] * 300 / 24000 - 1e-8
+    st64[0] = 0.0
+    text = rs.randint(2, 9, size=6).astype(np.int64)
+    e = {}
+    for tag, cast in (("f64", np.float64), ("f32", np.float32)):
+        np.random.seed(5)
+        _, b = collate([("u", dict(speech=wav, text=text, align_start=st64.astype(cast), align_end=en64.astype(cast)))])
+        for k in ("speech_segment_pos", "text_segment_pos", "masked_position"):
+            e[f"{tag}.{k}"] = b[k].numpy()
+    assert not np.array_equal(e["f64.speech_segment_pos"], e["f32.speech_segment_pos"])
+    e.update(wav=wav, text=text, align_start=st64, align_end=en64)
+    np.savez_compressed(os.path.join(out, "align_dtype.npz"), **e)
+    print("align_dtype.npz: segment ids differ at", int((e["f64.speech_segment_pos"] != e["f32.speech_segment_pos"]).sum()), "frames")
+
 
 def sweep(out, n_masks, n_models):
     """Randomised pinning of the ORACLE to the REFERENCE (container only; the fixed goldens above are what travels).

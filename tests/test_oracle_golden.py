@@ -331,3 +331,25 @@ def test_round2_reference_fixtures(tag):
             err = float(np.linalg.norm(got.astype(np.float64) - ref)) / max(float(np.linalg.norm(ref)), 1e-6)
             assert err < 2e-3, (n, err)
             np.testing.assert_allclose(got, ref, atol=2e-3 * max(1e-3, float(np.abs(ref).max())), rtol=2e-2, err_msg=n)
+
+
+@pytest.mark.parametrize("tag,cast", [("f64", np.float64), ("f32", np.float32)])
+def test_alignment_dtype_follows_the_reference_collate(tag, cast):
+    """align_dtype.npz (reference mlm_collate_fn, make_golden.py --only extra): the same utterance with float64 alignments
+    (what sedit_inference.py:603-604 hands over) and their float32 cast (dataset arrays) gets DIFFERENT segment ids --
+    floor(fs*t/hop) runs in the array's dtype (collate_fn.py:236-237).  Oracle and product follow."""
+    from a3t_amd import collate as C
+    g = _load("align_dtype.npz")
+    c = O.tiny_config()
+    st, en = g["align_start"].astype(cast), g["align_end"].astype(cast)
+    np.random.seed(5)
+    _, b = O.collate([("u", dict(speech=g["wav"], text=g["text"], align_start=st, align_end=en))], c)
+    for k in ("speech_segment_pos", "text_segment_pos", "masked_position"):
+        assert np.array_equal(b[k].numpy(), g[f"{tag}.{k}"]), k
+    # the product's host index logic on the same arrays
+    fs_ = C.align_to_frames(st[None], c.fs, c.hop_length)
+    fe_ = C.align_to_frames(en[None], c.fs, c.hop_length)
+    T_mel = g[f"{tag}.speech_segment_pos"].shape[1]
+    sp, tp = C.get_segment_pos(T_mel, len(g["text"]), fs_, fe_, np.array([len(st)]), True)
+    assert np.array_equal(sp, g[f"{tag}.speech_segment_pos"]) and np.array_equal(tp, g[f"{tag}.text_segment_pos"])
+    assert not np.array_equal(g["f64.speech_segment_pos"], g["f32.speech_segment_pos"])
