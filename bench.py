@@ -55,7 +55,7 @@ def build_trainer(cfg, device, compute, world, dropout=True, comm_dtype=torch.fl
                       comm_dtype=comm_dtype)
 
 
-def vocoder_rtf(dev, B=8, Tf=1000, reps=3):
+def vocoder_rtf(dev, B=8, Tf=1000, reps=3, cpu=False):
     """BASELINE.json configs[4]: ParallelWaveGAN v1 (30 blocks, 64/128/64 ch, hop 300 = 4*5*3*5) mel -> wav
     for B utterances of Tf frames (12.5 s each at 24 kHz); RTF = wall / audio seconds.  fp32 MFMA GEMMs."""
     import numpy as np
@@ -88,12 +88,33 @@ def vocoder_rtf(dev, B=8, Tf=1000, reps=3):
     dt = (time.perf_counter() - t0) / reps
     audio_s = B * Tf * 300 / 24000.0
     flops = 2.60e6 * B * Tf * 300
-    return dict(metric="vocoder RTF", rtf=dt / audio_s, ms=dt * 1e3, audio_seconds=audio_s, samples_per_s=B * Tf * 300 / dt,
-                tflops=flops / dt / 1e12, dtype="f32", finite=bool(torch.isfinite(wav).all()),
-                workload=f"ParallelWaveGAN v1 generator, B={B} x {Tf} frames, hop 300, 24 kHz")
+    res = dict(metric="vocoder RTF", rtf=dt / audio_s, ms=dt * 1e3, audio_seconds=audio_s, samples_per_s=B * Tf * 300 / dt,
+               tflops=flops / dt / 1e12, dtype="f32", finite=bool(torch.isfinite(wav).all()),
+               workload=f"ParallelWaveGAN v1 generator, B={B} x {Tf} frames, hop 300, 24 kHz")
+    if cpu:
+        # CPU baseline + parity ("own CPU restatement, 1 utterance of 400 frames"): the oracle's pwg_forward on
+        # the host cores with the same weights / mel / noise; the same utterance through the HIP generator for the error
+        try:
+            from oracle import a3t_oracle as O
+            Tc = 400
+            torch.set_num_threads(min(os.cpu_count() or 1, 32))
+            p = {k: torch.from_numpy(v) for k, v in state.items()}
+            c1, z1 = c[:1, :Tc].cpu(), z[:1, :Tc * 300].cpu()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                ref = O.pwg_forward(p, c1[0].t()[None], z1[0].t()[None], O.PWGConfig())[0, 0]
+            tc = time.perf_counter() - t0
+            got = voc.inference(c1.to(dev), z1.to(dev)).reshape(-1).cpu()
+            res["cpu_baseline"] = dict(kind="port", cores=torch.get_num_threads(), rtf=tc / (Tc * 300 / 24000.0),
+                                       samples_per_s=Tc * 300 / tc, sample=f"oracle pwg_forward fp32, 1 utterance x {Tc} frames ({tc:.1f} s)")
+            res["wav_max_abs_err_vs_oracle"] = float((got - ref).abs().max())
+            res["wav_scale"] = float(ref.abs().max())
+        except Exception as e:  # noqa: BLE001
+            res["cpu_baseline"] = dict(kind="port", value=None, note=type(e).__name__ + ": " + str(e)[:80])
+    return res
 
 
-def infill_leg(dev, B=8, Tm=1000, Tp=120, span=(400, 600), reps=5):
+def infill_leg(dev, B=8, Tm=1000, Tp=120, span=(400, 600), reps=5, cpu=False):
     """BASELINE.json configs[4] front half: teacher-forced span infill (ESPnetMLMModel.inference, sedit_model.py:239-284)
     of B utterances with the reference-yaml model (4+4 blocks), eval-mode engine, bf16 compute; one forward per batch,
     the predicted span [s, e) replaces the masked frames.  Reported next to the vocoder so that
@@ -119,8 +140,30 @@ def infill_leg(dev, B=8, Tm=1000, Tp=120, span=(400, 600), reps=5):
                for b in range(B)]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return dict(ms=dt * 1e3, utterances=B, frames=B * Tm, finite=bool(torch.isfinite(torch.stack(gen)).all()),
-                workload=f"teacher-forced infill of span [{span[0]}, {span[1]}) in {B} x {Tm} frames, 4+4 blocks, eval")
+    res = dict(ms=dt * 1e3, utterances=B, frames=B * Tm, finite=bool(torch.isfinite(torch.stack(gen)).all()),
+               workload=f"teacher-forced infill of span [{span[0]}, {span[1]}) in {B} x {Tm} frames, 4+4 blocks, eval")
+    if cpu:
+        # BASELINE configs[4] "mel-L1 vs reference": the oracle's teacher-forced infill (fp32, host) of ONE sampled utterance
+        # with the same weights against the bf16 device result -- mean |difference| over the 200 x 80 generated mel bins
+        try:
+            from oracle import a3t_oracle as O
+            oc = O.A3TConfig()
+            p = {k: v.detach().cpu() for k, v in store.state_dict().items()}
+            b1 = {k: v[2:3].cpu() for k, v in batch.items()}
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                ref = O.inference_splice(p, b1, oc, span)
+            tc = time.perf_counter() - t0
+            d = (gen[2].cpu() - ref)[span[0]:span[1]]
+            res["mel_l1_vs_oracle"] = float(d.abs().mean())
+            res["mel_max_abs_err_vs_oracle"] = float(d.abs().max())
+            res["mel_scale"] = float(ref[span[0]:span[1]].abs().max())
+            res["cpu_baseline"] = dict(kind="port", cores=torch.get_num_threads(), ms_per_utterance=tc * 1e3,
+                                       sample="oracle inference_splice fp32, 1 utterance")
+        except Exception as e:  # noqa: BLE001
+            res["mel_l1_vs_oracle"] = None
+            res["cpu_note"] = type(e).__name__ + ": " + str(e)[:80]
+    return res
 
 
 def collate_leg(dev, B=32, Tm=1000, Tp=120, reps=3):
@@ -369,6 +412,7 @@ def main():
                     algbw_GBps=nbytes / tc / 1e9, busbw_GBps=2.0 * (world - 1) / world * nbytes / tc / 1e9)
         del gbuf
     roofline = None
+    prof_rows = []
     if not a.no_kernel_profile:      # every rank runs the two extra steps (they contain collectives when world > 1)
         def gemm_profile():
             """One extra, untimed step with every GEMM launch bracketed by HIP events on the stream it is launched
@@ -377,6 +421,7 @@ def main():
             tr.step(batch)
             torch.cuda.synchronize()
             prof, ops.PROFILE = ops.PROFILE, None
+            prof_rows[:] = prof
             agg = {}
             for name, flops, e0, e1, _shape in prof:
                 s_ = agg.setdefault(name, [0.0, 0.0, 0])
@@ -396,14 +441,21 @@ def main():
         achieved = fl / tt / 1e12
         peak = MFMA_PEAK["bf16" if "bf16" in name else "f32"]
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic_per_kernel.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        if os.path.exists(tf):                                                    # passes of this same command
-            for k, v in json.load(open(tf)).items():
-                if name in k:
-                    traffic = v["hbm_bytes_per_launch"]
+        for tf in ("r02_hbm_traffic_per_kernel.json", "r01_hbm_traffic_per_kernel.json"):   # rocprofv3 --pmc FETCH_SIZE /
+            tf = os.path.join(ROOT, "profiles", tf)                                         # WRITE_SIZE passes of this command
+            if os.path.exists(tf) and traffic is None:
+                for k, v in json.load(open(tf)).items():
+                    if name in k:
+                        traffic = v["hbm_bytes_per_launch"]
+        # algorithmic bytes of one launch of that kernel (every operand read once, output written / atomically updated once
+        # per K-split): averaged over its launches of the profiled step
+        alg = [2.0 * (K_ * M_ + K_ * (N_ // max(tp_, 1)) if "<2," in nm else M_ * K_ // max(tp_, 1) + N_ * K_) * b_
+               + (4.0 * M_ * N_ * b_ * sk_ if "<2," in nm else 2.0 * M_ * N_ * b_)
+               for nm, _f, _e0, _e1, (M_, N_, K_, b_, tp_, sk_) in prof_rows if nm == name]
+        traffic_alg = sum(alg) / len(alg) if alg else None
         fa, ta, na = alone.get(name, (fl, tt, n))
         roofline = dict(bound="mfma", kernel=name, launches=n, avg_us=tt / n * 1e6, achieved=achieved, peak=peak,
-                        unit="TFLOP/s", frac=achieved / peak, traffic=traffic,
+                        unit="TFLOP/s", frac=achieved / peak, traffic=traffic, traffic_algorithmic=traffic_alg,
                         note="durations from HIP events inside the step; this kernel runs on the side stream and "
                              "shares the GPU with the data-gradient chain, 'alone' = same step on one stream",
                         alone=dict(avg_us=ta / na * 1e6, achieved=fa / ta / 1e12, frac=fa / ta / 1e12 / peak),
@@ -429,8 +481,8 @@ def main():
             out["comm"] = comm
         if world == 1 and not a.no_vocoder:
             log("vocoder leg (ParallelWaveGAN v1, 8 x 1000 frames)")
-            out["vocoder"] = vocoder_rtf(dev)
-            inf = infill_leg(dev)
+            out["vocoder"] = vocoder_rtf(dev, cpu=not a.no_cpu_baseline)
+            inf = infill_leg(dev, cpu=not a.no_cpu_baseline)
             out["vocoder"]["infill"] = inf
             out["vocoder"]["pipeline_rtf"] = (inf["ms"] + out["vocoder"]["ms"]) * 1e-3 / out["vocoder"]["audio_seconds"]
         if world == 1 and not a.no_collate:

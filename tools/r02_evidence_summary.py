@@ -22,12 +22,12 @@ out = {}
 for k, d in agg.items():
     row = {c: v / n for c, (n, v) in d.items()}
     row["launches_per_pass"] = max(n for n, _ in d.values())
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs' SQ instances as reported per XCD aggregate;
-    # utilisation = busy / (GRBM_GUI_ACTIVE * #CU * 4 SIMDs / 4) is calibrated below with the 32-cycle MFMA:
-    if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in row and "GRBM_GUI_ACTIVE" in row:
-        row["note"] = "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES-normalised); see DESIGN 4.1"
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "SQ_BUSY_CYCLES" in row and row["SQ_BUSY_CYCLES"]:
-        row["mfma_busy_over_sq_busy"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / row["SQ_BUSY_CYCLES"]
+    # SQ_VALU_MFMA_BUSY_CYCLES = MFMA-pipe busy cycles summed over the 1024 SIMDs (= 32 per v_mfma_f32_32x32x16_bf16:
+    # 123 863 040 = 32 x 3 870 720 MFMAs for 35840x1536x1152, checked); GRBM_GUI_ACTIVE is summed over the 8 XCDs, so
+    # utilisation of the matrix pipes = busy / (1024 SIMDs x kernel cycles) with kernel cycles = GRBM_GUI_ACTIVE / 8
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in row and row.get("GRBM_GUI_ACTIVE"):
+        row["mfma_util"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * row["GRBM_GUI_ACTIVE"] / 8.0)
+        row["kernel_cycles"] = row["GRBM_GUI_ACTIVE"] / 8.0
     if "SQ_WAVE_CYCLES" in row and row["SQ_WAVE_CYCLES"]:
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if c in row:
