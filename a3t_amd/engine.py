@@ -101,9 +101,14 @@ class MLMEngine:
         # (the exact-fp32 MFMA for that layer and its two gradients cost 0.55 ms); gradients use hi only.
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
-        # dBD on the backward pass).  Opt-in: on MI355X the forward kernel beats the materialised forward (291 vs 429 us per
-        # layer at the benchmark shape) but the two-pass backward does not yet, so the step is slower with it.
-        self.fused_attn = self.bf16 and os.environ.get("A3T_FUSED_ATTN", "0") == "1"
+        # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
+        # at the benchmark shape, B = 32: 576 workgroups) but the two-pass backward does not yet, and at the
+        # B = 8 of the inference benchmark its 144 workgroups leave 112 CUs idle (infill 5.3 vs 4.8 ms).  Hence opt-in:
+        # A3T_FUSED_ATTN=1: fused forward AND backward; =fwd: fused for forward-only passes (need_grad=False); default: off.
+        fa = os.environ.get("A3T_FUSED_ATTN", "")
+        self.fused_attn = self.bf16 and fa == "1"
+        self.fused_attn_fwd_only = self.bf16 and fa == "fwd"
+        self._fused_now = self.fused_attn
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -315,7 +320,7 @@ class MLMEngine:
         ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
         P = self._act(tag + ".P", (T, d))
         ops.linear_fwd(pos, self.W(pre + ".wpos"), P, compute=cmp)
-        if self.fused_attn and ops.attn_fused_supported(dk, T):
+        if self._fused_now and ops.attn_fused_supported(dk, T):
             adr = self._drop(c.attention_dropout_rate, tag + ".att")
             ctx = self._act(tag + ".ctx", (M, d))
             lse = self.ws.get(tag + ".lse", (B, H, T))
@@ -561,6 +566,7 @@ class MLMEngine:
         if self.bf16 and (T % 8 or Tm % 8):
             raise ValueError(f"compute='bf16' needs T_mel and T_mel+T_phn to be multiples of 8, got {Tm}, {T}")
         self.dims = (B, Tm, Tp, T)
+        self._fused_now = self.fused_attn or (self.fused_attn_fwd_only and not need_grad)
         self.step_seed += 1
         self.refresh_weights()
         self._arena_clear("fwd64")
