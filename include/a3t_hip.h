@@ -290,6 +290,9 @@ const char* a3t_version(void);
 /* Name (as rocprofv3 prints it, without "void " / "(GP)") of the kernel variant a3t_gemm's dispatcher launched last on
  * the calling thread -- lets a profiler harness attribute event-bracketed launches to kernel-trace rows. */
 const char* a3t_gemm_last_kernel(void);
+/* Kernel-selection override for A/B measurements and tests: 0 = never use the persistent 256x256 GEMM, 1 = whenever the
+ * descriptor is legal for it, 2 = the built-in heuristic, -1 = re-read A3T_GEMM_P256.  Returns the previous mode. */
+int a3t_gemm_p256_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,12 @@ def test_gemm_register_budget():
         four_per_cu = wn == 2 and (conv in (0, 1) or (conv == 2 and layout == 2))
         assert r["VGPRs"] <= (128 if four_per_cu else 168), (name, r["VGPRs"])
     assert seen >= 22
+    # the persistent 256x256 kernel runs one 512-thread workgroup per CU: 256 registers per wave, no scratch
+    path = path.replace("gemm_bf16.resources.json", "gemm_bf16_p256.resources.json")
+    rows = json.load(open(path))
+    assert len(rows) == 8
+    for name, r in rows.items():
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs"] <= 256, (name, r["VGPRs"])
 
 
 def test_sedit_driver_span_arithmetic_matches_reference():
