@@ -87,8 +87,8 @@ _SIGS = {
                            c_float, c_float, _P],
     "a3t_pwg_gate": [_P, _P, _P, c_int64, c_int, _P],
     "a3t_pwg_res_skip": [_P, _P, _P, c_int64, c_int, c_int, _P],
-    "a3t_pwg_upsample": [_P, _P, _P, c_int64, c_int, c_int, _P],
-    "a3t_replicate_pad": [_P, _P, c_int64, c_int, c_int, _P],
+    "a3t_pwg_upsample": [_P, _P, _P, c_int64, c_int64, c_int, c_int, _P],
+    "a3t_replicate_pad": [_P, _P, c_int64, c_int64, c_int, c_int, _P],
     "a3t_bias_act": [_P, _P, c_int64, c_int, c_int, c_float, _P],
     "a3t_dropout": [_P, c_int, _P, c_int, c_int64, c_float, ctypes.c_uint32, c_float, _P],
     "a3t_gemm_p256_mode": [c_int],

@@ -463,41 +463,45 @@ extern "C" int a3t_pwg_res_skip(const float* o, float* x, float* skips, int64_t 
     hipLaunchKernelGGL(pwg_res_skip_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, o, x, skips, T, R, S);
     return (int)hipGetLastError();
 }
-// out[t][c] = sum_j w[j] * c_stretched[t + j - scale][c], c_stretched[u] = c[u / scale], zero outside
+// out[b][t][c] = sum_j w[j] * c_stretched[b][t + j - scale][c], c_stretched[b][u] = c[b][u / scale], zero outside the utterance
 __global__ void pwg_upsample_kernel(const float* __restrict__ c, const float* __restrict__ w, float* __restrict__ out,
-                                    int64_t Tin, int C, int scale) {
+                                    int64_t B, int64_t Tin, int C, int scale) {
     const int64_t Tout = Tin * scale;
-    const int64_t n = Tout * C;
+    const int64_t n = B * Tout * C;
     GRID_STRIDE(i, n) {
-        int64_t t = i / C;
-        int ch = (int)(i - t * C);
+        const int64_t ta = i / C;
+        const int ch = (int)(i - ta * C);
+        const int64_t b = ta / Tout, t = ta - b * Tout;
+        const float* cb = c + b * Tin * C;
         float acc = 0.f;
         for (int j = 0; j <= 2 * scale; ++j) {
             int64_t u = t + j - scale;
-            if (u >= 0 && u < Tout) acc += w[j] * c[(u / scale) * C + ch];
+            if (u >= 0 && u < Tout) acc += w[j] * cb[(u / scale) * C + ch];
         }
         out[i] = acc;
     }
 }
-extern "C" int a3t_pwg_upsample(const float* c, const float* w, float* out, int64_t Tin, int C, int scale,
+extern "C" int a3t_pwg_upsample(const float* c, const float* w, float* out, int64_t B, int64_t Tin, int C, int scale,
                                 void* stream) {
-    int64_t n = Tin * scale * C;
-    hipLaunchKernelGGL(pwg_upsample_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, c, w, out, Tin, C,
+    int64_t n = B * Tin * scale * C;
+    hipLaunchKernelGGL(pwg_upsample_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, c, w, out, B, Tin, C,
                        scale);
     return (int)hipGetLastError();
 }
-__global__ void replicate_pad_kernel(const float* x, float* y, int64_t T, int C, int pad) {
-    const int64_t n = (T + 2 * pad) * C;
+__global__ void replicate_pad_kernel(const float* x, float* y, int64_t B, int64_t T, int C, int pad) {
+    const int64_t Tp = T + 2 * pad, n = B * Tp * C;
     GRID_STRIDE(i, n) {
-        int64_t t = i / C - pad;
-        int c = (int)(i % C);
+        const int64_t ta = i / C;
+        const int c = (int)(i - ta * C);
+        const int64_t b = ta / Tp;
+        int64_t t = ta - b * Tp - pad;
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
-        y[i] = x[t * C + c];
+        y[i] = x[(b * T + t) * C + c];
     }
 }
-extern "C" int a3t_replicate_pad(const float* x, float* y, int64_t T, int C, int pad, void* stream) {
-    int64_t n = (T + 2 * pad) * C;
-    hipLaunchKernelGGL(replicate_pad_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, T, C, pad);
+extern "C" int a3t_replicate_pad(const float* x, float* y, int64_t B, int64_t T, int C, int pad, void* stream) {
+    int64_t n = B * (T + 2 * pad) * C;
+    hipLaunchKernelGGL(replicate_pad_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, B, T, C, pad);
     return (int)hipGetLastError();
 }
 __global__ void bias_act_kernel(float* x, const float* bias, int64_t n, int C, int act, float scale) {

@@ -597,10 +597,13 @@ class MLMEngine:
             ops.dropout(pf, pos_e, *self._drop(pp, "pos.enc"))
             pf.copy_(self.pe[:T])
             ops.dropout(pf, pos_d, *self._drop(pp, "pos.dec"))
-        else:
+            ws.pos_key = None
+        elif getattr(ws, "pos_key", None) != (Tm, Tp, pos_e.data_ptr(), pos_d.data_ptr()):
+            # (constant for a given (T_mel, T_phn): rebuilt only when the shape or the workspace buffers change)
             pos_e[:Tm].copy_(self.pe[:Tm])
             pos_e[Tm:].copy_(self.pe[:Tp])
             pos_d.copy_(self.pe[:T])
+            ws.pos_key = (Tm, Tp, pos_e.data_ptr(), pos_d.data_ptr())     # (on the workspace: engines may share it)
         self.sv["embed"] = (xm, e, text, spos, tpos, masked, speech2)
         x = xs
         for i in range(c.enc_blocks):

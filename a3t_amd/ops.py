@@ -376,13 +376,17 @@ def pwg_res_skip(o, x, skips):
 
 
 def pwg_upsample(c, w, out, scale_):
-    Tin, C = c.shape
-    L.check(L.load().a3t_pwg_upsample(_ptr(c), _ptr(w), _ptr(out), Tin, C, scale_, _stream()), "pwg_upsample")
+    """c [Tin][C] or [B][Tin][C] (contiguous) -> out [.., Tin*scale, C]"""
+    B = c.shape[0] if c.dim() == 3 else 1
+    Tin, C = c.shape[-2:]
+    L.check(L.load().a3t_pwg_upsample(_ptr(c), _ptr(w), _ptr(out), B, Tin, C, scale_, _stream()), "pwg_upsample")
 
 
 def replicate_pad(x, y, pad):
-    T, C = x.shape
-    L.check(L.load().a3t_replicate_pad(_ptr(x), _ptr(y), T, C, pad, _stream()), "replicate_pad")
+    """x [T][C] or [B][T][C] (contiguous) -> y [.., T + 2 pad, C]"""
+    B = x.shape[0] if x.dim() == 3 else 1
+    T, C = x.shape[-2:]
+    L.check(L.load().a3t_replicate_pad(_ptr(x), _ptr(y), B, T, C, pad, _stream()), "replicate_pad")
 
 
 def bias_act(x, bias, act, scale_=1.0):

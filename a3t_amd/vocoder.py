@@ -91,16 +91,14 @@ class ParallelWaveGANGeneratorHIP:
         w = self.ctx
         Tp = Tf + 2 * w
         cp = torch.empty(B * Tp, A, device=dev)
-        for b in range(B):
-            ops.replicate_pad(c[b].contiguous(), cp[b * Tp:(b + 1) * Tp], w)
+        ops.replicate_pad(c.contiguous(), cp, w)
         ci = torch.empty(B * Tp, A, device=dev)
         ops.conv_fwd(cp, self.w_in, ci, Tp, w, compute=F32)
         cu = ci.view(B, Tp, A)[:, w:w + Tf].contiguous()
         T = Tf
         for sc, wk in zip(self.scales, self.w_up):
             out = torch.empty(B, T * sc, A, device=dev)
-            for b in range(B):
-                ops.pwg_upsample(cu[b], wk, out[b], sc)
+            ops.pwg_upsample(cu, wk, out, sc)
             cu, T = out, T * sc
         cu = cu.view(B * Tw, A)
         # ---- first conv (1 -> R), residual stack

@@ -262,10 +262,11 @@ int a3t_clip_adam_noam(float* p, const float* g, float* m, float* v, const doubl
 int a3t_pwg_gate(const float* y, const float* c, float* out, int64_t T, int H, void* stream);
 /* o [T][R+S] -> x = (o[:, :R] + x) * sqrt(.5); skips += o[:, R:] */
 int a3t_pwg_res_skip(const float* o, float* x, float* skips, int64_t T, int R, int S, void* stream);
-/* nearest stretch by `scale` then 1-D smoothing conv (2*scale+1 taps, zero pad) per channel */
-int a3t_pwg_upsample(const float* c, const float* w, float* out, int64_t Tin, int C, int scale,
+/* nearest stretch by `scale` then 1-D smoothing conv (2*scale+1 taps, zero pad) per channel; c [B][Tin][C] -> out [B][Tin*scale][C] */
+int a3t_pwg_upsample(const float* c, const float* w, float* out, int64_t B, int64_t Tin, int C, int scale,
                      void* stream);
-int a3t_replicate_pad(const float* x, float* y, int64_t T, int C, int pad, void* stream);
+/* x [B][T][C] -> y [B][T + 2 pad][C], edge frames replicated per utterance */
+int a3t_replicate_pad(const float* x, float* y, int64_t B, int64_t T, int C, int pad, void* stream);
 int a3t_bias_act(float* x, const float* bias, int64_t M, int C, int act, float scale, void* stream);
 
 /* Dropout (torch.nn.Dropout sites of the path).  Counter-based: keep = f(key, element index), so the
