@@ -102,12 +102,15 @@ class MLMEngine:
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
         # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
-        # at the benchmark shape, B = 32: 576 workgroups) but the two-pass backward does not yet, and at the
-        # B = 8 of the inference benchmark its 144 workgroups leave 112 CUs idle (infill 5.3 vs 4.8 ms).  Hence opt-in:
-        # A3T_FUSED_ATTN=1: fused forward AND backward; =fwd: fused for forward-only passes (need_grad=False); default: off.
-        fa = os.environ.get("A3T_FUSED_ATTN", "")
+        # at the benchmark shape; whole eval forward 4.32 vs 4.74 ms at B = 8, 10.5 vs 11.3 ms at B = 32, 4+4 blocks), except
+        # when it has too few workgroups to hide its 94-us latency floor (B <= 2: +1..2 %); the two-pass backward does not
+        # beat the materialised backward.  Hence the default "auto": forward-only passes (need_grad=False)
+        # use the fused kernel when it launches >= 64 workgroups; training steps stay materialised.
+        # A3T_FUSED_ATTN=0: never; =fwd: every forward-only pass; =1: fused forward AND backward.
+        fa = os.environ.get("A3T_FUSED_ATTN", "auto")
         self.fused_attn = self.bf16 and fa == "1"
         self.fused_attn_fwd_only = self.bf16 and fa == "fwd"
+        self.fused_attn_auto = self.bf16 and fa == "auto"
         self._fused_now = self.fused_attn
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
@@ -566,7 +569,8 @@ class MLMEngine:
         if self.bf16 and (T % 8 or Tm % 8):
             raise ValueError(f"compute='bf16' needs T_mel and T_mel+T_phn to be multiples of 8, got {Tm}, {T}")
         self.dims = (B, Tm, Tp, T)
-        self._fused_now = self.fused_attn or (self.fused_attn_fwd_only and not need_grad)
+        self._fused_now = self.fused_attn or (self.fused_attn_fwd_only and not need_grad) or \
+            (self.fused_attn_auto and not need_grad and B * c.heads * ((T + 127) // 128) >= 64)
         self.step_seed += 1
         self.refresh_weights()
         self._arena_clear("fwd64")

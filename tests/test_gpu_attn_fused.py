@@ -283,3 +283,40 @@ def test_engine_with_fused_attention_matches_materialised_engine(dropout, monkey
         if cos < 0.985 or not (0.93 < ratio < 1.07):
             bad.append((k, round(cos, 4), round(ratio, 4)))
     assert not bad, bad[:10]
+
+
+def test_forward_only_passes_take_the_fused_kernel_by_default(monkeypatch):
+    """Default A3T_FUSED_ATTN=auto: an eval / need_grad=False forward with >= 64 attention workgroups runs the fused forward
+    kernel (no T x T tensor), a training forward and a tiny batch stay on the materialised path, and both give the same
+    mel output to bf16 accuracy and the oracle's output within the bf16 tolerance of the parity tests."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.params import ParamStore
+    monkeypatch.delenv("A3T_FUSED_ATTN", raising=False)
+    oc = O.A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
+    c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab)
+    state = O.procedural_state(O.param_shapes(oc), 5)
+    B = 16
+    cpu_batch = O.synthetic_batch(oc, B=B, T_mel=232, T_phn=24, seed=9, lengths=[232] * 10 + [141, 77, 200, 99, 232, 8],
+                                  text_lengths=[24] * 10 + [17, 9, 24, 11, 24, 3])
+    batch = {k: v.to(DEV) for k, v in cpu_batch.items()}
+    store = ParamStore(c, DEV)
+    store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+    eng = MLMEngine(c, store, compute="bf16", training=False)
+    assert eng.fused_attn_auto and not eng.fused_attn
+    out = eng.forward(batch, need_grad=False)                       # 16 * 2 * 2 = 64 workgroups
+    assert sum(k.endswith(".fused") for k in eng.sv) == 3
+    fused_after = out["after"].float().clone()
+    small = {k: v[:2].contiguous() for k, v in batch.items()}
+    eng.forward(small, need_grad=False)                             # 8 workgroups: materialised
+    assert not any(k.endswith(".fused") for k in eng.sv)
+    eng.forward(batch, need_grad=True)                              # gradients wanted: materialised
+    assert not any(k.endswith(".fused") for k in eng.sv)
+    eng.fused_attn_auto = False
+    mat_after = eng.forward(batch, need_grad=False)["after"].float()
+    scale = float(mat_after.abs().max())
+    assert float((fused_after - mat_after).abs().max()) < 3e-2 * scale
+    with torch.no_grad():
+        _, _, ra = O.forward_loss(O.to_torch_state(state), cpu_batch, oc, False)
+    err = (fused_after.cpu().reshape(ra.shape) - ra)
+    assert float(err.pow(2).mean().sqrt()) < 1e-2 * scale and float(err.abs().max()) < 6e-2 * scale
