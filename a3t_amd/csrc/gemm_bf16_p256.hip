@@ -403,7 +403,8 @@ int a3t_gemm_bf16_p256(const GP& p, int batch, int ly, hipStream_t stream) {
         const char* e = getenv("A3T_GEMM_P256");
         mode = e ? atoi(e) : 0;
     }
-    if (ncus == 0) {
+    if (mode == 0) return -1;
+    if (ncus == 0) {   // (one process drives one GPU: trainer.py, bench.py)
         ncus = 256;
         int dev = 0;
         hipDeviceProp_t prop;
@@ -412,7 +413,7 @@ int a3t_gemm_bf16_p256(const GP& p, int batch, int ly, hipStream_t stream) {
         if (g) ncus = atoi(g);
         ncus &= ~7;
     }
-    if (mode == 0 || ncus < 8) return -1;
+    if (ncus < 8) return -1;
     if (ly != L_NT && ly != L_NN) return -1;
     if (p.K % 32 != 0 || p.splitk != 1 || p.kshift_mode) return -1;
     if (!p.epi_vec || p.accumulate == A3T_ACC_ATOMIC) return -1;
