@@ -1,0 +1,315 @@
+// gemm8p.hip -- calibration probe (round 3): the 256x256x64 "8-phase" bf16 GEMM schedule of the CDNA4 guide, rebuilt from
+// its description, stand-alone (no torch): C[M][N] = A[M][K] . B[N][K]^T, bf16 in, fp32 accumulate, bf16 out.
+//   * 8 waves = 2 (wr) x 4 (wc); LDS = 2 K-tile buffers x {A0, A1, B0, B1} half-tiles of 128 rows x 64 k (16 KiB each);
+//   * wave (wr, wc) owns rows wr*64..+63 of BOTH A halves and columns wc*32..+31 of BOTH B halves: a K-tile is four
+//     quadrant phases (A0xB0, A0xB1, A1xB1, A1xB0) of 16 v_mfma_f32_16x16x32_bf16 each;
+//   * one half-tile DMA (2 global_load_lds_dwordx4 per lane) per phase, issue order B0, A0, B1, A1, running 5-7 phases
+//     ahead of its first read; ONE counted wait per K-tile (vmcnt(6) in phase 4);
+//   * phase = [ds_reads | DMA issue] s_barrier [lgkmcnt(0) | setprio 1 | 16 MFMA | setprio 0] s_barrier; waves 4-7 run one
+//     barrier behind waves 0-3 (each SIMD holds one wave of each group: one multiplies while the other loads);
+//   * LDS images are lane-linear (DMA) with the 16-byte chunk XOR (row & 7) applied to the SOURCE address and to the read.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/gemm8p.hip -o tools/probes/gemm8p
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_AS(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define BAR()                                   \
+    do {                                        \
+        SB();                                   \
+        asm volatile("s_barrier" ::: "memory"); \
+        SB();                                   \
+    } while (0)
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+#ifndef SETPRIO
+#define SETPRIO 1
+#endif
+#ifndef GROUPM
+#define GROUPM 4
+#endif
+
+enum { HA0 = 0, HA1 = 1, HB0 = 2, HB1 = 3 };
+constexpr int HALF_BYTES = 128 * 64 * 2, TILE_BYTES = 4 * HALF_BYTES;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const u16* __restrict__ A, const u16* __restrict__ B, u16* __restrict__ C,
+                                                        int M, int N, int K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+
+    // bijective XCD remap (workgroup b runs on XCD b % 8): every XCD gets a contiguous run of tiles
+    int wi = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
+    }
+    // grouped tile order: GROUPM row tiles tall, column-major inside a group
+    int tm, tn;
+    {
+        const int per_group = GROUPM * tiles_n;
+        const int g = wi / per_group, first_m = g * GROUPM;
+        const int gm = min(tiles_m - first_m, GROUPM);
+        const int in = wi - g * per_group;
+        tm = first_m + in % gm;
+        tn = in / gm;
+    }
+
+    // ---- DMA sources.  Wave instruction (half H, q): LDS rows (q*8 + w)*8 .. +7 of the half (1 KiB, lane-linear);
+    // lane -> row +(lane>>3), chunk position lane&7, which holds SOURCE chunk (lane&7) ^ (row & 7) = (lane&7) ^ (lane>>3).
+    const int srow = lane >> 3, schunk = (lane & 7) ^ (lane >> 3);
+    const unsigned int voffA = (unsigned)(srow * K + schunk * 8) * 2u;      // bytes, per lane
+    const char* gA = (const char*)(A + (size_t)(tm * 256 + w * 8) * K);     // uniform
+    const char* gB = (const char*)(B + (size_t)(tn * 256 + w * 8) * K);
+    const size_t hstep = (size_t)128 * K * 2, qstep = (size_t)64 * K * 2;   // half / q strides in bytes (uniform)
+
+    auto issue = [&](const int H, const int t, const int buf) __attribute__((always_inline)) {
+        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + w * 1024;
+        const char* g = ((H < 2) ? gA : gB) + (size_t)(H & 1) * hstep + (size_t)t * 128 + voffA;
+        __builtin_amdgcn_global_load_lds(GLB_AS(g), LDS_AS(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_AS(g + qstep), LDS_AS(dst + 8192), 16, 0, 0);
+    };
+
+    // ---- fragment read addresses: row (l&15) of a 16-row block, k chunk (s*4 + (l>>4)) ^ (row&7)
+    const int frow = lane & 15;
+    const unsigned int fch = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);
+    const unsigned int aoff = (unsigned)((wr * 64 + frow) * 128) + fch;     // + i*2048, ^64 for s = 1
+    const unsigned int boff = (unsigned)((wc * 32 + frow) * 128) + fch;     // + j*2048
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto readA = [&](const unsigned char* img) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *(const bf16x8*)(img + i * 2048 + aoff);
+            fa[i][1] = *(const bf16x8*)(img + i * 2048 + (aoff ^ 64u));
+        }
+    };
+    auto readB = [&](const unsigned char* img, bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = *(const bf16x8*)(img + j * 2048 + boff);
+            fb[j][1] = *(const bf16x8*)(img + j * 2048 + (boff ^ 64u));
+        }
+    };
+    auto quad = [&](const int ha, const int hb, const bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ha][hb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][s], fa[i][s], acc[ha][hb][i][j], 0, 0, 0);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = K / 64;   // host contract: even, >= 2
+
+    // ---- prologue: K-tile 0 complete + three halves of K-tile 1 ---------------------------------------------------
+    issue(HB0, 0, 0), issue(HA0, 0, 0), issue(HB1, 0, 0), issue(HA1, 0, 0);
+    issue(HB0, 1, 1), issue(HA0, 1, 1), issue(HB1, 1, 1);
+    WAIT_VM(6);            // K-tile 0 landed (this wave's share)
+    BAR();                 // ... everyone's share
+    if (wr == 1) BAR();    // second group runs one barrier behind
+
+    // one K-tile = 4 phases.  LAST: no further tiles to stage (tile t is the last or the one before it)
+    auto ktile = [&](const int t, const int buf, const bool stage_next, const bool stage_next2) __attribute__((always_inline)) {
+        const unsigned char* cur = smem + buf * TILE_BYTES;
+        // phase 1: A0 x B0
+        readB(cur + HB0 * HALF_BYTES, fb0);
+        SB();
+        readA(cur + HA0 * HALF_BYTES);
+        if (stage_next) issue(HA1, t + 1, buf ^ 1);
+        WAIT_LGKM(8);      // the B0 reads have returned: B0 may be restaged in the next phase
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(0, 0, fb0);
+        BAR();
+        // phase 2: A0 x B1
+        readB(cur + HB1 * HALF_BYTES, fb1);
+        if (stage_next2) issue(HB0, t + 2, buf);
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(0, 1, fb1);
+        BAR();
+        // phase 3: A1 x B1
+        readA(cur + HA1 * HALF_BYTES);
+        if (stage_next2) issue(HA0, t + 2, buf);
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(1, 1, fb1);
+        BAR();
+        // phase 4: A1 x B0
+        if (stage_next2) {
+            issue(HB1, t + 2, buf);
+            WAIT_VM(6);    // everything but the three youngest half-tiles: K-tile t+1 has landed
+        } else if (stage_next) {
+            WAIT_VM(0);
+        }
+        BAR();
+        quad(1, 0, fb0);
+        BAR();
+    };
+
+    int t = 0;
+    for (; t < nk - 2; t += 2) {
+        ktile(t, 0, true, true);
+        ktile(t + 1, 1, true, true);
+    }
+    ktile(t, 0, true, false);
+    ktile(t + 1, 1, false, false);
+    if (wr == 0) BAR();
+
+    // ---- epilogue: lane holds C[m = ..+(l&15)][n = ..+(l>>4)*4 .. +3]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int m = tm * 256 + a * 128 + wr * 64 + i * 16 + (lane & 15);
+                    const int n = tn * 256 + b * 128 + wc * 32 + j * 16 + (lane >> 4) * 4;
+                    const f32x4 v = acc[a][b][i][j];
+                    uint2 o;
+                    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    *(uint2*)(C + (size_t)m * N + n) = o;
+                }
+}
+
+// ---- reference: one thread per output, fp32 accumulate ------------------------------------------------------------
+__global__ void ref_kernel(const u16* A, const u16* B, float* C, int M, int N, int K, int m0, int rows) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = m0 + blockIdx.y;
+    if (n >= N || blockIdx.y >= rows) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k)
+        s += __uint_as_float((unsigned)A[(size_t)m * K + k] << 16) * __uint_as_float((unsigned)B[(size_t)n * K + k] << 16);
+    C[(size_t)blockIdx.y * N + n] = s;
+}
+
+static u16 h_f2bf(float f) {
+    unsigned int u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+static float h_bf2f(u16 h) {
+    unsigned int u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+static int run_case(int M, int N, int K, int iters, bool check) {
+    const size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
+    std::vector<u16> ha(na), hb(nb);
+    unsigned long long s = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(M * 31 + N * 17 + K);
+    auto rnd = [&]() {
+        s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+        return (float)((s >> 40) & 0xffffff) / 8388608.0f - 1.0f;   // uniform [-1, 1)
+    };
+    for (auto& x : ha) x = h_f2bf(rnd());
+    for (auto& x : hb) x = h_f2bf(rnd());
+    u16 *dA, *dB, *dC;
+    (void)hipMalloc(&dA, na * 2), (void)hipMalloc(&dB, nb * 2), (void)hipMalloc(&dC, nc * 2);
+    (void)hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice);
+    (void)hipMemset(dC, 0xff, nc * 2);
+    const int tiles_m = M / 256, tiles_n = N / 256;
+    const int lds = 2 * TILE_BYTES;
+    (void)hipFuncSetAttribute((const void*)gemm8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    dim3 grid(tiles_m * tiles_n), block(512);
+    hipLaunchKernelGGL(gemm8p_kernel, grid, block, lds, 0, dA, dB, dC, M, N, K, tiles_m, tiles_n);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        printf("launch failed: %s\n", hipGetErrorString(hipGetLastError()));
+        return 1;
+    }
+    int bad = 0;
+    if (check) {
+        // reference rows: a sample of 256 rows spread over all row tiles / wave rows
+        const int rows = 64;
+        float* dR;
+        (void)hipMalloc(&dR, (size_t)rows * N * 4);
+        std::vector<float> hr((size_t)rows * N);
+        std::vector<u16> hc(nc);
+        (void)hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost);
+        double maxerr = 0;
+        for (int blk = 0; blk < 6; ++blk) {
+            const int m0 = (int)(((long long)blk * (M - rows)) / 5) / 1 ;
+            hipLaunchKernelGGL(ref_kernel, dim3((N + 255) / 256, rows), dim3(256), 0, 0, dA, dB, dR, M, N, K, m0, rows);
+            (void)hipMemcpy(hr.data(), dR, (size_t)rows * N * 4, hipMemcpyDeviceToHost);
+            for (int r = 0; r < rows; ++r)
+                for (int n = 0; n < N; ++n) {
+                    const float ref = hr[(size_t)r * N + n], got = h_bf2f(hc[(size_t)(m0 + r) * N + n]);
+                    const double err = fabs((double)ref - got), tol = 0.02 * sqrt((double)K) * 0.35 + 0.01 * fabs(ref);
+                    if (err > maxerr) maxerr = err;
+                    if (!(err <= tol)) {
+                        if (bad < 5) printf("  MISMATCH m=%d n=%d ref=%f got=%f\n", m0 + r, n, ref, got);
+                        ++bad;
+                    }
+                }
+        }
+        printf("  check %dx%dx%d: %s (max abs err %.4f, %d bad)\n", M, N, K, bad ? "FAIL" : "ok", maxerr, bad);
+        (void)hipFree(dR);
+    }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm8p_kernel, grid, block, lds, 0, dA, dB, dC, M, N, K, tiles_m, tiles_n);
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm8p_kernel, grid, block, lds, 0, dA, dB, dC, M, N, K, tiles_m, tiles_n);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("gemm8p %6d x %5d x %5d : %8.1f us  %7.1f TFLOP/s  (%d tiles, %.2f rounds)\n", M, N, K, us, tf, tiles_m * tiles_n,
+           tiles_m * tiles_n / 256.0);
+    (void)hipFree(dA), (void)hipFree(dB), (void)hipFree(dC);
+    return bad != 0;
+}
+
+int main(int argc, char** argv) {
+    int rc = 0;
+    if (argc >= 4) return run_case(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), 20, true);
+    rc |= run_case(256, 256, 128, 5, true);
+    rc |= run_case(512, 768, 256, 5, true);
+    rc |= run_case(4096, 4096, 4096, 30, true);
+    rc |= run_case(4096, 4096, 4096, 30, false);
+    rc |= run_case(8192, 8192, 8192, 10, false);
+    rc |= run_case(35840, 1536, 1152, 30, true);
+    rc |= run_case(35840, 1536, 4608, 20, false);
+    return rc;
+}
