@@ -10,7 +10,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 import torch  # noqa: F401  (load order matters)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "liba3t_hip.so")
+LIB_PATH = os.environ.get("A3T_LIB_PATH") or os.path.join(HERE, "lib", "liba3t_hip.so")   # (override: instrumented builds of tools/)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3
@@ -34,6 +34,7 @@ class GemmDesc(ctypes.Structure):
         ("s_dtype", c_int32), ("colsum_slots", c_int32),
         ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("drop_key", ctypes.c_uint32),
         ("drop_p", c_float), ("colsum_ss", c_int32),
+        ("keep_out", c_void_p), ("keep_in", c_void_p),
     ]
 
 
@@ -74,6 +75,7 @@ _SIGS = {
     "a3t_scale_dev": [_P, _P, c_int64, _P, _P],
     "a3t_slice_rows": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "a3t_cast_bf16": [_P, _P, c_int64, _P],
+    "a3t_cast_bf16_conv_t": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_split_bf16": [_P, _P, _P, c_int64, _P],
     "a3t_reflect_pad": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_stft_amp": [_P, _P, c_int64, c_int, c_int, _P],
@@ -91,10 +93,11 @@ _SIGS = {
     "a3t_replicate_pad": [_P, _P, c_int64, c_int64, c_int, c_int, _P],
     "a3t_bias_act": [_P, _P, c_int64, c_int, c_int, c_float, _P],
     "a3t_dropout": [_P, c_int, _P, c_int, c_int64, c_float, ctypes.c_uint32, c_float, _P],
-    "a3t_gemm_p256_mode": [c_int],
+    "a3t_gemm_8p_mode": [c_int],
+    "a3t_gemm_8p_supported": [c_int, c_int, c_int, c_int, c_int],
     "a3t_dropout_bwd_cast": [_P, _P, c_int, _P, c_float, c_int, c_int, c_float, ctypes.c_uint32, _P],
 }
-EXPORTS = sorted(list(_SIGS) + ["a3t_version", "a3t_gemm_last_kernel"])
+EXPORTS = sorted(list(_SIGS) + ["a3t_version", "a3t_gemm_last_kernel", "a3t_gemm_keep_bytes"])
 
 _lib = None
 
@@ -121,6 +124,8 @@ def load():
     lib.a3t_version.argtypes = []
     lib.a3t_gemm_last_kernel.restype = c_char_p
     lib.a3t_gemm_last_kernel.argtypes = []
+    lib.a3t_gemm_keep_bytes.restype = c_int64
+    lib.a3t_gemm_keep_bytes.argtypes = [c_int, c_int]
     _lib = lib
     return lib
 

@@ -27,8 +27,14 @@ __device__ __forceinline__ unsigned int rng_fmix32(unsigned int h) {
 }
 // One 32-bit hash serves an (even, odd) element pair, 16 random bits each (drop probability resolution 2^-16):
 // the vector kernels, which own 4-8 consecutive elements, pay half the integer work per element.
+// Round 3: the PCG output permutation (RXS-M-XS, the "pcg_hash" of Jarzynski & Olano, Hash Functions for GPU Rendering) on
+// the keyed counter -- 2 quarter-rate 32-bit multiplies per pair instead of the 5 of two murmur finalisers (the dropout
+// epilogue of a 256x256 GEMM tile is 64 hashes per lane with nothing to hide them behind).  The key is itself a mixed
+// 32-bit hash of (step seed, site) computed on the host.
 __device__ __forceinline__ unsigned int rng_pair(unsigned int key, unsigned int pair) {
-    return rng_fmix32(rng_fmix32(pair * 0x9E3779B1u + key) ^ key);
+    const unsigned int state = (pair + key) * 747796405u + 2891336453u;
+    const unsigned int word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
 }
 __device__ __forceinline__ bool rng_keep(unsigned int key, unsigned int idx, unsigned int thr) {
     const unsigned int h = rng_pair(key, idx >> 1);

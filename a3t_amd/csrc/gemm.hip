@@ -464,6 +464,10 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.drop_key = d->drop_key;
     p.drop_thr = (unsigned int)((double)d->drop_p * 4294967296.0);
     p.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 0.f;
+    p.keep_out = (unsigned char*)d->keep_out, p.keep_in = (const unsigned char*)d->keep_in;
+    p.a_bytes = p.b_bytes = 0;
+    const bool keep = p.keep_out || p.keep_in;
+    if (keep && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16)) return A3T_EINVAL;
     if (p.c_dtype == A3T_BF16 && p.accumulate != A3T_ACC_STORE) return A3T_EINVAL;
     const bool AK = (d->a_cs == 1), BKC = (d->b_cs == 1);
     if (!AK && d->a_rs != 1) return A3T_EINVAL;
@@ -512,6 +516,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         int rc = a3t_gemm_bf16_glds(p, batch, AK, BKC, stream);   // direct-to-LDS production kernel
         if (rc >= 0) return rc;                                   // -1: alignment contract not met
     }
+    if (keep) return A3T_EINVAL;        // keep-bit images only exist in the 8-phase kernel
     if (d->colsum) return A3T_EINVAL;   // fused column sums live in the direct-to-LDS kernel's epilogue
     {
         const int ea = d->a_dtype == A3T_BF16 ? 2 : 4, eb = d->b_dtype == A3T_BF16 ? 2 : 4;

@@ -447,8 +447,7 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 static inline bool m8(int64_t v) { return (v % 8) == 0; }
 
-int a3t_gemm_bf16_t256(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_t256.hip
-int a3t_gemm_bf16_p256(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_p256.hip
+int a3t_gemm_bf16_8p(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_8p.hip
 
 template <int LY, int ST, int WM, int CV, int WN = 2>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
@@ -482,13 +481,9 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
                  al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
     if (p.colsum && !pv.epi_vec) return -1;
 
-    {   // many-tile k-contiguous-A GEMMs: persistent 256x256 kernel with the epilogue folded into the K loop
-        const int rc = a3t_gemm_bf16_p256(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
-        if (rc >= 0) return rc;
-    }
-    {   // large GEMMs: 256x256 ping-pong kernel (returns -1 when the shape does not qualify)
-        const int rc = a3t_gemm_bf16_t256(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
-        if (rc >= 0) return rc;
+    {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
+        const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
+        if (rc != -1) return rc;
     }
     static int forced_st = -1;
     if (forced_st < 0) {

@@ -1,0 +1,580 @@
+// gemm_bf16_8p.hip -- 256x256x64 bf16 MFMA GEMM for gfx950 on the 8-phase schedule of the CDNA4 guide, as a persistent
+// kernel with the conv (im2col) loader and the epilogue folded into the load segments of the K loop.
+//
+// C[M][N] = epilogue( A[M][K] . B[N][K]^T ), both operands k-contiguous bf16 (Linear, Conv1d over time as implicit
+// im2col, and -- through a transposed weight shadow -- their data gradients), fp32 accumulate.
+//
+// Structure (calibrated stand-alone in tools/probes/gemm8p.hip: 1.22-1.32 PFLOP/s at 4096^3 on uniform random data):
+//   * 8 waves = 2 (wr) x 4 (wc).  LDS = 2 K-tile buffers x {A0, A1, B0, B1} half-tile images of 128 rows x 64 k (16 KiB
+//     each); wave (wr, wc) owns rows wr*64..+63 of both A halves and 32 rows of both B halves: a 128 x 64 output as four
+//     64 x 32 quadrants.  A K-tile is four phases (A0xB0, A0xB1, A1xB1, A1xB0) of 16 v_mfma_f32_16x16x32_bf16 each.
+//   * phase = [ds_read_b128 fragments | one half-tile of DMA (2 buffer_load ... lds per lane)] s_barrier
+//     [lgkmcnt(0) | setprio 1 | 16 MFMA | setprio 0] s_barrier.  Waves 4-7 run one barrier behind waves 0-3: every SIMD holds
+//     one wave of each group, one multiplies while the other loads.
+//   * DMA order B0, A0, B1, A1, issued 5-7 phases ahead of the first read; ONE counted wait per K-tile (vmcnt(6) in phase 4:
+//     the three youngest half-tiles stay in flight); a buffer is read one phase after the wait that retires it and
+//     restaged >= 2 phases after its last read (B0: 1 phase, behind an lgkmcnt that retires its reads before the barrier).
+//   * LDS images are lane-linear (DMA) with the 16-byte chunk index XOR (row & 7) applied to the SOURCE address and to the
+//     fragment read: conflict-free ds_read_b128.  Out-of-range rows / conv padding / K-tiles past the end read through the
+//     buffer descriptor's bounds check (voffset = 0x80000000 -> zeros), so the steady state is branch-free.
+//   * Persistent: one workgroup per CU walks tiles pos, pos + G, ...; the DMA cursor runs across tile boundaries (no
+//     per-tile prologue).  B rows are permuted in the LDS image so that a lane's accumulators of one quadrant row are 8
+//     CONSECUTIVE output columns (16-byte bf16 stores, 128-byte rows per wave) without any cross-lane exchange.
+//   * Epilogue per quadrant, in the load segments that follow its last MFMA phase (phase 2, phase 4 x 2, next phase 1),
+//     always issued BEFORE that segment's DMA or after the counted wait, so the vmcnt bookkeeping only ever sees DMA among
+//     the youngest six operations.  bias (fp32, via a 1-KiB DMA into LDS) -> relu -> keep-bit mask -> dropout -> alpha ->
+//     store bf16 | fp32, column sums (bias gradient) by DPP row reduction + atomics.
+//   * keep bits: the forward conv can emit one bit per output (value > 0 after relu/dropout) in a tile-major image
+//     (16 bytes per lane and tile); the matching data-gradient GEMM (same M x N output, same tiling) applies it as its
+//     ReLU'/dropout mask -- 1/16 of the bytes of re-reading the bf16 activations.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/a3t_hip.h"
+#include "gemm_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define LDS_AS(p) ((__attribute__((address_space(3))) void*)(p))
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define BAR()                                   \
+    do {                                        \
+        SB();                                   \
+        asm volatile("s_barrier" ::: "memory"); \
+        SB();                                   \
+    } while (0)
+#define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+#ifdef G8_TIMING
+__device__ unsigned long long g8_stamps[256 * 2 * 16];
+#define STAMP(k) do { if (lane == 0 && (w & 3) == 0 && (k) < 16) g8_stamps[(blockIdx.x * 2 + wr) * 16 + (k)] = wall_clock64(); } while (0)
+extern "C" int a3t_debug_read(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g8_stamps), bytes); }
+#else
+#define STAMP(k)
+#endif
+namespace {
+enum { HA0 = 0, HA1 = 1, HB0 = 2, HB1 = 3 };
+constexpr int HALF_BYTES = 128 * 64 * 2, TILE_BYTES = 4 * HALF_BYTES;
+constexpr int LDS_BIAS = 2 * TILE_BYTES;      // 2 x 1 KiB: fp32 bias of the tile's 256 columns, by tile parity
+constexpr int LDS_BITS = LDS_BIAS + 2048;     // 2 x 8 x 1 KiB: keep bits of the tile (16 B per lane), per wave, by tile parity
+constexpr int LDS_CSUM = LDS_BITS + 16384;    // 2 x 1 KiB: column sums of the tile's 256 columns (fp32), by tile parity
+constexpr int LDS_TOTAL = LDS_CSUM + 2048;    // 151 552 B
+constexpr unsigned OOB = 0x80000000u;         // voffset beyond every descriptor (host contract: operands < 2 GiB)
+
+__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row, result in every lane
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    return v;
+}
+}   // namespace
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, lane_ = lane;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), w_ = w;
+    const int wr = w >> 2, wc = w & 3;
+    const int G = gridDim.x;
+    int pos = blockIdx.x;
+    {   // bijective XCD remap: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of each round's tiles
+        const int q = G >> 3, r = G & 7, xcd = pos & 7;
+        pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pos >> 3);
+    }
+    const int tiles_n = p.tiles_n, ntiles = p.ntiles;
+    if (pos >= ntiles) return;
+    const int n_my = (ntiles - pos + G - 1) / G;
+    const int nk = p.K >> 6;             // host contract: K % 128 == 0
+    const int total = n_my * nk;
+    const int dm = G / tiles_n, dn = G % tiles_n;   // row-major tile order; stepping by G tiles without a division
+    auto step_tile = [&](int& tm, int& tn) __attribute__((always_inline)) {
+        tm += dm, tn += dn;
+        if (tn >= tiles_n) tn -= tiles_n, ++tm;
+    };
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+    // Epilogue-only parameters are NOT kept in SGPRs across the K loop (the kernel would spill ~80 of them): the epilogue
+    // re-reads them from the kernarg segment through a pointer the optimiser cannot see through.
+    typedef const __attribute__((address_space(4))) GP* kargp;
+#define EPI_ARGS(q) kargp q = (kargp)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q))
+
+    // ---- DMA lane geometry.  Wave instruction (half, q) fills LDS rows rho = (q*8 + w)*8 .. +7 of the half (1 KiB,
+    // lane-linear): lane -> row rho + (lane>>3), chunk position lane&7, which holds SOURCE chunk (lane&7) ^ (rho & 7).
+    // A half h holds tile rows h*128 + rho.  B half hb holds tile COLUMNS  n = (rho>>5)*64 + ((rho>>2)&3)*16 + hb*8 +
+    // ((rho>>4)&1)*4 + (rho&3): fragment row (16-block j, lane group g, register r) of wave wc is column
+    // wc*64 + g*16 + hb*8 + j*4 + r, i.e. a lane's 8 accumulators of one quadrant row are 8 consecutive columns.
+    const int srow = lane >> 3;
+    const unsigned schunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
+    const int rho0 = w * 8 + srow;                                            // q = 0; q = 1: rho0 + 64
+    const int nloc0 = (rho0 >> 5) * 64 + ((rho0 >> 2) & 3) * 16 + ((rho0 >> 4) & 1) * 4 + (rho0 & 3);   // q = 1: + 128
+    const unsigned a_rsb_ = (unsigned)p.a_rs * 2u, b_rsb_ = (unsigned)p.b_rs * 2u;
+    const int Tq = CONV ? p.Tseq : 1;
+
+    // issue cursor: uniform (unit, K-tile, tile, tap, channel) + per-lane row state of its tile
+    int c_unit = 0, c_kt = 0, c_tm = pos / tiles_n, c_tn = pos % tiles_n, c_tap = 0, c_c0 = 0;
+    unsigned voffA, voffB;
+    int tposA[2], nB0;     // tposA[h] = position inside the utterance of the lane's rows (q = 0 | q = 1 << 16), -16384: no such row
+    auto set_tile_lanes = [&]() __attribute__((always_inline)) {
+        const int m0 = c_tm * 256 + rho0;
+        voffA = (unsigned)m0 * a_rsb_ + schunk16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int t[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int m = m0 + h * 128 + q * 64;
+                t[q] = (m < p.M) ? (CONV ? m % p.Tseq : 0) : -16384;
+            }
+            tposA[h] = (t[0] & 0xffff) | (t[1] << 16);
+        }
+        nB0 = c_tn * 256 + nloc0;
+        voffB = (unsigned)nB0 * b_rsb_ + schunk16;
+    };
+    set_tile_lanes();
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++c_unit, ++c_kt;
+        if (CONV) {
+            c_c0 += 64;
+            if (c_c0 == p.Kc) c_c0 = 0, ++c_tap;
+        }
+        if (c_kt == nk) {
+            c_kt = 0, c_tap = 0, c_c0 = 0;
+            step_tile(c_tm, c_tn);
+            if (c_unit < total) set_tile_lanes();
+        }
+    };
+#ifdef G8_SIMPLE_ISSUE   // experiment: the probe's plain-GEMM address arithmetic on global_load_lds (no tails, no conv)
+    const unsigned voffS = (unsigned)(srow * p.K * 2) + schunk16;
+    auto issue = [&](const int H, const int buf) __attribute__((always_inline)) {
+        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + w * 1024;
+        const bool live = c_unit < total;
+        const size_t rs = (size_t)p.K * 2;
+        const char* base = (H < 2) ? (const char*)p.A + (size_t)(c_tm * 256 + w * 8 + (H & 1) * 128) * rs
+                                   : (const char*)p.B + (size_t)(c_tn * 256 + ((w * 8) >> 5) * 64 + (((w * 8) >> 2) & 3) * 16 + (((w * 8) >> 4) & 1) * 4 + (H & 1) * 8) * rs;
+        const unsigned lo = (H < 2) ? voffS : (unsigned)((((srow >> 2) & 1) * 16 + (srow & 3)) * p.K * 2) + schunk16;
+        base = live ? base + (size_t)c_kt * 128 : (const char*)p.B;
+        const size_t qs = (H < 2) ? 64 * rs : 128 * rs;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lo), LDS_AS(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + qs + lo), LDS_AS(dst + 8192), 16, 0, 0);
+    };
+    auto issue_unused = [&](const int H, const int buf) __attribute__((always_inline)) {
+#else
+    auto issue = [&](const int H, const int buf) __attribute__((always_inline)) {
+#endif
+        // (uniform address parts are recomputed here on purpose: hoisted out of the K loop they cost ~30 SGPRs and spill)
+        int wv = w;
+        unsigned a_rsb = a_rsb_, b_rsb = b_rsb_;
+        asm volatile("" : "+s"(wv), "+s"(a_rsb), "+s"(b_rsb));
+        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + wv * 1024;
+        const bool live = c_unit < total;
+        const int h = H & 1;
+        if (H < 2) {
+            const int shift = CONV ? (c_tap - p.pad) * p.dil : 0;
+            // (the descriptor's range check looks at voffset alone: the row offset -- which may be negative for the
+            //  first tap -- must live there, only the non-negative channel offset goes into soffset)
+            const unsigned so = CONV ? (unsigned)c_c0 * 2u : (unsigned)c_kt * 128u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int tp = q ? (tposA[h] >> 16) : (int)(short)(tposA[h] & 0xffff);
+                const bool ok = live && ((unsigned)(tp + shift) < (unsigned)Tq);
+                const unsigned vb = voffA + (unsigned)(h * 128 + q * 64 + shift) * a_rsb;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_AS(dst + q * 8192), 16, ok ? vb : OOB, so, 0, 0);
+            }
+        } else {
+            const unsigned so = (unsigned)(h * 8) * b_rsb + (unsigned)c_kt * 128u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = live && (nB0 + h * 8 + q * 128 < p.N);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_AS(dst + q * 8192), 16, ok ? voffB : OOB, so + (unsigned)(q * 128) * b_rsb, 0, 0);
+            }
+        }
+    };
+    // once per tile, in the first load segment of its first K-tile: bias of its 256 columns (wave 0) and its keep bits
+    auto tile_extras = [&](const int tm, const int tn, const int par) __attribute__((always_inline)) {
+        EPI_ARGS(q);
+        int lane = lane_, w = w_;
+        asm volatile("" : "+v"(lane), "+s"(w));
+        if (q->bias && w == 0) {
+            const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc((void*)q->bias, 0, q->N * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rBias, LDS_AS(smem + LDS_BIAS + par * 1024), 16, (unsigned)lane * 16u, (unsigned)tn * 1024u, 0, 0);
+        }
+        if (q->keep_in) {
+            const __amdgpu_buffer_rsrc_t rKeep = __builtin_amdgcn_make_buffer_rsrc((void*)q->keep_in, 0, q->ntiles * 8192, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rKeep, LDS_AS(smem + LDS_BITS + par * 8192 + w * 1024), 16, (unsigned)lane * 16u,
+                                                     (unsigned)((tm * tiles_n + tn) * 8 + w) * 1024u, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses: row (l&15) of a 16-row block, k chunk (s*4 + (l>>4)) ^ (row & 7)
+    const int fr = lane & 15, g = lane >> 4;
+    const unsigned fch = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);
+    const unsigned aoff = (unsigned)((wr * 64 + fr) * 128) + fch;     // + i*2048; ^64 for the second k step
+    const unsigned boff = (unsigned)((wc * 32 + fr) * 128) + fch;     // + j*2048
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto readA = [&](const unsigned char* img) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *(const bf16x8*)(img + i * 2048 + aoff);
+            fa[i][1] = *(const bf16x8*)(img + i * 2048 + (aoff ^ 64u));
+        }
+    };
+    auto readB = [&](const unsigned char* img, bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = *(const bf16x8*)(img + j * 2048 + boff);
+            fb[j][1] = *(const bf16x8*)(img + j * 2048 + (boff ^ 64u));
+        }
+    };
+    auto quad = [&](const int ha, const int hb, const bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ha][hb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][s], fa[i][s], acc[ha][hb][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- epilogue of quadrant (a, hb) of tile (tm, tn): lane (fr, g) owns rows a*128 + wr*64 + i*16 + fr (i = 0..3) x
+    // the 8 columns wc*64 + g*16 + hb*8 .. +7
+    auto epi = [&](const int a, const int hb, const int tm, const int tn, const int par) __attribute__((always_inline)) {
+#ifdef G8_NOEPI
+        return;
+#endif
+        EPI_ARGS(q);
+        // (everything derived from the lane id is recomputed here: hoisted out of the K loop these addresses would be spilled,
+        //  and a scratch reload costs a vmcnt(0), i.e. the whole DMA pipeline)
+        int lane = lane_, w = w_;
+        asm volatile("" : "+v"(lane), "+s"(w));
+        const int fr = lane & 15, g = lane >> 4, wr = w >> 2, wc = w & 3;
+        const int nloc = wc * 64 + g * 16 + hb * 8;
+        const int ncol = tn * 256 + nloc;
+        const bool nok = ncol < q->N;
+        float b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+        if (q->bias) {
+            const float4 b0 = *(const float4*)(smem + LDS_BIAS + par * 1024 + nloc * 4);
+            const float4 b1 = *(const float4*)(smem + LDS_BIAS + par * 1024 + nloc * 4 + 16);
+            b8[0] = b0.x, b8[1] = b0.y, b8[2] = b0.z, b8[3] = b0.w, b8[4] = b1.x, b8[5] = b1.y, b8[6] = b1.z, b8[7] = b1.w;
+        }
+        unsigned kin = 0xffffffffu, kout = 0u;
+        if (q->keep_in) kin = *(const unsigned*)(smem + LDS_BITS + par * 8192 + w * 1024 + lane * 16 + (a * 2 + hb) * 4);
+        float cs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = tm * 256 + a * 128 + wr * 64 + i * 16 + fr;
+            const bool ok = nok && (m < q->M);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[a][hb][i][e >> 2][e & 3] + b8[e];
+            if (q->act == A3T_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (q->keep_in) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = ((kin >> (i * 8 + e)) & 1u) ? v[e] : 0.f;
+            }
+            const int64_t idx = (int64_t)m * q->c_rs + ncol;
+            if (q->drop_inv > 0.f) {
+                const unsigned t = q->drop_thr >> 16;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const unsigned hsh = rng_pair(q->drop_key, ((unsigned)idx + (unsigned)e) >> 1);
+                    v[e] = ((hsh & 0xffffu) >= t) ? v[e] * q->drop_inv : 0.f;
+                    v[e + 1] = ((hsh >> 16) >= t) ? v[e + 1] * q->drop_inv : 0.f;
+                }
+            }
+            unsigned kb = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] *= q->alpha;
+                kb |= (v[e] > 0.f ? 1u : 0u) << e;
+            }
+            kout |= kb << (i * 8);
+            if (ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cs[e] += v[e];
+                if (q->c_dtype == A3T_BF16) {
+                    uint4 o;
+                    o.x = io_pack2(v[0], v[1]), o.y = io_pack2(v[2], v[3]), o.z = io_pack2(v[4], v[5]), o.w = io_pack2(v[6], v[7]);
+                    *(uint4*)((u16*)q->C + idx) = o;
+                } else {
+                    float* c = (float*)q->C + idx;
+                    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            acc[a][hb][i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[a][hb][i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (q->keep_out)
+            *(unsigned*)(q->keep_out + ((size_t)((tm * tiles_n + tn) * 8 + w) * 64 + lane) * 16 + (a * 2 + hb) * 4) = kout;
+        if (q->colsum) {   // LDS accumulators of this tile; csum_flush() sends them on once every wave is done with the tile
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] = row16_sum(cs[e]);
+            if (fr == 0) {
+                float* acc_l = (float*)(smem + LDS_CSUM + par * 1024) + nloc;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) __hip_atomic_fetch_add(acc_l + e, cs[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    // column sums of a finished tile (LDS, parity par): each wave forwards 32 of the 256 columns with ONE global atomic
+    // instruction and clears them.  Called >= 2 barriers after the tile's last quadrant epilogue.
+    auto csum_flush = [&](const int tn, const int par) __attribute__((always_inline)) {
+        EPI_ARGS(q);
+        int lane = lane_, w = w_;
+        asm volatile("" : "+v"(lane), "+s"(w));
+        if (q->colsum && lane < 32) {
+            float* a_l = (float*)(smem + LDS_CSUM + par * 1024) + w * 32 + lane;
+            const float v = *a_l;
+            *a_l = 0.f;
+            const int col = tn * 256 + w * 32 + lane;
+            if (col < q->N) atomicAdd(q->colsum + col, q->colsum_scale * v);
+        }
+    };
+
+    // ---- prologue: first tile's bias / keep bits, unit 0 complete, B0 A0 B1 of unit 1 (its A1 goes out in phase 1)
+    int u_tm = c_tm, u_tn = c_tn, u_kt = 0, u_par = 0;     // compute cursor
+    int e_tm = 0, e_tn = 0, e_par = 0;                     // tile whose last quadrant (A1 x B0) is still to be written
+    bool pend = false;
+    int f_tn = 0;                                          // column tile of the tile whose column sums await their flush
+    if (tid < 512) ((float*)(smem + LDS_CSUM))[tid] = 0.f;     // (made visible by the prologue barrier)
+    int st_k = 2;
+    (void)st_k;
+    STAMP(0);
+    tile_extras(u_tm, u_tn, 0);
+    issue(HB0, 0), issue(HA0, 0), issue(HB1, 0), issue(HA1, 0);
+    advance();
+    issue(HB0, 1), issue(HA0, 1), issue(HB1, 1);
+    WAIT_VM(6);            // unit 0 and the extras have landed (this wave's share)
+    WAIT_LGKM(0);          // (the cleared column-sum accumulators)
+    BAR();                 // ... everyone's share
+    if (wr == 1) BAR();    // second group runs one barrier behind
+    STAMP(1);
+
+    for (int u = 0; u < total; u += 2) {
+        // =================== even K-tile (buffer 0); the first K-tile of a tile is always even =====================
+        {
+            const unsigned char* cur = smem;
+            const bool first = (u_kt == 0);
+            // phase 1: A0 x B0.  DMA: A1 of the unit under the cursor (this unit + 1); then the cursor moves on
+            readB(cur + HB0 * HALF_BYTES, fb0);
+            SB();
+            readA(cur + HA0 * HALF_BYTES);
+            if (first && u > 0) tile_extras(u_tm, u_tn, u_par);
+            issue(HA1, 1);
+            advance();
+            WAIT_LGKM(8);      // the B0 reads have returned: B0 may be restaged in the next phase
+            if (pend) {
+                epi(1, 0, e_tm, e_tn, e_par);
+                pend = false;
+            }
+            BAR();
+            WAIT_LGKM(0);
+            SB();
+            quad(0, 0, fb0);
+            BAR();
+            // phase 2: A0 x B1.  DMA: B0 of unit + 2
+            readB(cur + HB1 * HALF_BYTES, fb1);
+            issue(HB0, 0);
+            BAR();
+            WAIT_LGKM(0);
+            SB();
+            quad(0, 1, fb1);
+            BAR();
+            // phase 3: A1 x B1.  DMA: A0 of unit + 2
+            readA(cur + HA1 * HALF_BYTES);
+            issue(HA0, 0);
+            BAR();
+            WAIT_LGKM(0);
+            SB();
+            quad(1, 1, fb1);
+            BAR();
+            // phase 4: A1 x B0.  DMA: B1 of unit + 2; all but the three youngest half-tiles have landed = unit + 1
+            issue(HB1, 0);
+            WAIT_VM(6);
+            if (first && u > 0) csum_flush(f_tn, u_par ^ 1);     // previous tile: every wave wrote its last quadrant 3 phases ago
+            BAR();
+            quad(1, 0, fb0);
+            BAR();
+        }
+        // =================== odd K-tile (buffer 1); the last K-tile of a tile is always odd ========================
+        {
+            const unsigned char* cur = smem + TILE_BYTES;
+            const bool last = (u_kt + 2 == nk);
+            readB(cur + HB0 * HALF_BYTES, fb0);
+            SB();
+            readA(cur + HA0 * HALF_BYTES);
+            issue(HA1, 0);
+            advance();
+            WAIT_LGKM(8);
+            BAR();
+            WAIT_LGKM(0);
+            SB();
+            quad(0, 0, fb0);
+            BAR();
+            // phase 2: the quadrant A0 x B0 is complete -> its epilogue goes out BEFORE this segment's DMA
+            readB(cur + HB1 * HALF_BYTES, fb1);
+            if (last) epi(0, 0, u_tm, u_tn, u_par);
+            issue(HB0, 1);
+            BAR();
+            WAIT_LGKM(0);
+            SB();
+            quad(0, 1, fb1);
+            BAR();
+            readA(cur + HA1 * HALF_BYTES);
+            issue(HA0, 1);
+            BAR();
+            WAIT_LGKM(0);
+            SB();
+            quad(1, 1, fb1);
+            BAR();
+            // phase 4: after the counted wait (its six youngest operations are DMA only): A0 x B1 and A1 x B1
+            issue(HB1, 1);
+            WAIT_VM(6);
+            if (last) {
+                epi(0, 1, u_tm, u_tn, u_par);
+                epi(1, 1, u_tm, u_tn, u_par);
+            }
+            BAR();
+            quad(1, 0, fb0);
+            BAR();
+            u_kt += 2;
+            if (last) {
+                STAMP(st_k);
+                ++st_k;
+                // A1 x B0 was just issued: it is written in the next load segment (or after the loop)
+                e_tm = u_tm, e_tn = u_tn, e_par = u_par, pend = true;
+                f_tn = u_tn;
+                u_kt = 0, u_par ^= 1;
+                step_tile(u_tm, u_tn);
+            }
+        }
+    }
+    if (pend) epi(1, 0, e_tm, e_tn, e_par);
+#ifdef G8_NOEPI   // (timing experiment: keep the accumulators alive)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
+#endif
+    STAMP(st_k);
+    WAIT_LGKM(0);
+    if (wr == 0) BAR();
+    BAR();                 // every wave has added its last column sums
+    csum_flush(f_tn, u_par ^ 1);
+    WAIT_VM(0);            // the trailing (zero) DMA must not outlive the workgroup's LDS allocation
+}
+
+static int g8_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <bool CV>
+static void launch_8p(const GP& pv, int grid, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_8p_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipLaunchKernelGGL((gemm_bf16_8p_kernel<CV>), dim3(grid), dim3(512), LDS_TOTAL, stream, pv);
+}
+
+// mode: 0 never, 1 whenever legal, 2 heuristic (default); A3T_GEMM_8P or a3t_gemm_8p_mode()
+static int g_8p_mode = -1;
+static int g8_mode() {
+    if (g_8p_mode < 0) {
+        const char* e = getenv("A3T_GEMM_8P");
+        g_8p_mode = e ? atoi(e) : 2;
+    }
+    return g_8p_mode;
+}
+extern "C" int a3t_gemm_8p_mode(int mode) {
+    const int old = g8_mode();
+    g_8p_mode = mode;
+    return old;
+}
+extern "C" int64_t a3t_gemm_keep_bytes(int M, int N) { return (int64_t)((M + 255) / 256) * ((N + 255) / 256) * 8192; }
+
+// Is the 8-phase kernel the one a3t_gemm picks for this problem?  (The engine asks before it chooses the keep-bit
+// protocol: both GEMMs of a pair must agree.)
+static bool g8_applicable(const GP& p, int batch, int ly, bool keep) {
+    const int mode = g8_mode();
+    if (mode == 0 || ly != 0 || batch != 1 || p.splitk != 1 || p.accumulate != A3T_ACC_STORE) return false;
+    if (p.K % 128 != 0 || p.N % 8 != 0 || p.c_rs % 8 != 0 || p.a_cs != 1 || p.b_cs != 1) return false;
+    if (p.R || p.S || p.kshift_mode) return false;
+    if (p.colsum && p.colsum_slots > 1) return false;
+    if (p.act != A3T_ACT_NONE && p.act != A3T_ACT_RELU) return false;
+    if (p.taps > 1 && (p.Kc % 64 != 0 || p.b_ts != p.Kc || p.Tseq <= 0)) return false;
+    if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return false;
+    if (p.bias && ((uintptr_t)p.bias & 15)) return false;
+    const int64_t a_bytes = ((int64_t)p.M * p.a_rs) * 2, b_bytes = ((int64_t)p.N * p.b_rs) * 2;
+    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || (int64_t)p.M * p.c_rs >= (1ll << 32)) return false;
+    if (keep && (p.N % 256 != 0)) return false;
+    if (mode == 2) {
+        // one 128-KiB workgroup per CU: it pays when the padded tile grid wastes little and a workgroup has enough K-tiles
+        // to amortise the pipeline fill (measured on MI355X, tools/ffn_gemm_bench.py)
+        const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+        const double fill = (double)p.M * p.N / ((double)tm * 256 * tn * 256);
+        if (fill < 0.9 || tm * tn < 128 || p.K < 768) return false;
+    }
+    return true;
+}
+
+extern "C" int a3t_gemm_8p_supported(int M, int N, int K, int taps, int keep) {
+    GP p = {};
+    p.M = M, p.N = N, p.K = K, p.taps = taps < 1 ? 1 : taps, p.Kc = K / p.taps, p.b_ts = p.Kc;
+    p.a_rs = p.Kc, p.a_cs = 1, p.b_rs = K, p.b_cs = 1, p.c_rs = N, p.splitk = 1, p.accumulate = A3T_ACC_STORE;
+    p.Tseq = 1, p.colsum_slots = 1;
+    return g8_applicable(p, 1, 0, keep != 0) ? 1 : 0;
+}
+
+// Called by a3t_gemm_bf16_glds after the alignment contract has been checked.  Returns -1 when not applicable.
+int a3t_gemm_bf16_8p(const GP& p, int batch, int ly, hipStream_t stream) {
+    const bool keep = p.keep_in || p.keep_out;
+    if (!g8_applicable(p, batch, ly, keep)) return keep ? A3T_EINVAL : -1;
+    GP pv = p;
+    const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+    pv.tiles_n = (int)tn;
+    pv.ntiles = (int)(tm * tn);
+    pv.a_bytes = (unsigned)(((int64_t)p.M * p.a_rs) * 2);
+    pv.b_bytes = (unsigned)(((int64_t)p.N * p.b_rs) * 2);
+    const int grid = (int)(pv.ntiles < g8_cus() ? pv.ntiles : g8_cus());
+    const bool conv = p.taps > 1;
+    if (conv)
+        launch_8p<true>(pv, grid, stream);
+    else
+        launch_8p<false>(pv, grid, stream);
+    a3t_note_kernel("gemm_bf16_8p_kernel<%s>", conv ? "true" : "false");
+    return (int)hipGetLastError();
+}

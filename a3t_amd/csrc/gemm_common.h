@@ -31,6 +31,10 @@ struct GP {
     int colsum_slots, colsum_ss;   // >1: atomics spread over `slots` accumulator copies, `ss` floats apart
     unsigned int drop_key, drop_thr;
     float drop_inv;   // 1/(1-p), 0 when dropout is off
+    // 8-phase kernel (gemm_bf16_8p.hip)
+    unsigned char* keep_out;        // optional: one keep bit per output (value > 0), tile-major image
+    const unsigned char* keep_in;   // optional: keep bits applied as a mask (written by the GEMM with the same M x N tiling)
+    unsigned int a_bytes, b_bytes;  // operand extents for the buffer descriptors
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return io_f2bf(f); }   // hardware RNE conversion

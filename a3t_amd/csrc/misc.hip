@@ -167,6 +167,35 @@ extern "C" int a3t_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
                        (unsigned short*)y, n / 4);
     return (int)hipGetLastError();
 }
+// Transposed bf16 shadow of Conv1d weights for the data gradient as a k-contiguous GEMM (gemm_bf16_8p.hip):
+// Wt[c][taps-1-t][n] = bf16(W[n][t][c]).  `count` weights of identical shape at element offsets src_off[i] / dst_off[i] of
+// the flat fp32 parameter buffer / the shadow buffer, one launch.  32 x 32 tiles of the (n, c) plane through LDS.
+__global__ __launch_bounds__(256) void cast_conv_t_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                         const int64_t* __restrict__ src_off, const int64_t* __restrict__ dst_off,
+                                                         int N, int taps, int C) {
+    __shared__ float tile[32][33];
+    const float* W = src + src_off[blockIdx.z];
+    unsigned short* Wt = dst + dst_off[blockIdx.z];
+    const int tc = (C + 31) / 32;
+    const int t = blockIdx.y, n0 = (blockIdx.x / tc) * 32, c0 = (blockIdx.x % tc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, c = c0 + tx;
+        tile[r][tx] = (n < N && c < C) ? W[((int64_t)n * taps + t) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, n = n0 + tx;
+        if (c < C && n < N) Wt[((int64_t)c * taps + (taps - 1 - t)) * N + n] = io_f2bf(tile[tx][r]);
+    }
+}
+extern "C" int a3t_cast_bf16_conv_t(const float* src, void* dst, const int64_t* src_off, const int64_t* dst_off, int count, int N,
+                                    int taps, int C, void* stream) {
+    if (count <= 0 || N <= 0 || taps <= 0 || C <= 0) return A3T_EINVAL;
+    dim3 grid((unsigned)(((N + 31) / 32) * ((C + 31) / 32)), (unsigned)taps, (unsigned)count);
+    hipLaunchKernelGGL(cast_conv_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, src_off, dst_off, N, taps, C);
+    return (int)hipGetLastError();
+}
 // x = hi + lo with hi = bf16(x), lo = bf16(x - hi): two bf16 GEMMs on (hi, lo) reproduce the fp32 operand to ~2^-17
 __global__ void split_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo,
                                   int64_t n4) {

@@ -119,6 +119,8 @@ class MLMEngine:
                     raise ValueError(f"compute='bf16' needs {n} % 8 == 0 (16-byte DMA granules), got {v}")
             self.flat16 = torch.zeros(store.total, dtype=torch.bfloat16, device=self.dev)
             self.p16 = {k: self.flat16[o:o + math.prod(s)].view(s) for k, (o, s) in store.offsets.items()}
+        self._keep_ok = {}
+        self._w2t = self._setup_w2t() if (self.bf16 and self.dev.type == "cuda") else None
 
     # ------------------------------------------------------------------ helpers
     def _drop(self, p, tag):
@@ -150,6 +152,36 @@ class MLMEngine:
     def refresh_weights(self):
         if self.bf16:
             ops.cast_bf16(self.store.flat, self.flat16)
+            if self._w2t is not None:
+                src_off, dst_off, _ = self._w2t
+                c = self.c
+                ops.cast_bf16_conv_t(self.store.flat, self.w2t_flat, src_off, dst_off, c.adim, c.ff_kernel, c.ff)
+
+    def _setup_w2t(self):
+        """Transposed bf16 shadows of every FFN w_2 ([d][k][ff] -> [ff][k'][d], taps reversed): the data gradient of the second
+        FFN conv becomes a k-contiguous conv of the output gradient, which the 8-phase GEMM runs with the keep-bit mask the
+        forward conv left behind.  One transposing cast per step for all of them."""
+        c = self.c
+        names = [k for k in self.store.offsets if k.endswith(".w2") and tuple(self.store.offsets[k][1]) == (c.adim, c.ff_kernel, c.ff)]
+        if not names:
+            return None
+        n = c.adim * c.ff_kernel * c.ff
+        self.w2t_flat = torch.zeros(n * len(names), dtype=torch.bfloat16, device=self.dev)
+        src = torch.tensor([self.store.offsets[k][0] for k in names], dtype=torch.int64, device=self.dev)
+        dst = torch.arange(len(names), dtype=torch.int64, device=self.dev) * n
+        views = {k: self.w2t_flat[i * n:(i + 1) * n].view(c.ff, c.ff_kernel, c.adim) for i, k in enumerate(names)}
+        return (src, dst, views)
+
+    def _ffn_keep(self, M):
+        """True when both halves of the keep-bit protocol (forward conv 1 writes, data gradient of conv 2 reads) run on the
+        8-phase GEMM for this token count."""
+        c = self.c
+        if not self.bf16 or self._w2t is None or os.environ.get("A3T_FFN_KEEPBITS", "1") == "0":
+            return False
+        key = ("keep", M)
+        if key not in self._keep_ok:
+            self._keep_ok[key] = ops.gemm_8p_supported(M, c.ff, c.ff_kernel * c.adim, c.ff_kernel, keep=True)
+        return self._keep_ok[key]
 
     def _act(self, name, shape):
         return self.ws.get(name, shape, self.adt)
@@ -274,19 +306,22 @@ class MLMEngine:
         pad = (c.ff_kernel - 1) // 2
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
         h = self._act(tag + ".h", (M, c.ff))
+        keep = None
+        if self._ffn_keep(M):     # one bit per element of h (value > 0 after relu / dropout) for the backward mask
+            keep = self.ws.get(tag + ".keep", (ops.gemm_keep_bytes(M, c.ff),), torch.uint8)
         ops.conv_fwd(y, self.W(pre + ".w1"), h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=self.cmp,
-                     drop=self._drop(c.dropout_rate, tag + ".h"))
+                     drop=self._drop(c.dropout_rate, tag + ".h"), keep_out=keep)
         xo = self.ws.get(tag + ".xo", (M, c.adim))
         ops.conv_fwd(h, self.W(pre + ".w2"), xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=self.cmp,
                      drop=self._drop(c.dropout_rate, tag + ".o"))
-        self.sv[tag] = (y, h)
+        self.sv[tag] = (y, h, keep)
         return xo
 
     def _ffn_bwd(self, tag, pre, g, T, nb=None, nxt=None):
         """g = grad wrt the sub-layer output (fp32 residual stream, updated in place to the grad wrt
         the sub-layer input); in bf16 mode grad.x16 holds the same values in bf16 on entry and exit."""
         p, gr, c = self.store.p, self.store.g, self.c
-        y, h = self.sv[tag]
+        y, h, keep = self.sv[tag]
         M = g.shape[0]
         pad = (c.ff_kernel - 1) // 2
         self._sub_begin()
@@ -297,8 +332,13 @@ class MLMEngine:
         # (without dropout b2's gradient = 0.5*colsum(g) was accumulated by the LayerNorm backward that
         #  produced g; the dropout on h folds into the relu mask S=h>0 and the 1/(1-p) factor)
         hd = self._drop(c.dropout_rate, tag + ".h")
-        ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=0.5 / (1.0 - hd[0]) if hd else 0.5,
-                          compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
+        a_dh = 0.5 / (1.0 - hd[0]) if hd else 0.5
+        if keep is not None:     # k-contiguous conv of ga with the transposed weights, masked by the forward's keep bits
+            ops.conv_fwd(ga, self._w2t[2][pre + ".w2"], dh, T, c.ff_kernel - 1 - pad, alpha=a_dh, compute=self.cmp,
+                         keep_in=keep, colsum=gr[pre + ".b1"])
+        else:
+            ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=a_dh,
+                              compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
         self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp))
         dy = self._act("tmp.dy", (M, c.adim))
         ops.conv_bwd_data(dh, self.W(pre + ".w1"), dy, T, pad, compute=self.cmp)

@@ -37,7 +37,7 @@ def _dt(t):
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
          act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
-         drop=None, colsum_slots=1, colsum_ss=0):
+         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -59,6 +59,8 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.colsum_bs1, d.colsum_scale = colsum_bs1, colsum_scale
     d.colsum_slots, d.colsum_ss = colsum_slots, colsum_ss
     d.drop_p, d.drop_key = (drop if drop is not None else (0.0, 0))
+    d.keep_out = keep_out.data_ptr() if keep_out is not None else None
+    d.keep_in = keep_in.data_ptr() if keep_in is not None else None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -105,11 +107,22 @@ def linear_bwd_weight(dy, x, dW, alpha=1.0, compute=F32):
 
 
 # ---- Conv1d over time as implicit-im2col GEMM; weights kept as Wk[N][taps][Cin] --------------
-def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None):
+def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None,
+             keep_out=None, keep_in=None, colsum=None):
     M, Cin = x.shape
     N, taps, _ = Wk.shape
     gemm(x, Wk, out, M, N, taps * Cin, Cin, 1, taps * Cin, 1, N, b_ts=Cin, bias=bias, R=R, taps=taps, pad=pad,
-         dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute, drop=drop)
+         dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute, drop=drop, keep_out=keep_out, keep_in=keep_in,
+         colsum=colsum)
+
+
+def gemm_8p_supported(M, N, K, taps=1, keep=False):
+    """True when a3t_gemm runs this k-contiguous bf16 problem on the persistent 8-phase kernel (csrc/gemm_bf16_8p.hip)."""
+    return bool(L.load().a3t_gemm_8p_supported(int(M), int(N), int(K), int(taps), int(bool(keep))))
+
+
+def gemm_keep_bytes(M, N):
+    return int(L.load().a3t_gemm_keep_bytes(int(M), int(N)))
 
 
 def conv_bwd_data(dy, Wk, dx, Tseq, pad, dil=1, S=None, alpha=1.0, compute=F32, colsum=None):
@@ -308,6 +321,12 @@ def attn_bias_fold(slots, S, d, gu, gv, gbqkv):
 
 def cast_bf16(x, y):
     L.check(L.load().a3t_cast_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "cast_bf16")
+
+
+def cast_bf16_conv_t(src_flat, dst, src_off, dst_off, N, taps, C):
+    """Transposed, tap-reversed bf16 shadows of src_off.numel() conv weights [N][taps][C] of the flat fp32 buffer."""
+    L.check(L.load().a3t_cast_bf16_conv_t(_ptr(src_flat), _ptr(dst), _ptr(src_off), _ptr(dst_off), src_off.numel(), N, taps, C,
+                                          _stream()), "cast_bf16_conv_t")
 
 
 def split_bf16(x, hi, lo):

@@ -88,9 +88,19 @@ typedef struct a3t_gemm_desc {
     uint32_t drop_key;                 /* dropout fused into the epilogue (after act / mask, before alpha): */
     float drop_p;                      /*   v = keep(drop_key, linear index in C) ? v/(1-p) : 0 ; p = 0 disables */
     int32_t colsum_ss;                 /* slot stride (floats) of the spread column sums */
+    void* keep_out;                    /* optional (8-phase kernel only, N % 256 == 0): one bit per output = (stored value > 0), */
+    const void* keep_in;               /*   in the kernel's tile-major image of a3t_gemm_keep_bytes(M, N) bytes; keep_in applies
+                                            such an image as a mask in the place of S (the ReLU'/dropout mask of
+                                            multi_layer_conv.py:52-63's hidden layer on its way back).  a3t_gemm fails with
+                                            A3T_EINVAL when either is set and the 8-phase kernel does not take the problem:
+                                            ask a3t_gemm_8p_supported first. */
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
+/* 1 when a3t_gemm runs the k-contiguous bf16 problem (M, N, K = taps * channels) on the persistent 256x256 8-phase kernel
+ * (csrc/gemm_bf16_8p.hip) -- keep != 0: with keep_out / keep_in; bytes of a keep-bit image */
+int a3t_gemm_8p_supported(int M, int N, int K, int taps, int keep);
+int64_t a3t_gemm_keep_bytes(int M, int N);
 
 /* LayerNorm over the last dim (transformer/layer_norm.py:12-42 eps=1e-12; torch.nn.LayerNorm
  * eps=1e-5 in the speech embed, conformer/encoder.py:404).  mean/rstd: [M] saved for backward. */
@@ -220,6 +230,11 @@ int a3t_slice_rows(const float* x, void* y, int y_dtype, int B, int T, int Tm, i
                    void* stream);
 /* fp32 -> bf16 (round to nearest even); n % 4 == 0 (the flat parameter buffer once per step) */
 int a3t_cast_bf16(const float* x, void* y, int64_t n, void* stream);
+/* Transposed bf16 shadows of `count` Conv1d weights W[N][taps][C] (multi_layer_conv.py:36-50) living at element offsets
+ * src_off[i] of the flat fp32 buffer `src`: dst[dst_off[i] + (c*taps + taps-1-t)*N + n] = bf16(W[n][t][c]) -- the B operand of
+ * the conv's data gradient written as a forward conv of dy (k-contiguous, pad' = taps-1-pad).  Offsets live on the device. */
+int a3t_cast_bf16_conv_t(const float* src, void* dst, const int64_t* src_off, const int64_t* dst_off, int count, int N,
+                         int taps, int C, void* stream);
 /* hi = bf16(x), lo = bf16(x - hi): a pair of bf16 GEMM operands that carries an fp32 tensor to ~2^-17 relative (the first
  * postnet conv reads the log-mel-scale `before`, tacotron2/decoder.py:165-267, whose bf16 ulp would otherwise be amplified
  * by five BatchNorm layers); n % 4 == 0 */
@@ -291,9 +306,9 @@ const char* a3t_version(void);
 /* Name (as rocprofv3 prints it, without "void " / "(GP)") of the kernel variant a3t_gemm's dispatcher launched last on
  * the calling thread -- lets a profiler harness attribute event-bracketed launches to kernel-trace rows. */
 const char* a3t_gemm_last_kernel(void);
-/* Kernel-selection override for A/B measurements and tests: 0 = never use the persistent 256x256 GEMM, 1 = whenever the
- * descriptor is legal for it, 2 = the built-in heuristic, -1 = re-read A3T_GEMM_P256.  Returns the previous mode. */
-int a3t_gemm_p256_mode(int mode);
+/* Kernel-selection override for A/B measurements and tests: 0 = never use the persistent 256x256 8-phase GEMM, 1 = whenever
+ * the descriptor is legal for it, 2 = the built-in heuristic, -1 = re-read A3T_GEMM_8P.  Returns the previous mode. */
+int a3t_gemm_8p_mode(int mode);
 
 #ifdef __cplusplus
 }

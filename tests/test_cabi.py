@@ -42,4 +42,5 @@ def test_gemm_desc_layout_matches_header():
     assert GemmDesc.a_rs.offset == 64 and GemmDesc.c_rs.offset == 104
     assert GemmDesc.batch.offset == 112 and GemmDesc.a_bs0.offset == 120
     assert GemmDesc.taps.offset == 168 and GemmDesc.alpha.offset == 188
-    assert GemmDesc.s_dtype.offset == 220 and GemmDesc.colsum.offset == 232 and GemmDesc.drop_p.offset == 256 and ctypes.sizeof(GemmDesc) == 264
+    assert GemmDesc.s_dtype.offset == 220 and GemmDesc.colsum.offset == 232 and GemmDesc.drop_p.offset == 256
+    assert GemmDesc.keep_out.offset == 264 and GemmDesc.keep_in.offset == 272 and ctypes.sizeof(GemmDesc) == 280

@@ -609,64 +609,75 @@ def test_gemm_dispatch_randomised_sweep():
     assert len(glds) >= 8, seen
 
 
-def test_persistent_gemm_randomised_sweep_and_ab():
-    """The opt-in persistent 256x256 GEMM (gemm_bf16_p256.hip) must agree with fp32 torch math on the same random sweep and
-    with the 128x128 kernel on the model's conv-FFN launches with their fused epilogues (bias + relu + dropout; ReLU' mask +
-    column sums; residual + fp32 output), including M / N tails and a partial last round."""
+def test_8phase_gemm_randomised_sweep_and_ab():
+    """The persistent 8-phase 256x256 GEMM (gemm_bf16_8p.hip) must agree with fp32 torch math on the random sweep (forced
+    on for every problem it accepts) and, bit for bit, with the 128x128 kernel on the model's conv-FFN launches with their
+    fused epilogues: bias + relu + dropout (+ keep bits out); the data gradient through the transposed weight shadow with the
+    keep-bit mask and fused column sums against the strided-W / S = h formulation; M / N tails; fp32 output."""
     import fuzz_gemm as mod
     from a3t_amd import _lib
     from a3t_amd._lib import ACT_RELU, BF16
     ops = _ops()
     lib = _lib.load()
-    old = lib.a3t_gemm_p256_mode(1)
+    old = lib.a3t_gemm_8p_mode(1)
     try:
-        fails, seen = mod.run(seed=11, n_cases=40, verbose=False)
+        fails, seen = mod.run(seed=11, n_cases=60, verbose=False)
         assert fails == 0
-        assert sum(v for k, v in seen.items() if k.startswith("gemm_bf16_p256_kernel")) >= 20, seen
+        assert sum(v for k, v in seen.items() if k.startswith("gemm_bf16_8p_kernel")) >= 5, seen
     finally:
-        lib.a3t_gemm_p256_mode(0)
+        lib.a3t_gemm_8p_mode(old)
     g = torch.Generator(device=DEV).manual_seed(0)
     rn = lambda *s, sc=1.0: torch.randn(*s, device=DEV, generator=g) * sc
     B, T, d, ff = 9, 1120, 384, 1536          # 40 row tiles x 6 column tiles = 240 tiles: one partial round on 256 CUs
-    M = B * T - 8                              # (M tail inside the last row tile; Tseq no longer divides M: plain linears)
-    y, x = rn(B * T, d).bfloat16(), rn(B * T, d)
+    M = B * T
+    y = rn(M, d).bfloat16()
     W1, W2 = rn(ff, 3, d, sc=0.03).bfloat16(), rn(d, 3, ff, sc=0.02).bfloat16()
-    b1, b2 = rn(ff), rn(d)
-    hh, ga = torch.relu(rn(B * T, ff)).bfloat16(), rn(B * T, d).bfloat16()
+    W2t = W2.permute(2, 1, 0).flip(1).contiguous()
+    b1 = rn(ff)
+    ga = rn(M, d).bfloat16()
     Wl, bl = rn(544, d, sc=0.05).bfloat16(), rn(544)
+    Mt = M - 8
 
-    def run_all():
+    def run_all(keepbits):
         outs = []
-        h = torch.empty(B * T, ff, device=DEV, dtype=torch.bfloat16)
-        ops.conv_fwd(y, W1, h, T, 1, bias=b1, act=ACT_RELU, compute=BF16, drop=(0.2, 777))
+        h = torch.empty(M, ff, device=DEV, dtype=torch.bfloat16)
+        keep = torch.zeros(ops.gemm_keep_bytes(M, ff), dtype=torch.uint8, device=DEV) if keepbits else None
+        ops.conv_fwd(y, W1, h, T, 1, bias=b1, act=ACT_RELU, compute=BF16, drop=(0.2, 777), keep_out=keep)
         outs.append((lib.a3t_gemm_last_kernel().decode(), h))
-        xo = torch.empty(B * T, d, device=DEV)
-        ops.conv_fwd(hh, W2, xo, T, 1, bias=b2, R=x, alpha=0.5, compute=BF16, drop=(0.1, 5))
-        outs.append((lib.a3t_gemm_last_kernel().decode(), xo))
-        dh, gb = torch.empty(B * T, ff, device=DEV, dtype=torch.bfloat16), torch.zeros(ff, device=DEV)
-        ops.conv_bwd_data(ga, W2, dh, T, 1, S=hh, alpha=0.625, compute=BF16, colsum=gb)
+        dh, gb = torch.empty(M, ff, device=DEV, dtype=torch.bfloat16), torch.zeros(ff, device=DEV)
+        if keepbits:
+            ops.conv_fwd(ga, W2t, dh, T, 1, alpha=0.625, compute=BF16, keep_in=keep, colsum=gb)
+        else:
+            ops.conv_bwd_data(ga, W2, dh, T, 1, S=h, alpha=0.625, compute=BF16, colsum=gb)
         outs.append((lib.a3t_gemm_last_kernel().decode(), dh))
         outs.append(("colsum", gb))
-        o = torch.empty(M, 544, device=DEV)
-        ops.linear_fwd(y[:M], Wl, o, bias=bl, R=rn(M, 544) * 0, act=ACT_RELU, alpha=0.7, compute=BF16)
+        o = torch.empty(Mt, 544, device=DEV)
+        ops.linear_fwd(y[:Mt], Wl, o, bias=bl, act=ACT_RELU, alpha=0.7, compute=BF16)
         outs.append((lib.a3t_gemm_last_kernel().decode(), o))
-        dx = torch.empty(M, d, device=DEV, dtype=torch.bfloat16)
-        ops.linear_bwd_data(o.bfloat16(), Wl, dx, compute=BF16)
-        outs.append((lib.a3t_gemm_last_kernel().decode(), dx))
         torch.cuda.synchronize()
         return outs
 
-    ref = run_all()
-    lib.a3t_gemm_p256_mode(1)
+    lib.a3t_gemm_8p_mode(0)
     try:
-        got = run_all()
+        ref = run_all(False)
+        lib.a3t_gemm_8p_mode(1)
+        got = run_all(True)
     finally:
-        lib.a3t_gemm_p256_mode(old if old >= 0 else 0)
-    assert sum("p256" in k for k, _ in got) == 5 and not any("p256" in k for k, _ in ref), [k for k, _ in got]
+        lib.a3t_gemm_8p_mode(old)
+    assert sum("8p" in k for k, _ in got) == 3 and not any("8p" in k for k, _ in ref), [k for k, _ in got]
     for (kr, a), (kg, b) in zip(ref, got):
-        # same products, different fp32 summation order (K rotation): bf16 outputs may differ by one rounding step
-        err = float((a.float() - b.float()).abs().max() / (a.float().abs().max() + 1e-9))
-        assert err < 6e-3, (kr, kg, err)
+        if kr == "colsum":      # fp32 atomics in a different order
+            assert float((a - b).abs().max() / (a.abs().max() + 1e-9)) < 1e-5
+        else:                   # same products in the same k order: identical results
+            assert torch.equal(a, b), (kr, kg, float((a.float() - b.float()).abs().max()))
+    # keep bits without the 8-phase kernel must be refused, not ignored
+    lib.a3t_gemm_8p_mode(0)
+    try:
+        with pytest.raises(_lib.A3TLibraryError):
+            ops.conv_fwd(y, W1, torch.empty(M, ff, device=DEV, dtype=torch.bfloat16), T, 1, compute=BF16,
+                         keep_out=torch.zeros(ops.gemm_keep_bytes(M, ff), dtype=torch.uint8, device=DEV))
+    finally:
+        lib.a3t_gemm_8p_mode(old)
 
 
 def test_row_kernels_randomised_sweep():

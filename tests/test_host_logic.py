@@ -152,12 +152,15 @@ def test_gemm_register_budget():
         four_per_cu = wn == 2 and (conv in (0, 1) or (conv == 2 and layout == 2))
         assert r["VGPRs"] <= (128 if four_per_cu else 168), (name, r["VGPRs"])
     assert seen >= 22
-    # the persistent 256x256 kernel runs one 512-thread workgroup per CU: 256 registers per wave, no scratch
-    path = path.replace("gemm_bf16.resources.json", "gemm_bf16_p256.resources.json")
+    # the persistent 8-phase 256x256 kernel runs one 512-thread workgroup per CU: 256 registers per wave, and NOTHING may
+    # spill -- a scratch reload inside its K loop is a vector-memory operation whose wait (vmcnt(0)) drains the DMA pipeline,
+    # and spilled SGPRs (the descriptor has ~50 scalar fields) cost VGPR lanes and readlane traffic in every load segment
+    path = path.replace("gemm_bf16.resources.json", "gemm_bf16_8p.resources.json")
     rows = json.load(open(path))
-    assert len(rows) == 8
+    assert len(rows) >= 2
     for name, r in rows.items():
         assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs"] <= 256, (name, r["VGPRs"])
+        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0, (name, r)
 
 
 def test_sedit_driver_span_arithmetic_matches_reference():

@@ -49,6 +49,13 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const u16* __restrict__ A, const u16* __restrict__ B, u16* __restrict__ C,
                                                         int M, int N, int K, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -210,6 +217,198 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const u16* __restrict__ 
                 }
 }
 
+
+#ifdef TIMING
+__device__ unsigned long long g_stamps[256 * 2 * 16];
+#define STAMP(k) do { if (lane == 0 && (w & 3) == 0 && (k) < 16) g_stamps[(blockIdx.x * 2 + wr) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define STAMP(k)
+#endif
+// ---- v2: persistent workgroups, the DMA stream runs across tile boundaries (no per-tile prologue), 16-byte epilogue stores
+// (v_permlane16_swap pairs the two 16-column blocks of a wave so that a lane owns 8 consecutive columns).
+__global__ __launch_bounds__(512, 2) void gemm8p_persist(const u16* __restrict__ A, const u16* __restrict__ B, u16* __restrict__ C,
+                                                         const u16* __restrict__ ZP, int M, int N, int K, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int G = gridDim.x;
+    int pos = blockIdx.x;
+    {
+        const int q = G >> 3, r = G & 7, xcd = pos & 7;
+        pos = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (pos >> 3);
+    }
+    const int ntiles = tiles_m * tiles_n;
+    if (pos >= ntiles) return;
+    const int n_my = (ntiles - pos + G - 1) / G;
+    const int nk = K / 64;
+    const int total = n_my * nk;
+    // row-major tile order (column tile fastest); stepping by G tiles needs no division inside the loop
+    const int dm = G / tiles_n, dn = G % tiles_n;
+    auto step_tile = [&](int& tm, int& tn) __attribute__((always_inline)) {
+        tm += dm, tn += dn;
+        if (tn >= tiles_n) tn -= tiles_n, ++tm;
+    };
+    int c_tm = pos / tiles_n, c_tn = pos % tiles_n;     // issue cursor's tile
+    int u_tm = c_tm, u_tn = c_tn;                       // compute cursor's tile
+
+    const int srow = lane >> 3, schunk = (lane & 7) ^ (lane >> 3);
+    const unsigned int voffA = (unsigned)(srow * K + schunk * 8) * 2u;
+    const size_t hstep = (size_t)128 * K * 2, qstep = (size_t)64 * K * 2;
+    // issue cursor (all uniform)
+    int c_unit = 0, c_kt = 0, c_ord = 0;
+    const char *gA, *gB;
+    auto set_tile = [&]() __attribute__((always_inline)) {
+        gA = (const char*)(A + (size_t)(c_tm * 256 + w * 8) * K);
+        gB = (const char*)(B + (size_t)(c_tn * 256 + w * 8) * K);
+    };
+    set_tile();
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++c_unit, ++c_kt;
+        if (c_kt == nk) {
+            c_kt = 0, ++c_ord;
+            step_tile(c_tm, c_tn);
+            if (c_unit < total) set_tile();
+        }
+    };
+    auto issue = [&](const int H, const int buf) __attribute__((always_inline)) {
+        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + w * 1024;
+        const bool live = c_unit < total;
+        const char* base = live ? ((H < 2) ? gA : gB) + (size_t)(H & 1) * hstep + (size_t)c_kt * 128 : (const char*)ZP;
+        const unsigned int vo = live ? voffA : 0u;
+        const size_t qs = live ? qstep : 0;
+        __builtin_amdgcn_global_load_lds(GLB_AS(base + vo), LDS_AS(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_AS(base + qs + vo), LDS_AS(dst + 8192), 16, 0, 0);
+    };
+
+    const int frow = lane & 15;
+    const unsigned int fch = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4);
+    const unsigned int aoff = (unsigned)((wr * 64 + frow) * 128) + fch;
+    const unsigned int boff = (unsigned)((wc * 32 + frow) * 128) + fch;
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto readA = [&](const unsigned char* img) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i][0] = *(const bf16x8*)(img + i * 2048 + aoff);
+            fa[i][1] = *(const bf16x8*)(img + i * 2048 + (aoff ^ 64u));
+        }
+    };
+    auto readB = [&](const unsigned char* img, bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            fb[j][0] = *(const bf16x8*)(img + j * 2048 + boff);
+            fb[j][1] = *(const bf16x8*)(img + j * 2048 + (boff ^ 64u));
+        }
+    };
+    auto quad = [&](const int ha, const int hb, const bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ha][hb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][s], fa[i][s], acc[ha][hb][i][j], 0, 0, 0);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: unit 0 complete + B0, A0, B1 of unit 1; the cursor then stands at unit 1 (its A1 goes out in phase 1)
+    STAMP(0);
+    issue(HB0, 0), issue(HA0, 0), issue(HB1, 0), issue(HA1, 0);
+    advance();
+    issue(HB0, 1), issue(HA0, 1), issue(HB1, 1);
+    WAIT_VM(6);
+    BAR();
+    if (wr == 1) BAR();
+    STAMP(1);
+
+    auto ktile = [&](const int buf) __attribute__((always_inline)) {
+        const unsigned char* cur = smem + buf * TILE_BYTES;
+        // phase 1: A0 x B0;  DMA: A1 of the unit under the cursor (= this unit + 1), then the cursor moves on
+        readB(cur + HB0 * HALF_BYTES, fb0);
+        SB();
+        readA(cur + HA0 * HALF_BYTES);
+        issue(HA1, buf ^ 1);
+        advance();
+        WAIT_LGKM(8);
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(0, 0, fb0);
+        BAR();
+        // phase 2: A0 x B1;  DMA: B0 of unit + 2
+        readB(cur + HB1 * HALF_BYTES, fb1);
+        issue(HB0, buf);
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(0, 1, fb1);
+        BAR();
+        // phase 3: A1 x B1;  DMA: A0 of unit + 2
+        readA(cur + HA1 * HALF_BYTES);
+        issue(HA0, buf);
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(1, 1, fb1);
+        BAR();
+        // phase 4: A1 x B0;  DMA: B1 of unit + 2; everything but the three youngest half-tiles has landed = unit + 1
+        issue(HB1, buf);
+        WAIT_VM(6);
+        BAR();
+        quad(1, 0, fb0);
+        BAR();
+    };
+
+    int u_kt = 0, u_ord = 0;
+    for (int u = 0; u < total; u += 2) {
+        ktile(0);
+        ktile(1);
+        u_kt += 2;
+        if (u_kt == nk) {
+            const int tm = u_tm, tn = u_tn;
+            STAMP(2 + u_ord * 2);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        f32x4 x = acc[a][b][i][0], y = acc[a][b][i][1];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+                            x[r] = __uint_as_float(sw[0]), y[r] = __uint_as_float(sw[1]);
+                        }
+                        const int g = lane >> 4;
+                        const int m = tm * 256 + a * 128 + wr * 64 + i * 16 + (lane & 15);
+                        const int n = tn * 256 + b * 128 + wc * 32 + (g & 1) * 16 + (g >> 1) * 8;
+                        uint4 o;
+                        o.x = pack2(x[0], x[1]), o.y = pack2(x[2], x[3]), o.z = pack2(y[0], y[1]), o.w = pack2(y[2], y[3]);
+                        *(uint4*)(C + (size_t)m * N + n) = o;
+                        acc[a][b][i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[a][b][i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            STAMP(3 + u_ord * 2);
+            u_kt = 0, ++u_ord;
+            step_tile(u_tm, u_tn);
+        }
+    }
+    if (wr == 0) BAR();
+    WAIT_VM(0);
+}
+
 // ---- reference: one thread per output, fp32 accumulate ------------------------------------------------------------
 __global__ void ref_kernel(const u16* A, const u16* B, float* C, int M, int N, int K, int m0, int rows) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = m0 + blockIdx.y;
@@ -233,6 +432,7 @@ static float h_bf2f(u16 h) {
     return f;
 }
 
+static int g_variant = 1, g_grid = 256, g_extra_lds = 0;
 static int run_case(int M, int N, int K, int iters, bool check) {
     const size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
     std::vector<u16> ha(na), hb(nb);
@@ -249,10 +449,19 @@ static int run_case(int M, int N, int K, int iters, bool check) {
     (void)hipMemcpy(dB, hb.data(), nb * 2, hipMemcpyHostToDevice);
     (void)hipMemset(dC, 0xff, nc * 2);
     const int tiles_m = M / 256, tiles_n = N / 256;
-    const int lds = 2 * TILE_BYTES;
+    const int lds = 2 * TILE_BYTES + g_extra_lds;
     (void)hipFuncSetAttribute((const void*)gemm8p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    dim3 grid(tiles_m * tiles_n), block(512);
-    hipLaunchKernelGGL(gemm8p_kernel, grid, block, lds, 0, dA, dB, dC, M, N, K, tiles_m, tiles_n);
+    (void)hipFuncSetAttribute((const void*)gemm8p_persist, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    u16* dZ;
+    (void)hipMalloc(&dZ, 4096), (void)hipMemset(dZ, 0, 4096);
+    dim3 grid(g_variant == 0 ? tiles_m * tiles_n : (tiles_m * tiles_n < g_grid ? tiles_m * tiles_n : g_grid)), block(512);
+    auto launch = [&]() {
+        if (g_variant == 0)
+            hipLaunchKernelGGL(gemm8p_kernel, grid, block, lds, 0, dA, dB, dC, M, N, K, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL(gemm8p_persist, grid, block, lds, 0, dA, dB, dC, dZ, M, N, K, tiles_m, tiles_n);
+    };
+    launch();
     if (hipDeviceSynchronize() != hipSuccess) {
         printf("launch failed: %s\n", hipGetErrorString(hipGetLastError()));
         return 1;
@@ -287,15 +496,30 @@ static int run_case(int M, int N, int K, int iters, bool check) {
     }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm8p_kernel, grid, block, lds, 0, dA, dB, dC, M, N, K, tiles_m, tiles_n);
+    for (int i = 0; i < 3; ++i) launch();
     (void)hipEventRecord(e0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm8p_kernel, grid, block, lds, 0, dA, dB, dC, M, N, K, tiles_m, tiles_n);
+    for (int i = 0; i < iters; ++i) launch();
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-    printf("gemm8p %6d x %5d x %5d : %8.1f us  %7.1f TFLOP/s  (%d tiles, %.2f rounds)\n", M, N, K, us, tf, tiles_m * tiles_n,
+#ifdef TIMING
+    if (g_variant == 1) {
+        std::vector<unsigned long long> st(256 * 2 * 16);
+        (void)hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
+        for (int blk : {0, 1, 100, 255}) {
+            if (blk >= (int)grid.x) continue;
+            for (int g = 0; g < 2; ++g) {
+                const unsigned long long* q = &st[(blk * 2 + g) * 16];
+                printf("   wg %3d group %d (10 ns ticks):", blk, g);
+                for (int k = 1; k < 12 && q[k]; ++k) printf(" %lld", (long long)(q[k] - q[0]));
+                printf("\n");
+            }
+        }
+    }
+#endif
+    printf("gemm8p[v%d] %6d x %5d x %5d : %8.1f us  %7.1f TFLOP/s  (%d tiles, %.2f rounds)\n", g_variant, M, N, K, us, tf, tiles_m * tiles_n,
            tiles_m * tiles_n / 256.0);
     (void)hipFree(dA), (void)hipFree(dB), (void)hipFree(dC);
     return bad != 0;
@@ -303,7 +527,9 @@ static int run_case(int M, int N, int K, int iters, bool check) {
 
 int main(int argc, char** argv) {
     int rc = 0;
+    if (argc >= 5) g_extra_lds = atoi(argv[4]);
     if (argc >= 4) return run_case(atoi(argv[1]), atoi(argv[2]), atoi(argv[3]), 20, true);
+    for (g_variant = 0; g_variant < 2; ++g_variant) {
     rc |= run_case(256, 256, 128, 5, true);
     rc |= run_case(512, 768, 256, 5, true);
     rc |= run_case(4096, 4096, 4096, 30, true);
@@ -311,5 +537,6 @@ int main(int argc, char** argv) {
     rc |= run_case(8192, 8192, 8192, 10, false);
     rc |= run_case(35840, 1536, 1152, 30, true);
     rc |= run_case(35840, 1536, 4608, 20, false);
+    }
     return rc;
 }
