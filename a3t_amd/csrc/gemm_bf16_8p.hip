@@ -308,10 +308,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
             }
             unsigned kb = 0u;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[e] *= q->alpha;
-                kb |= (v[e] > 0.f ? 1u : 0u) << e;
+            for (int e = 0; e < 8; ++e) v[e] *= q->alpha;
+            if (q->R && ok) {      // fp32 residual (plain loads: the compiler drains the DMA queue for them, see the host heuristic)
+                const float4 r0 = *(const float4*)(q->R + idx), r1 = *(const float4*)(q->R + idx + 4);
+                v[0] += r0.x, v[1] += r0.y, v[2] += r0.z, v[3] += r0.w, v[4] += r1.x, v[5] += r1.y, v[6] += r1.z, v[7] += r1.w;
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kb |= (v[e] > 0.f ? 1u : 0u) << e;
             kout |= kb << (i * 8);
             if (ok) {
 #pragma unroll
@@ -493,6 +496,238 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
     WAIT_VM(0);            // the trailing (zero) DMA must not outlive the workgroup's LDS allocation
 }
 
+
+// =====================================================================================================================
+// TN variant: C[M][N] (+)= alpha * sum_k A[k][m] * B[k][n], both operands REDUCTION-strided (token-major activations):
+// the weight gradients of Linear / Conv1d (multi_layer_conv.py:36-63 backward), reduction over the B*T tokens split over
+// workgroups (fp32 atomics).  Same 8-phase schedule; what changes:
+//   * half-tile image = 64 k-rows x 128 m (256 B per k-row); a wave DMA instruction = 4 k-rows; chunk position p of k-row
+//     kr holds source chunk p ^ (((kr & 3) << 2) | (((kr >> 3) & 1) << 1)): the 8 k-rows x 32 B that the 32 lanes of a
+//     ds_read_b64_tr_b16 group touch fall on disjoint banks;
+//   * fragments by two transposed LDS reads (4 k each) per 16x16x32 operand;
+//   * fused conv weight gradient (WG): output columns are (tap, c); a 128-column B half lies inside one tap and reads
+//     x[k + (tap - pad) * dil] with zeros across utterance boundaries (buffer range check, as in the forward loader);
+//   * one tile x one K split per workgroup; epilogue = atomics straight from the accumulators (64-byte row segments).
+template <bool WG>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    int wi = blockIdx.x;
+    {   // slice-major, XCD-contiguous: the tiles of one K split (same operand slabs) stay inside one XCD's L2
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
+    }
+    const int bid = wi % p.ntiles, ks = wi / p.ntiles;
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int nkt = (p.K + 63) >> 6;              // (tokens past K read zeros through the range check)
+    int per = (nkt + p.splitk - 1) / p.splitk;
+    per += per & 1;                               // whole pairs of K-tiles; tiles past the end read zeros
+    const int kt0 = ks * per;
+    if (kt0 >= nkt) return;
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+
+    // ---- DMA lane geometry: instruction (half, q) fills k-rows (q*8 + w)*4 + (lane>>4), chunk position lane&15
+    const int krl = w * 4 + (lane >> 4);                                        // q = 0; q = 1: + 32
+    const int sc = (lane & 15) ^ (((lane >> 4) << 2) | (((w >> 1) & 1) << 1));   // source chunk of this lane (same for q = 0, 1)
+    const unsigned a_csb = (unsigned)p.a_cs * 2u, b_csb = (unsigned)p.b_cs * 2u;
+    const int mA = tm * 256 + sc * 8;                                            // + h*128
+    const unsigned voffA = (unsigned)krl * a_csb + (unsigned)mA * 2u;
+    const int cin = WG ? p.N / p.taps : p.N;
+    int shiftB[2], c0B[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n0 = tn * 256 + h * 128;
+        const int tap = WG ? n0 / cin : 0;
+        shiftB[h] = WG ? (tap - p.pad) * p.dil : 0;
+        c0B[h] = n0 - tap * cin;
+    }
+    const unsigned voffB = (unsigned)krl * b_csb + (unsigned)(sc * 16);
+    int tpos = 0;                                                                // (q = 0 | q = 1 << 16): token position inside its utterance
+    if (WG) {
+        const int t0 = (kt0 * 64 + krl) % p.Tseq, t1 = (kt0 * 64 + krl + 32) % p.Tseq;
+        tpos = t0 | (t1 << 16);
+    }
+    int c_kt = kt0;
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++c_kt;
+        if (WG) {
+            int t0 = (tpos & 0xffff) + 64, t1 = (tpos >> 16) + 64;
+            if (p.Tseq >= 64) {
+                t0 = t0 >= p.Tseq ? t0 - p.Tseq : t0, t1 = t1 >= p.Tseq ? t1 - p.Tseq : t1;
+            } else {
+                t0 %= p.Tseq, t1 %= p.Tseq;
+            }
+            tpos = t0 | (t1 << 16);
+        }
+    };
+    auto issue = [&](const int H, const int buf) __attribute__((always_inline)) {
+        int wv = w;
+        unsigned acs = a_csb, bcs = b_csb;
+        asm volatile("" : "+s"(wv), "+s"(acs), "+s"(bcs));
+        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + wv * 1024;
+        const int krem = p.K - c_kt * 64 - krl;       // > q*32: the lane's token row exists
+        const int h = H & 1;
+        if (H < 2) {
+            const bool colok = mA + h * 128 < p.M;
+            const unsigned so = (unsigned)c_kt * 64u * acs;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned vb = voffA + (unsigned)(h * 256) + (unsigned)(q * 32) * acs;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_AS(dst + q * 8192), 16, (colok && krem > q * 32) ? vb : OOB, so, 0, 0);
+            }
+        } else {
+            const bool colok = tn * 256 + h * 128 + sc * 8 < p.N;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int tp = q ? (tpos >> 16) : (tpos & 0xffff);
+                const bool ok = colok && (krem > q * 32) && (!WG || ((unsigned)(tp + shiftB[h]) < (unsigned)p.Tseq));
+                // (the whole token offset lives in voffset: the range check ignores soffset, and the tap shift may be negative)
+                const unsigned vb = voffB + (unsigned)(c_kt * 64 + q * 32 + shiftB[h]) * bcs + (unsigned)(c0B[h] * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_AS(dst + q * 8192), 16, ok ? vb : OOB, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- transposed fragment reads: lane (g, pp) supplies the address of 4 consecutive m of k-row g*8 + (pp>>2) (+4) and
+    // receives column pp of the 16-column block: 8 k-values of row/column pp -- the MFMA operand layout
+    const int g = lane >> 4, pp = lane & 15;
+    const unsigned swz = (unsigned)(((pp >> 2) << 2) | ((g & 1) << 1));
+    const unsigned kbyte = (unsigned)(g * 8 + (pp >> 2)) * 256u + (unsigned)(pp & 1) * 8u;
+    unsigned offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offA[i] = kbyte + ((((unsigned)(wr * 8 + i * 2) + (unsigned)((pp & 3) >> 1)) ^ swz) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) offB[j] = kbyte + ((((unsigned)(wc * 4 + j * 2) + (unsigned)((pp & 3) >> 1)) ^ swz) << 4);
+    auto frag = [&](const unsigned char* img, unsigned off, int s) __attribute__((always_inline)) -> bf16x8 {
+        const unsigned char* a0 = img + off + s * 8192;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0 + 1024));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+    auto readA = [&](const unsigned char* img, const int i0, const int i1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i) fa[i][0] = frag(img, offA[i], 0), fa[i][1] = frag(img, offA[i], 1);
+    };
+    auto readB = [&](const unsigned char* img, bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j][0] = frag(img, offB[j], 0), fb[j][1] = frag(img, offB[j], 1);
+    };
+    auto quad = [&](const int ha, const int hb, const bf16x8(&fb)[2][2]) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ha][hb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], fb[j][s], acc[ha][hb][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    STAMP(0);
+    issue(HB0, 0), issue(HA0, 0), issue(HB1, 0), issue(HA1, 0);
+    advance();
+    issue(HB0, 1), issue(HA0, 1), issue(HB1, 1);
+    WAIT_VM(6);
+    BAR();
+    if (wr == 1) BAR();
+    STAMP(1);
+
+    auto ktile = [&](const int buf) __attribute__((always_inline)) {
+        const unsigned char* cur = smem + buf * TILE_BYTES;
+        // phase 1: A0 x B0 (8 + 16 transposed reads; the lgkmcnt field counts to 15: the wait that retires the B0 reads sits
+        // after the first half of the A reads)
+        readB(cur + HB0 * HALF_BYTES, fb0);
+        SB();
+        readA(cur + HA0 * HALF_BYTES, 0, 2);
+        WAIT_LGKM(8);
+        SB();
+        readA(cur + HA0 * HALF_BYTES, 2, 4);
+        issue(HA1, buf ^ 1);
+        advance();
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(0, 0, fb0);
+        BAR();
+        readB(cur + HB1 * HALF_BYTES, fb1);
+        issue(HB0, buf);
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(0, 1, fb1);
+        BAR();
+        readA(cur + HA1 * HALF_BYTES, 0, 4);
+        issue(HA0, buf);
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(1, 1, fb1);
+        BAR();
+        issue(HB1, buf);
+        WAIT_VM(6);
+        BAR();
+        quad(1, 0, fb0);
+        BAR();
+    };
+    for (int u = 0; u < per; u += 2) {
+        ktile(0);
+        ktile(1);
+    }
+    STAMP(2);
+    if (wr == 0) BAR();
+    WAIT_VM(0);
+
+    // ---- epilogue: lane (g, pp) holds rows a*128 + wr*64 + i*16 + g*4 + r, column hb*128 + wc*32 + j*16 + pp
+    float* C = (float*)p.C;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = tm * 256 + a * 128 + wr * 64 + i * 16 + g * 4 + r;
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = tn * 256 + b * 128 + wc * 32 + j * 16 + pp;
+                        if (m < p.M && n < p.N) {
+                            const float v = p.alpha * acc[a][b][i][j][r];
+                            float* c = C + (int64_t)m * p.c_rs + n;
+                            if (p.accumulate == A3T_ACC_ATOMIC)
+                                atomicAdd(c, v);
+                            else if (p.accumulate == A3T_ACC_ADD)
+                                *c += v;
+                            else
+                                *c = v;
+                        }
+                    }
+            }
+#ifdef G8_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(3);
+#endif
+}
+
 static int g8_cus() {
     static int n = 0;
     if (!n) {
@@ -532,7 +767,8 @@ static bool g8_applicable(const GP& p, int batch, int ly, bool keep) {
     const int mode = g8_mode();
     if (mode == 0 || ly != 0 || batch != 1 || p.splitk != 1 || p.accumulate != A3T_ACC_STORE) return false;
     if (p.K % 128 != 0 || p.N % 8 != 0 || p.c_rs % 8 != 0 || p.a_cs != 1 || p.b_cs != 1) return false;
-    if (p.R || p.S || p.kshift_mode) return false;
+    if (p.S || p.kshift_mode) return false;
+    if (p.R && (((uintptr_t)p.R & 15) || p.keep_out)) return false;
     if (p.colsum && p.colsum_slots > 1) return false;
     if (p.act != A3T_ACT_NONE && p.act != A3T_ACT_RELU) return false;
     if (p.taps > 1 && (p.Kc % 64 != 0 || p.b_ts != p.Kc || p.Tseq <= 0)) return false;
@@ -542,25 +778,94 @@ static bool g8_applicable(const GP& p, int batch, int ly, bool keep) {
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || (int64_t)p.M * p.c_rs >= (1ll << 32)) return false;
     if (keep && (p.N % 256 != 0)) return false;
     if (mode == 2) {
-        // one 128-KiB workgroup per CU: it pays when the padded tile grid wastes little and a workgroup has enough K-tiles
-        // to amortise the pipeline fill (measured on MI355X, tools/ffn_gemm_bench.py)
-        const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
-        const double fill = (double)p.M * p.N / ((double)tm * 256 * tn * 256);
-        if (fill < 0.9 || tm * tn < 128 || p.K < 768) return false;
+        // Cost model fitted on MI355X (tools/g8_check.py, tools/g8_c4_shapes.py): one 128-KiB workgroup per CU runs its K loop
+        // at ~1.65 us per 64-wide K-tile (1.3 PFLOP/s) but nothing overlaps a tile's fixed costs -- pipeline refill and
+        // quadrant epilogues ~7 us, bias/activation 1.5, dropout hashes 5, keep bits / fp32 + residual 2 each -- nor the partially
+        // filled last round of the grid; the 128x128 kernel (4 workgroups per CU, epilogues hidden behind its neighbours)
+        // sustains ~780 TFLOP/s on the same problems.  It wins for long K and grids that fill their rounds: configs[3]'s
+        // d=512 / ff=2048 FFN (+8 % and +28 %), not configs[1]'s N=1536, K=1152 convs (4 rounds for 3.28, 18 K-tiles: -8 %).
+        const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn;
+        const int cus = g8_cus();
+        const double rounds = (double)((tiles + cus - 1) / cus);
+        double fixed = 7.0;
+        if (p.bias || p.act != A3T_ACT_NONE) fixed += 1.5;
+        if (p.drop_inv > 0.f) fixed += 5.0;
+        if (p.keep_out || p.keep_in) fixed += 2.0;
+        if (p.R || p.c_dtype == A3T_F32) fixed += 2.0;
+        if (p.colsum) fixed += 2.0;
+        const double t8 = rounds * ((p.K / 64) * 1.65 + fixed);
+        const double t128 = 2.0 * p.M * p.N * (double)p.K / 780e6;     // us
+        if (tiles < cus / 2 || t8 > 0.95 * t128) return false;
     }
     return true;
 }
 
-extern "C" int a3t_gemm_8p_supported(int M, int N, int K, int taps, int keep) {
+// flags: 1 bias / activation, 2 dropout, 4 keep bits out, 8 keep bits in, 16 fp32 output / residual, 32 column sums
+extern "C" int a3t_gemm_8p_supported(int M, int N, int K, int taps, int flags) {
+    static float dummy[4] __attribute__((aligned(16)));
     GP p = {};
     p.M = M, p.N = N, p.K = K, p.taps = taps < 1 ? 1 : taps, p.Kc = K / p.taps, p.b_ts = p.Kc;
     p.a_rs = p.Kc, p.a_cs = 1, p.b_rs = K, p.b_cs = 1, p.c_rs = N, p.splitk = 1, p.accumulate = A3T_ACC_STORE;
-    p.Tseq = 1, p.colsum_slots = 1;
-    return g8_applicable(p, 1, 0, keep != 0) ? 1 : 0;
+    p.Tseq = 1, p.colsum_slots = 1, p.c_dtype = (flags & 16) ? A3T_F32 : A3T_BF16;
+    if (flags & 1) p.bias = dummy, p.act = A3T_ACT_RELU;
+    if (flags & 2) p.drop_inv = 1.25f;
+    if (flags & 4) p.keep_out = (unsigned char*)dummy;
+    if (flags & 8) p.keep_in = (const unsigned char*)dummy;
+    if (flags & 32) p.colsum = dummy;
+    return g8_applicable(p, 1, 0, (flags & 12) != 0) ? 1 : 0;
+}
+
+template <bool WGF>
+static void launch_8p_tn(const GP& pv, int grid, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_8p_tn_kernel<WGF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES);
+    hipLaunchKernelGGL((gemm_bf16_8p_tn_kernel<WGF>), dim3(grid), dim3(512), 2 * TILE_BYTES, stream, pv);
+}
+
+// weight gradients: reduction-strided operands, K (tokens) split over workgroups
+static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
+    // Opt-in (A3T_GEMM_8P_TN=1, or mode 1): its K loop runs 1.55 us per K-tile (1.39 PFLOP/s) but the 240 workgroups of a
+    // split-K grid finish together and their 15.7 M fp32 atomics cost 20-35 us with nothing to hide them behind: 153 / 165 us
+    // against 170 / 171 us for the two FFN weight gradients alone, and no gain inside the training step.
+    static int tn_on = -1;
+    if (tn_on < 0) {
+        const char* e = getenv("A3T_GEMM_8P_TN");
+        tn_on = e ? atoi(e) : 0;
+    }
+    const int mode = g8_mode();
+    if (!tn_on && mode != 1) return -1;
+    if (mode == 0 || batch != 1 || p.c_dtype != A3T_F32 || p.M % 8 != 0 || p.N % 8 != 0) return -1;
+    if (p.a_rs != 1 || p.b_rs != 1 || p.bias || p.R || p.S || p.colsum || p.act != A3T_ACT_NONE || p.drop_inv > 0.f) return -1;
+    const bool wg = p.taps > 1;
+    if (wg && ((p.N % p.taps) || ((p.N / p.taps) % 128) || p.Tseq <= 0 || p.Tseq >= 32768)) return -1;
+    if (!wg && p.kshift_mode) return -1;
+    if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return -1;
+    const int64_t a_bytes = (int64_t)p.K * p.a_cs * 2, b_bytes = (int64_t)p.K * p.b_cs * 2;
+    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || p.a_cs % 8 || p.b_cs % 8) return -1;
+    const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn;
+    const int cus = g8_cus(), nkt = (p.K + 63) / 64;
+    int splits = (int)(cus / tiles);
+    if (splits < 1) splits = 1;
+    if (splits > nkt / 16) splits = nkt / 16 > 0 ? nkt / 16 : 1;       // >= 16 K-tiles per workgroup
+    if (splits > 1 && p.accumulate != A3T_ACC_ATOMIC) splits = 1;
+    if (mode == 2) {
+        const double fill = (double)p.M * p.N / ((double)tm * 256 * tn * 256);
+        if (fill < 0.7 || tiles * splits < 160 || nkt / splits < 32) return -1;
+    }
+    GP pv = p;
+    pv.tiles_n = (int)tn, pv.ntiles = (int)tiles, pv.splitk = splits;
+    pv.a_bytes = (unsigned)a_bytes, pv.b_bytes = (unsigned)b_bytes;
+    const int grid = (int)(tiles * splits);
+    if (wg)
+        launch_8p_tn<true>(pv, grid, stream);
+    else
+        launch_8p_tn<false>(pv, grid, stream);
+    a3t_note_kernel("gemm_bf16_8p_tn_kernel<%s>", wg ? "true" : "false");
+    return (int)hipGetLastError();
 }
 
 // Called by a3t_gemm_bf16_glds after the alignment contract has been checked.  Returns -1 when not applicable.
 int a3t_gemm_bf16_8p(const GP& p, int batch, int ly, hipStream_t stream) {
+    if (ly == 2) return (p.keep_in || p.keep_out) ? A3T_EINVAL : gemm_8p_tn(p, batch, stream);
     const bool keep = p.keep_in || p.keep_out;
     if (!g8_applicable(p, batch, ly, keep)) return keep ? A3T_EINVAL : -1;
     GP pv = p;

@@ -119,8 +119,8 @@ class MLMEngine:
                     raise ValueError(f"compute='bf16' needs {n} % 8 == 0 (16-byte DMA granules), got {v}")
             self.flat16 = torch.zeros(store.total, dtype=torch.bfloat16, device=self.dev)
             self.p16 = {k: self.flat16[o:o + math.prod(s)].view(s) for k, (o, s) in store.offsets.items()}
-        self._keep_ok = {}
-        self._w2t = self._setup_w2t() if (self.bf16 and self.dev.type == "cuda") else None
+        self._ffn_plans = {}
+        self._wt = {}        # transposed FFN weight shadows (8-phase data gradients), built on demand
 
     # ------------------------------------------------------------------ helpers
     def _drop(self, p, tag):
@@ -152,36 +152,45 @@ class MLMEngine:
     def refresh_weights(self):
         if self.bf16:
             ops.cast_bf16(self.store.flat, self.flat16)
-            if self._w2t is not None:
-                src_off, dst_off, _ = self._w2t
-                c = self.c
-                ops.cast_bf16_conv_t(self.store.flat, self.w2t_flat, src_off, dst_off, c.adim, c.ff_kernel, c.ff)
+            for suf, (src_off, dst_off, _, flat, shp) in self._wt.items():
+                ops.cast_bf16_conv_t(self.store.flat, flat, src_off, dst_off, *shp)
 
-    def _setup_w2t(self):
-        """Transposed bf16 shadows of every FFN w_2 ([d][k][ff] -> [ff][k'][d], taps reversed): the data gradient of the second
-        FFN conv becomes a k-contiguous conv of the output gradient, which the 8-phase GEMM runs with the keep-bit mask the
-        forward conv left behind.  One transposing cast per step for all of them."""
-        c = self.c
-        names = [k for k in self.store.offsets if k.endswith(".w2") and tuple(self.store.offsets[k][1]) == (c.adim, c.ff_kernel, c.ff)]
+    def _setup_wt(self, suf, shape):
+        """Transposed, tap-reversed bf16 shadows of every FFN weight `*.suf` of `shape` = [n][k][c] -> [c][k'][n]: the data
+        gradient of that conv becomes a k-contiguous conv of the output gradient (a3t_cast_bf16_conv_t), which the 8-phase GEMM
+        can run.  One transposing cast per step for all of them; only built when the 8-phase kernel would take the GEMM."""
+        names = [k for k in self.store.offsets if k.endswith("." + suf) and tuple(self.store.offsets[k][1]) == tuple(shape)]
         if not names:
-            return None
-        n = c.adim * c.ff_kernel * c.ff
-        self.w2t_flat = torch.zeros(n * len(names), dtype=torch.bfloat16, device=self.dev)
+            return
+        n = math.prod(shape)
+        flat = torch.zeros(n * len(names), dtype=torch.bfloat16, device=self.dev)
         src = torch.tensor([self.store.offsets[k][0] for k in names], dtype=torch.int64, device=self.dev)
         dst = torch.arange(len(names), dtype=torch.int64, device=self.dev) * n
-        views = {k: self.w2t_flat[i * n:(i + 1) * n].view(c.ff, c.ff_kernel, c.adim) for i, k in enumerate(names)}
-        return (src, dst, views)
+        views = {k: flat[i * n:(i + 1) * n].view(shape[2], shape[1], shape[0]) for i, k in enumerate(names)}
+        self._wt[suf] = (src, dst, views, flat, tuple(shape))
+        ops.cast_bf16_conv_t(self.store.flat, flat, src, dst, *shape)
 
-    def _ffn_keep(self, M):
-        """True when both halves of the keep-bit protocol (forward conv 1 writes, data gradient of conv 2 reads) run on the
-        8-phase GEMM for this token count."""
-        c = self.c
-        if not self.bf16 or self._w2t is None or os.environ.get("A3T_FFN_KEEPBITS", "1") == "0":
-            return False
-        key = ("keep", M)
-        if key not in self._keep_ok:
-            self._keep_ok[key] = ops.gemm_8p_supported(M, c.ff, c.ff_kernel * c.adim, c.ff_kernel, keep=True)
-        return self._keep_ok[key]
+    def _ffn_plan(self, M):
+        """Which FFN GEMMs of an M-token batch go to the persistent 8-phase kernel (the library's cost model decides,
+        a3t_gemm_8p_supported): (keep, dgrad1) = the keep-bit protocol (forward conv 1 writes one bit per hidden activation,
+        the data gradient of conv 2 reads it through the transposed w_2), and the data gradient of conv 1 through the
+        transposed w_1.  A3T_FFN_8P=0 turns both off."""
+        if M not in self._ffn_plans:
+            c = self.c
+            keep = d1 = False
+            if self.bf16 and self.dev.type == "cuda" and os.environ.get("A3T_FFN_8P", "1") != "0":
+                k = c.ff_kernel
+                drop = ops.G8_DROP if (self.dropping and c.dropout_rate > 0) else 0
+                keep = ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_BIAS_ACT | drop | ops.G8_KEEP_OUT) and \
+                    ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_KEEP_IN | ops.G8_COLSUM)
+                d1 = ops.gemm_8p_supported(M, c.adim, k * c.ff, k, 0)
+                if keep and "w2" not in self._wt:
+                    self._setup_wt("w2", (c.adim, k, c.ff))
+                if d1 and "w1" not in self._wt:
+                    self._setup_wt("w1", (c.ff, k, c.adim))
+                keep, d1 = keep and "w2" in self._wt, d1 and "w1" in self._wt
+            self._ffn_plans[M] = (keep, d1)
+        return self._ffn_plans[M]
 
     def _act(self, name, shape):
         return self.ws.get(name, shape, self.adt)
@@ -307,7 +316,7 @@ class MLMEngine:
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
         h = self._act(tag + ".h", (M, c.ff))
         keep = None
-        if self._ffn_keep(M):     # one bit per element of h (value > 0 after relu / dropout) for the backward mask
+        if self._ffn_plan(M)[0]:  # one bit per element of h (value > 0 after relu / dropout) for the backward mask
             keep = self.ws.get(tag + ".keep", (ops.gemm_keep_bytes(M, c.ff),), torch.uint8)
         ops.conv_fwd(y, self.W(pre + ".w1"), h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=self.cmp,
                      drop=self._drop(c.dropout_rate, tag + ".h"), keep_out=keep)
@@ -334,14 +343,17 @@ class MLMEngine:
         hd = self._drop(c.dropout_rate, tag + ".h")
         a_dh = 0.5 / (1.0 - hd[0]) if hd else 0.5
         if keep is not None:     # k-contiguous conv of ga with the transposed weights, masked by the forward's keep bits
-            ops.conv_fwd(ga, self._w2t[2][pre + ".w2"], dh, T, c.ff_kernel - 1 - pad, alpha=a_dh, compute=self.cmp,
+            ops.conv_fwd(ga, self._wt["w2"][2][pre + ".w2"], dh, T, c.ff_kernel - 1 - pad, alpha=a_dh, compute=self.cmp,
                          keep_in=keep, colsum=gr[pre + ".b1"])
         else:
             ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=a_dh,
                               compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
         self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp))
         dy = self._act("tmp.dy", (M, c.adim))
-        ops.conv_bwd_data(dh, self.W(pre + ".w1"), dy, T, pad, compute=self.cmp)
+        if self._ffn_plan(M)[1]:
+            ops.conv_fwd(dh, self._wt["w1"][2][pre + ".w1"], dy, T, c.ff_kernel - 1 - pad, compute=self.cmp)
+        else:
+            ops.conv_bwd_data(dh, self.W(pre + ".w1"), dy, T, pad, compute=self.cmp)
         if not self.bf16:
             self._bias_grad(dh, gr[pre + ".b1"])
         self._pre_ln(ga, g, g16)

@@ -116,9 +116,13 @@ def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT
          colsum=colsum)
 
 
-def gemm_8p_supported(M, N, K, taps=1, keep=False):
-    """True when a3t_gemm runs this k-contiguous bf16 problem on the persistent 8-phase kernel (csrc/gemm_bf16_8p.hip)."""
-    return bool(L.load().a3t_gemm_8p_supported(int(M), int(N), int(K), int(taps), int(bool(keep))))
+G8_BIAS_ACT, G8_DROP, G8_KEEP_OUT, G8_KEEP_IN, G8_F32_OR_RES, G8_COLSUM = 1, 2, 4, 8, 16, 32
+
+
+def gemm_8p_supported(M, N, K, taps=1, flags=0):
+    """True when a3t_gemm runs this k-contiguous bf16 problem, with the epilogue `flags`, on the persistent 8-phase kernel
+    (csrc/gemm_bf16_8p.hip)."""
+    return bool(L.load().a3t_gemm_8p_supported(int(M), int(N), int(K), int(taps), int(flags)))
 
 
 def gemm_keep_bytes(M, N):

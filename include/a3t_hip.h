@@ -98,8 +98,9 @@ typedef struct a3t_gemm_desc {
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
 /* 1 when a3t_gemm runs the k-contiguous bf16 problem (M, N, K = taps * channels) on the persistent 256x256 8-phase kernel
- * (csrc/gemm_bf16_8p.hip) -- keep != 0: with keep_out / keep_in; bytes of a keep-bit image */
-int a3t_gemm_8p_supported(int M, int N, int K, int taps, int keep);
+ * (csrc/gemm_bf16_8p.hip) with the epilogue `flags` (1 bias/activation, 2 dropout, 4 keep_out, 8 keep_in, 16 fp32 output or
+ * residual, 32 column sums); bytes of a keep-bit image */
+int a3t_gemm_8p_supported(int M, int N, int K, int taps, int flags);
 int64_t a3t_gemm_keep_bytes(int M, int N);
 
 /* LayerNorm over the last dim (transformer/layer_norm.py:12-42 eps=1e-12; torch.nn.LayerNorm
