@@ -225,8 +225,10 @@ class MLMEngine:
                               dxsum=nb[0], dxsum_scale=nb[1], drop=dr)
             self._gm_ready = nxt
             return
-        if dropping:
-            nb = None          # with dropout the bias gradients come from the masked gradient (_gm)
+        if dropping and nxt is not None:
+            nb = None          # a layer with output dropout: its bias gradient comes from the masked gradient (_gm)
+        # (nxt is None: the layer has no output dropout -- the speech-embedding Linear -- and its bias gradient is the plain
+        #  column sum of dx also when dropout is on; round 3: until then emb.b got no gradient in dropout-on steps)
         fuse = self.bf16 and nb is not None
         ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=dx16,
                           dxsum=nb[0] if fuse else None, dxsum_scale=nb[1] if fuse else 1.0)
