@@ -66,7 +66,7 @@ _SIGS = {
     "a3t_pwg_block": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_mask_fill": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint32,
-                             _P],
+                             _P, _P],
     "a3t_embed_finish_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                              ctypes.c_uint32, _P],
     "a3t_scale": [_P, _P, c_int64, c_float, _P],

@@ -170,4 +170,7 @@ def synthetic_batch(c: A3TConfig, B: int, T_mel: int, T_phn: int, seed: int, dev
                masked_position=torch.from_numpy(masked), speech_mask=torch.from_numpy(ones_s)[:, None, :],
                text_mask=torch.ones(B, 1, T_phn, dtype=torch.bool), speech_segment_pos=torch.from_numpy(sp),
                text_segment_pos=torch.from_numpy(tp))
+    if c.spk_embed_dim > 0:      # unit-norm speaker vectors
+        xv = rs.standard_normal((B, c.spk_embed_dim)).astype(np.float32)
+        out["spembs"] = torch.from_numpy(xv / np.linalg.norm(xv, axis=1, keepdims=True))
     return {k: v.to(device) for k, v in out.items()}

@@ -28,6 +28,10 @@ class A3TConfig:
     positional_dropout_rate: float = 0.2
     attention_dropout_rate: float = 0.2
     postnet_dropout_rate: float = 0.5
+    # speaker conditioning (BASELINE configs[3] "+ x-vector cond"): spembs (B, spk_embed_dim) -> Linear -> added to every token
+    # after the embedding prologue.  The reference accepts `spembs` and ignores it (sedit_model.py:246): this is an
+    # extension with no reference behaviour (parity unpinned); 0 = off, the reference's behaviour.
+    spk_embed_dim: int = 0
     # feature extraction
     fs: int = 24000
     n_fft: int = 2048
@@ -69,6 +73,15 @@ class A3TConfig:
                 if k in feats_conf and feats_conf[k] is not None:
                     setattr(c, k, feats_conf[k])
         return c
+
+
+def config_c4(**kw) -> A3TConfig:
+    """BASELINE.json configs[3]: LibriTTS multi-speaker, 6 + 6 blocks, d=512, H=4 (d_k=128), ff=2048, x-vector (512-d)
+    conditioning."""
+    c = A3TConfig(adim=512, heads=4, ff=2048, enc_blocks=6, dec_blocks=6, spk_embed_dim=512)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
 
 
 def config_c2(**kw) -> A3TConfig:

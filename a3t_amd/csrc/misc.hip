@@ -34,7 +34,7 @@ __global__ void embed_finish_fwd_kernel(const float* __restrict__ e, const float
                                         const float* __restrict__ seg, const int64_t* __restrict__ text,
                                         const int64_t* __restrict__ spos, const int64_t* __restrict__ tpos,
                                         float* __restrict__ xs, int B, int Tm, int Tp, int D, float xscale,
-                                        unsigned int thr, float inv, unsigned int key) {
+                                        unsigned int thr, float inv, unsigned int key, const float* __restrict__ spk) {
     const int T = Tm + Tp;
     const int64_t n = (int64_t)B * T * D;
     GRID_STRIDE(i, n) {
@@ -52,16 +52,17 @@ __global__ void embed_finish_fwd_kernel(const float* __restrict__ e, const float
             sg = seg[tpos[r] * D + c];
         }
         if (inv > 0.f) v = rng_keep(key, (unsigned int)i, thr) ? v * inv : 0.f;   // positional dropout, before + seg
+        if (spk) sg += spk[(int64_t)b * D + c];     // projected speaker embedding, the same vector for every token of b
         xs[i] = v + sg;
     }
 }
 extern "C" int a3t_embed_finish_fwd(const float* e, const float* emb, const float* seg, const int64_t* text,
                                     const int64_t* spos, const int64_t* tpos, float* xs, int B, int Tm, int Tp, int D,
-                                    float xscale, float drop_p, uint32_t drop_key, void* stream) {
+                                    float xscale, float drop_p, uint32_t drop_key, const float* spk, void* stream) {
     int64_t n = (int64_t)B * (Tm + Tp) * D;
     hipLaunchKernelGGL(embed_finish_fwd_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, e, emb, seg, text,
                        spos, tpos, xs, B, Tm, Tp, D, xscale, (unsigned int)((double)drop_p * 4294967296.0),
-                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f, drop_key);
+                       drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f, drop_key, spk);
     return (int)hipGetLastError();
 }
 

@@ -644,8 +644,18 @@ class MLMEngine:
         e = self._ln_fwd("emb.ln", e0, "emb.ln", eps=1e-5, out_dtype=torch.float32)
         xs = ws.get("emb.xs", (B * T, d))
         xscale = math.sqrt(d)
+        spk = None
+        if c.spk_embed_dim > 0 and batch.get("spembs") is not None:
+            # x-vector conditioning (configs[3]): Linear(spembs) added to every token of the utterance, fused into the
+            # prologue kernel.  fp32 (B x 512 x d: negligible); an extension, the reference ignores spembs
+            se = batch["spembs"].to(self.dev, torch.float32).contiguous()
+            spk = ws.get("emb.spk", (B, d))
+            ops.linear_fwd(se, p["spk.w"], spk, bias=p["spk.b"], compute=F32)
+            self.sv["spk"] = se
+        else:
+            self.sv.pop("spk", None)
         ops.embed_finish_fwd(e, p["temb"], p["seg"], text, spos, tpos, xs, B, Tm, Tp, d, xscale,
-                             drop=self._drop(pp, "emb.x") or (0.0, 0))
+                             drop=self._drop(pp, "emb.x") or (0.0, 0), spk=spk)
         pos_e = self._act("pos.enc", (T, d))
         pos_d = self._act("pos.dec", (T, d))
         if self._drop(pp, "pos.enc"):      # dropout(pos_emb) (embedding.py:170)
@@ -792,6 +802,13 @@ class MLMEngine:
             self.block_bwd(f"enc.{i}", g, B, T)
             done(f"enc.{i}.ffm.ln.g")
         # --- prologue backward
+        if "spk" in self.sv:     # d Linear(spembs): per-utterance column sums of the gradient of the token stream
+            se = self.sv["spk"]
+            dspk = ws.get("tmp.dspk", (B, d), zero=True)
+            for b in range(B):
+                ops.bias_grad(g[b * T:(b + 1) * T], dspk[b], self.scratch64)
+            ops.linear_bwd_weight(dspk, se, gr["spk.w"], compute=F32)
+            self._bias_grad(dspk, gr["spk.b"])
         xm, e, text, spos, tpos, masked, speech2 = self.sv["embed"]
         de = ws.get("tmp.de", (B * Tm, d))
         ops.embed_finish_bwd(g, e, text, spos, tpos, de, gr["temb"], gr["seg"], B, Tm, Tp, d, c.vocab, c.seg_table,

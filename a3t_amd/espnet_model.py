@@ -120,11 +120,14 @@ class ESPnetMLMEncAsDecoderModel(torch.nn.Module):
                       speech_segment_pos, text_segment_pos, y_masks=None) -> Dict[str, torch.Tensor]:
         return {"feats": speech, "feats_lengths": speech_lengths}
 
-    def _batch(self, speech, text, masked_position, speech_mask, text_mask, speech_segment_pos, text_segment_pos):
+    def _batch(self, speech, text, masked_position, speech_mask, text_mask, speech_segment_pos, text_segment_pos,
+               spembs=None):
         dev = self.store.device
         b = dict(speech=speech.to(dev, torch.float32), text=text.to(dev), masked_position=masked_position.to(dev),
                  speech_mask=speech_mask.to(dev), text_mask=text_mask.to(dev),
                  speech_segment_pos=speech_segment_pos.to(dev), text_segment_pos=text_segment_pos.to(dev))
+        if spembs is not None and self.cfg.spk_embed_dim > 0:
+            b["spembs"] = spembs.to(dev, torch.float32)
         if self.compute == "bf16":
             b = self._pad_to_dma_granule(b)
         return b
@@ -155,10 +158,12 @@ class ESPnetMLMEncAsDecoderModel(torch.nn.Module):
         return out
 
     def forward(self, speech, text, masked_position, speech_mask, text_mask, speech_segment_pos, text_segment_pos,
-                y_masks=None, speech_lengths=None, text_lengths=None):
+                y_masks=None, speech_lengths=None, text_lengths=None, spembs=None):
+        """spembs (B, spk_embed_dim): speaker x-vectors; used only by a model built with spk_embed_dim > 0 (an extension:
+        the reference model ignores them, sedit_model.py:246)."""
         batch_size = speech.shape[0]
         batch = self._batch(speech, text, masked_position, speech_mask, text_mask, speech_segment_pos,
-                            text_segment_pos)
+                            text_segment_pos, spembs)
         if torch.is_grad_enabled() and self.training:
             loss = _TrainStep.apply(self, batch, *self._params.values())
         else:
@@ -177,7 +182,7 @@ class ESPnetMLMEncAsDecoderModel(torch.nn.Module):
         if not use_teacher_forcing:
             raise NotImplementedError("only use_teacher_forcing=True is functional in the reference")
         batch = self._batch(speech, text, masked_position, speech_mask, text_mask, speech_segment_pos,
-                            text_segment_pos)
+                            text_segment_pos, spembs)
         out = self._engine().forward(batch, need_grad=False)
         zs = out["after"]
         s, e = int(span_boundary[0]), int(span_boundary[1])

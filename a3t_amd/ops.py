@@ -296,9 +296,9 @@ def mask_fill(speech, masked, mask_feature, out):
                                    _stream()), "mask_fill")
 
 
-def embed_finish_fwd(e, emb, seg, text, spos, tpos, xs, B, Tm, Tp, D, xscale, drop=(0.0, 0)):
+def embed_finish_fwd(e, emb, seg, text, spos, tpos, xs, B, Tm, Tp, D, xscale, drop=(0.0, 0), spk=None):
     L.check(L.load().a3t_embed_finish_fwd(_ptr(e), _ptr(emb), _ptr(seg), _ptr(text), _ptr(spos), _ptr(tpos), _ptr(xs),
-                                          B, Tm, Tp, D, xscale, drop[0], drop[1], _stream()), "embed_fwd")
+                                          B, Tm, Tp, D, xscale, drop[0], drop[1], _ptr(spk), _stream()), "embed_fwd")
 
 
 def embed_finish_bwd(dxs, e, text, spos, tpos, de, demb, dseg, B, Tm, Tp, D, V, nseg, xscale, drop=(0.0, 0)):

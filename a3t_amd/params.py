@@ -43,6 +43,9 @@ def param_layout(c: A3TConfig) -> "OrderedDict[str, tuple]":
     lay["emb.ln.g"] = (d,)
     lay["emb.ln.b"] = (d,)
     lay["temb"] = (c.vocab, d)
+    if c.spk_embed_dim > 0:
+        lay["spk.w"] = (d, c.spk_embed_dim)
+        lay["spk.b"] = (d,)
     for i in range(c.enc_blocks):
         for n, s in _block_layout(c, c.enc_kernel):
             lay[f"enc.{i}.{n}"] = s
@@ -122,6 +125,8 @@ def reference_key_map(c: A3TConfig):
          ("encoder.speech_embed.2.weight", "emb.ln.g", None, "reshape"),
          ("encoder.speech_embed.2.bias", "emb.ln.b", None, "reshape"),
          ("encoder.text_embed.0.weight", "temb", None, "reshape")]
+    if c.spk_embed_dim > 0:    # extension keys (no reference counterpart): optional when loading a reference checkpoint
+        m += [("spk_proj.weight", "spk.w", None, "optional"), ("spk_proj.bias", "spk.b", None, "optional")]
     for i in range(c.enc_blocks):
         m += _ref_block_map(f"encoder.encoders.{i}.", f"enc.{i}.", c)
     m += [("encoder.after_norm.weight", "enc.after.g", None, "reshape"),
@@ -216,7 +221,8 @@ class ParamStore:
         missing = []
         for key, name, rows, kind in self.keymap:
             if key not in sd:
-                missing.append(key)
+                if kind != "optional":
+                    missing.append(key)
                 continue
             src = sd.pop(key)
             if not torch.is_tensor(src):

@@ -55,6 +55,37 @@ def build_trainer(cfg, device, compute, world, dropout=True, comm_dtype=torch.fl
                       comm_dtype=comm_dtype)
 
 
+def c4_leg(dev, compute, steps=8, warmup=3):
+    """BASELINE.json configs[3] on ONE GPU: LibriTTS multi-speaker A3T, 6+6 blocks d=512 H=4 (d_k=128) ff=2048, x-vector (512-d)
+    conditioning, B=16, T_mel=1600, T_phn=200; the same step (fwd + bwd + clip + Adam, recipe dropout) as the headline."""
+    from a3t_amd.collate import synthetic_batch
+    from a3t_amd.config import config_c4
+    cfg = config_c4()
+    B, Tm, Tp = 16, 1600, 200
+    tr = build_trainer(cfg, dev, compute, 1)
+    batch = synthetic_batch(cfg, B, Tm, Tp, seed=4321, device=dev)
+    for _ in range(warmup):
+        tr.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(batch)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    fl = 3.0 * fwd_flops_per_step(cfg, B, Tm, Tp)
+    plan = tr.engine._ffn_plan(B * (Tm + Tp))
+    out = dict(workload="LibriTTS multi-speaker A3T train step: 6+6 Conformer blocks d=512 H=4 ff=2048(k3) + x-vector (512) add, "
+                        "B=16, T_mel=1600, T_phn=200, fwd+bwd+clip+Adam, recipe dropout",
+               ms_per_step=ms, frames_per_s=B * Tm / (ms * 1e-3), steps=steps, params=tr.store.n_params,
+               algorithmic_tflop_per_step=fl / 1e12, step_tflops=fl / (ms * 1e-3) / 1e12,
+               frac=fl / (ms * 1e-3) / 1e12 / MFMA_PEAK["bf16"], final_loss=float(loss),
+               ffn_on_8phase_gemm=dict(keep_bit_protocol=bool(plan[0]), conv1_data_gradient=bool(plan[1])),
+               hbm_allocated_gb=torch.cuda.max_memory_allocated(dev) / 1e9)
+    del tr, batch
+    torch.cuda.empty_cache()
+    return out
+
+
 def vocoder_rtf(dev, B=8, Tf=1000, reps=3, cpu=False):
     """BASELINE.json configs[4]: ParallelWaveGAN v1 (30 blocks, 64/128/64 ch, hop 300 = 4*5*3*5) mel -> wav
     for B utterances of Tf frames (12.5 s each at 24 kHz); RTF = wall / audio seconds.  fp32 MFMA GEMMs."""
@@ -315,6 +346,7 @@ def main():
     ap.add_argument("--no-dropout", action="store_true", help="disable the recipe's dropout sites (debug only)")
     ap.add_argument("--no-vocoder", action="store_true")
     ap.add_argument("--no-collate", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="skip the BASELINE configs[3] leg (d=512, H=4, ff=2048, B=16, T_mel=1600)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--fake-cpu", action="store_true", help="N-rank launch-path test on gloo/CPU (no kernels)")
@@ -431,22 +463,29 @@ def main():
             return agg
 
         agg = gemm_profile()                       # as timed: weight-gradient GEMMs overlap on the side stream
+        agg_rows = list(prof_rows)
         eng = tr.engine
         side, eng.side = eng.side, None            # same step, one stream: every kernel alone on the GPU
         alone = gemm_profile()
+        alone_rows = list(prof_rows)
+        prof_rows[:] = agg_rows
         eng.side = side
+        fwd_shapes = {(cfg.ff, cfg.ff_kernel * cfg.adim), (cfg.adim, cfg.ff_kernel * cfg.ff)}
+        wg_shapes = {(cfg.ff, cfg.ff_kernel * cfg.adim), (cfg.adim, cfg.ff_kernel * cfg.ff)}
         sync()
     if rank == 0 and not a.no_kernel_profile:
         name, (fl, tt, n) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = fl / tt / 1e12
         peak = MFMA_PEAK["bf16" if "bf16" in name else "f32"]
-        traffic = None
-        for tf in ("r02_hbm_traffic_per_kernel.json", "r01_hbm_traffic_per_kernel.json"):   # rocprofv3 --pmc FETCH_SIZE /
-            tf = os.path.join(ROOT, "profiles", tf)                                         # WRITE_SIZE passes of this command
-            if os.path.exists(tf) and traffic is None:
-                for k, v in json.load(open(tf)).items():
+        traffic, traffic_source = None, None
+        for tf in ("r03_hbm_traffic_per_kernel.json", "r02_hbm_traffic_per_kernel.json", "r01_hbm_traffic_per_kernel.json"):
+            tfp = os.path.join(ROOT, "profiles", tf)                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+            if os.path.exists(tfp) and traffic is None:
+                for k, v in json.load(open(tfp)).items():
                     if name in k:
                         traffic = v["hbm_bytes_per_launch"]
+                        traffic_source = ("profiles/" + tf + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                          "command, FETCH_SIZE x2 for gfx950; a tracked file, not measured in this run)")
         # algorithmic bytes of one launch of that kernel (every operand read once, output written / atomically updated once
         # per K-split): averaged over its launches of the profiled step
         alg = [2.0 * (K_ * M_ + K_ * (N_ // max(tp_, 1)) if "<2," in nm else M_ * K_ // max(tp_, 1) + N_ * K_) * b_
@@ -454,8 +493,25 @@ def main():
                for nm, _f, _e0, _e1, (M_, N_, K_, b_, tp_, sk_) in prof_rows if nm == name]
         traffic_alg = sum(alg) / len(alg) if alg else None
         fa, ta, na = alone.get(name, (fl, tt, n))
+        # per-class table of the conv-FFN GEMMs (75 % of the FLOPs), from the one-stream pass: forward / data gradient /
+        # weight gradient; MFMA-busy from the tracked counter pass (profiles/r02_gemm_mfma_busy.json) when present
+        classes = {}
+        seen_wgrad = False          # launch order: every conv-FFN GEMM before the first weight gradient belongs to the forward pass
+        for nm, fl_, e0_, e1_, (M_, N_, K_, b_, tp_, sk_) in alone_rows:
+            if tp_ != cfg.ff_kernel or b_ != 1 or (N_, K_) not in fwd_shapes and (M_, N_) not in wg_shapes:
+                continue
+            is_wg = sk_ > 1 or "<2," in nm or "_tn_" in nm
+            seen_wgrad = seen_wgrad or is_wg
+            cls = "wgrad" if is_wg else ("dgrad" if seen_wgrad else "fwd")
+            c_ = classes.setdefault(cls, [0, 0.0, 0.0])
+            c_[0] += 1
+            c_[1] += e0_.elapsed_time(e1_) * 1e-3
+            c_[2] += fl_
+        gemm_classes = {k: dict(launches=v[0], avg_us=v[1] / v[0] * 1e6, tflops=v[2] / v[1] / 1e12, frac=v[2] / v[1] / 1e12 / peak)
+                        for k, v in classes.items()}
         roofline = dict(bound="mfma", kernel=name, launches=n, avg_us=tt / n * 1e6, achieved=achieved, peak=peak,
-                        unit="TFLOP/s", frac=achieved / peak, traffic=traffic, traffic_algorithmic=traffic_alg,
+                        unit="TFLOP/s", frac=achieved / peak, traffic=traffic, traffic_source=traffic_source,
+                        traffic_algorithmic=traffic_alg, ffn_gemm_classes_alone=gemm_classes,
                         note="durations from HIP events inside the step; this kernel runs on the side stream and "
                              "shares the GPU with the data-gradient chain, 'alone' = same step on one stream",
                         alone=dict(avg_us=ta / na * 1e6, achieved=fa / ta / 1e12, frac=fa / ta / 1e12 / peak),
@@ -485,6 +541,11 @@ def main():
             inf = infill_leg(dev, cpu=not a.no_cpu_baseline)
             out["vocoder"]["infill"] = inf
             out["vocoder"]["pipeline_rtf"] = (inf["ms"] + out["vocoder"]["ms"]) * 1e-3 / out["vocoder"]["audio_seconds"]
+        if world == 1 and not a.no_c4:
+            log("configs[3] leg (d=512 H=4 ff=2048 + x-vector, B=16, T_mel=1600)")
+            del tr, batch
+            torch.cuda.empty_cache()
+            out["c4"] = c4_leg(dev, a.compute)
         if world == 1 and not a.no_collate:
             log("collate leg (on-device log-mel)")
             out["collate"] = collate_leg(dev)

@@ -211,10 +211,12 @@ int a3t_attn_bwd_finish(const void* dqu, const void* dqvl, const void* dqvu, voi
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
 int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,
                   int out_dtype, int M, int C, void* stream);
-/* xs[b][t] (t<Tm): relu(e[b*Tm+t]) * xscale + seg[spos];  (t>=Tm): emb[text]*xscale + seg[tpos] */
+/* xs[b][t] (t<Tm): relu(e[b*Tm+t]) * xscale + seg[spos];  (t>=Tm): emb[text]*xscale + seg[tpos];
+ * spk (optional, [B][D]): projected speaker embedding added to every token of utterance b (x-vector conditioning of
+ * BASELINE configs[3]; no reference behaviour: sedit_model.py:246 ignores spembs) */
 int a3t_embed_finish_fwd(const float* e, const float* emb, const float* seg, const int64_t* text,
                          const int64_t* spos, const int64_t* tpos, float* xs, int B, int Tm, int Tp, int D,
-                         float xscale, float drop_p, uint32_t drop_key, void* stream);
+                         float xscale, float drop_p, uint32_t drop_key, const float* spk, void* stream);
 int a3t_embed_finish_bwd(const float* dxs, const float* e, const int64_t* text, const int64_t* spos,
                          const int64_t* tpos, float* de, float* demb, float* dseg, int B, int Tm, int Tp,
                          int D, int V, int nseg, float xscale, float drop_p, uint32_t drop_key, void* stream);
