@@ -873,11 +873,9 @@ template <int NDB>
 static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     constexpr int TB = DT16<NDB>::BYTES;
     constexpr int lds = 10 * TB + 8 * 16 * SC16_LD * 4 + 4 * 128;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
+    // (the attribute is per device: set it on every launch -- a process that drives several GPUs would otherwise launch on
+    //  its second device without the raised LDS limit)
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int nqb = (a.T + 127) / 128;
     hipLaunchKernelGGL(attn_fwd16_kernel<NDB>, dim3((unsigned)(a.B * a.H * nqb)), dim3(512), lds, s, a);
     return (int)hipGetLastError();
@@ -930,12 +928,8 @@ static int launch_bwd(const AttnArgs& a, int which, hipStream_t s) {
     constexpr int TB = Tile<NDB>::BYTES, RSB = Tile<NDB>::RSB;
     constexpr int lds_q = 8 * TB + 4 * 32 * SC_LD * 4 + 4 * 32 * GS_LD * 2 + 4 * 128;
     constexpr int lds_kv = 7 * TB + 34 * RSB + 4 * 32 * SC_LD * 4 + 64 * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-        attr = true;
-    }
+    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     const int nb = (a.T + 127) / 128;
     const dim3 grid((unsigned)(a.B * a.H * nb));
     if (which & 1) hipLaunchKernelGGL(attn_bwd_q_kernel<NDB>, grid, dim3(256), lds_q, s, a);

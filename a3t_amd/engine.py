@@ -100,6 +100,7 @@ class MLMEngine:
         # K = 5*80 bf16 GEMMs carry `before` to ~2^-17 (max error of `after` 6.2e-2 -> 4.3e-2 of scale) for ~0.05 ms per step
         # (the exact-fp32 MFMA for that layer and its two gradients cost 0.55 ms); gradients use hi only.
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
+        self.sfc_f32 = os.environ.get("A3T_SFC_F32", "1") != "0"
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
         # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
         # at the benchmark shape; whole eval forward 4.32 vs 4.74 ms at B = 8, 10.5 vs 11.3 ms at B = 32, 4+4 blocks), except
@@ -692,7 +693,14 @@ class MLMEngine:
         hs = self._act("head.hs", (B * Tm, d))
         ops.slice_rows(x, hs, B, T, Tm, d)
         before = ws.get("head.before", (B * Tm, c.odim))
-        ops.linear_fwd(hs, self.W("sfc.w"), before, bias=p["sfc.b"], compute=self.cmp)
+        if self.bf16 and self.sfc_f32:
+            # the mel projection on the exact-fp32 MFMA from the fp32 LayerNorm output and the fp32 master weights (B*T_mel x 80 x d:
+            # ~20 us): `before` is what the postnet amplifies, its last rounding step is the cheapest one to remove
+            hs32 = ws.get("head.hs32", (B * Tm, d))
+            ops.slice_rows(x, hs32, B, T, Tm, d)
+            ops.linear_fwd(hs32, p["sfc.w"], before, bias=p["sfc.b"], compute=F32)
+        else:
+            ops.linear_fwd(hs, self.W("sfc.w"), before, bias=p["sfc.b"], compute=self.cmp)
         y = before
         f32_first = self.bf16 and self.post_f32_first
         ylo = None

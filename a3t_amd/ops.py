@@ -254,7 +254,8 @@ def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, 
 
 
 def attn_fused_supported(dk, T):
-    return dk % 32 == 0 and dk <= 192 and dk != 160 and T % 8 == 0
+    """Mirror of attn_shape_ok (csrc/attn_fused.hip): shapes outside fall back to the materialised attention path."""
+    return dk % 32 == 0 and dk <= 192 and dk != 160 and T % 8 == 0 and 8 <= T <= 4096
 
 
 def attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=(0.0, 0)):

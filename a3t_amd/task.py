@@ -82,24 +82,25 @@ class MLMTask:
     @classmethod
     def build_model(cls, args: argparse.Namespace, device="cpu", compute: str = "f32") -> ESPnetMLMEncAsDecoderModel:
         """tasks/mlm.py:328-443."""
-        if isinstance(args.token_list, str):
-            with open(args.token_list, encoding="utf-8") as f:
-                token_list = [line.rstrip() for line in f]
-            args.token_list = list(token_list)
-        elif isinstance(args.token_list, (tuple, list)):
-            token_list = list(args.token_list)
-        else:
+        # Same side effects on `args` as the reference (tasks/mlm.py:331-355), because the mutated namespace is what gets
+        # dumped to config.yaml: a token file path is replaced by the list it holds, and a model fed pre-computed features
+        # (odim given) has its feats_extract entries cleared.
+        tl = args.token_list
+        if isinstance(tl, str):
+            with open(tl, encoding="utf-8") as fh:
+                tl = [ln.rstrip() for ln in fh]
+            args.token_list = list(tl)
+        elif not isinstance(tl, (tuple, list)):
             raise RuntimeError("token_list must be str or list")
+        token_list = list(tl)
         vocab_size = len(token_list)
-        logging.info(f"Vocabulary size: {vocab_size }")
-        if args.odim is None:
+        logging.info("Vocabulary size: %d", vocab_size)
+        feats_extract, odim = None, args.odim
+        if odim is None:            # the model owns the feature extractor and takes its output size
             feats_extract = cls._feats(args, device)
             odim = feats_extract.output_size()
         else:
-            args.feats_extract = None
-            args.feats_extract_conf = None
-            feats_extract = None
-            odim = args.odim
+            args.feats_extract = args.feats_extract_conf = None
         if getattr(args, "normalize", None) is not None:
             logging.warning("normalize is built but never applied by the reference model (SURVEY §0); ignored")
         if args.encoder != "conformer" or args.decoder not in ("conformer",):

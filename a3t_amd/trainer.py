@@ -117,13 +117,19 @@ class FlatAllReduce:
 
     def wait(self):
         for w, rng in self.works:
-            w.wait()
-            if rng is not None:            # cast the reduced bucket back into the fp32 gradient
-                if self.cuda:
-                    with torch.cuda.stream(self.stream):
-                        self.g[rng[0]:rng[1]].copy_(self.stage[rng[0]:rng[1]])
-                else:
+            if rng is None:
+                w.wait()
+                continue
+            # bf16 bucket: cast the reduced bucket back into the fp32 gradient.  Work.wait() blocks the CURRENT stream on the
+            # collective's end event, so it has to be called on the stream that issues the copy-back (round 3, ADVICE: it used
+            # to be called on the caller's stream, leaving the copy on self.stream unordered against the all-reduce)
+            if self.cuda:
+                with torch.cuda.stream(self.stream):
+                    w.wait()
                     self.g[rng[0]:rng[1]].copy_(self.stage[rng[0]:rng[1]])
+            else:
+                w.wait()
+                self.g[rng[0]:rng[1]].copy_(self.stage[rng[0]:rng[1]])
         self.works = []
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
