@@ -654,7 +654,8 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
                                                                  void* __restrict__ dbd,
                                                                  int o_dt, int T, int64_t p_bs, int64_t dp_bs,
                                                                  int64_t o_bs, float scale, int64_t nrows,
-                                                                 const void* __restrict__ pdrop, float dinv) {
+                                                                 const void* __restrict__ pdrop, float dinv, int H,
+                                                                 int64_t dbd_bsb, int64_t dbd_bsh) {
     // attention dropout: dprobs is the gradient of the DROPPED probabilities; the mask is read off the
     // saved dropped tensor (pdrop != 0), so no RNG replay is needed: dP = dPd * mask/(1-p)
     auto dpv = [&](int64_t pidx, float d) -> float {
@@ -669,6 +670,8 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
     const int64_t po = zz * p_bs + (int64_t)i * T;
     const int64_t dro = zz * dp_bs + (int64_t)i * T;
     const int64_t oz = zz * o_bs;
+    const int64_t dz = (zz / H) * dbd_bsb + (zz % H) * dbd_bsh;     // dBD block of (b, h): its own strides (head-major for the
+                                                                    // batch-folded d linear_pos GEMM)
     float pv[NV > 0 ? NV : 1], dv[NV > 0 ? NV : 1];
     float s = 0.f;
     if (NV > 0) {
@@ -686,9 +689,9 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
     auto emit = [&](int j, float v) {
         stx(ds, o_dt, oz + (int64_t)i * T + j, v);
         if (j <= i)
-            stx(dbd, o_dt, oz + (int64_t)i * T + (T - 1 - i + j), v);
+            stx(dbd, o_dt, dz + (int64_t)i * T + (T - 1 - i + j), v);
         else if (j > i + 1)
-            stx(dbd, o_dt, oz + (int64_t)(i + 1) * T + (j - i - 2), v);
+            stx(dbd, o_dt, dz + (int64_t)(i + 1) * T + (j - i - 2), v);
     };
     if (NV > 0) {
 #pragma unroll
@@ -701,14 +704,14 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_kernel(const void* __r
             emit(j, ldx(probs, p_dt, po + j) * (dpv(po + j, ldx(dprobs, dp_dt, dro + j)) - s) * scale);
     }
     if (i == 0)  // BD[0][0..T-2] never reaches the scores
-        for (int j = lane; j < T - 1; j += 64) stx(dbd, o_dt, oz + j, 0.f);
+        for (int j = lane; j < T - 1; j += 64) stx(dbd, o_dt, dz + j, 0.f);
 }
 
 template <int NC>
 __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
     const unsigned short* __restrict__ probs, const unsigned short* __restrict__ dprobs, unsigned short* __restrict__ ds,
     unsigned short* __restrict__ dbd, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs, float scale, int64_t nrows,
-    const unsigned short* __restrict__ pdrop, float dinv) {
+    const unsigned short* __restrict__ pdrop, float dinv, int H, int64_t dbd_bsb, int64_t dbd_bsh) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -717,8 +720,9 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
     const int64_t po = zz * p_bs + (int64_t)i * T;
     const unsigned short* dr = dprobs + zz * dp_bs + (int64_t)i * T;
     unsigned short* so = ds + zz * o_bs + (int64_t)i * T;
-    unsigned short* d0 = dbd + zz * o_bs + (int64_t)i * T + (T - 1 - i);    // + j   (j <= i)
-    unsigned short* d1 = dbd + zz * o_bs + (int64_t)(i + 1) * T - i - 2;    // + j   (j >= i + 2)
+    const int64_t dz = (zz / H) * dbd_bsb + (zz % H) * dbd_bsh;            // dBD block of (b, h), own strides
+    unsigned short* d0 = dbd + dz + (int64_t)i * T + (T - 1 - i);          // + j   (j <= i)
+    unsigned short* d1 = dbd + dz + (int64_t)(i + 1) * T - i - 2;          // + j   (j >= i + 2)
     const int nch = T >> 3;
     float pv[NC][8], dv[NC][8];
     float s = 0.f;
@@ -774,23 +778,25 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
         }
     }
     if (i == 0)  // BD[0][0..T-2] never reaches the scores
-        for (int j = lane; j < T - 1; j += 64) dbd[zz * o_bs + j] = 0;
+        for (int j = lane; j < T - 1; j += 64) dbd[dz + j] = 0;
 }
 
 extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprobs, int dprobs_dtype, void* ds,
                                       void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs,
-                                      int64_t o_bs, float scale, const void* probs_drop, float drop_p, void* stream) {
+                                      int64_t o_bs, float scale, const void* probs_drop, float drop_p, int64_t dbd_bsb,
+                                      int64_t dbd_bsh, void* stream) {
+    if (dbd_bsb == 0 && dbd_bsh == 0) dbd_bsb = (int64_t)H * o_bs, dbd_bsh = o_bs;     // default: [B][H][T][T] like ds
     const float dinv = 1.f / (1.f - drop_p);
     if (drop_p == 0.f) probs_drop = nullptr;
     int64_t nrows = (int64_t)B * H * T;
     if (probs_dtype == A3T_BF16 && dprobs_dtype == A3T_BF16 && out_dtype == A3T_BF16 && T % 8 == 0 && T <= 2048 &&
-        p_bs % 8 == 0 && dp_bs % 8 == 0 && o_bs % 8 == 0 && sm_al16(probs) && sm_al16(dprobs) && sm_al16(ds) &&
+        p_bs % 8 == 0 && dp_bs % 8 == 0 && o_bs % 8 == 0 && dbd_bsb % 8 == 0 && dbd_bsh % 8 == 0 && sm_al16(probs) && sm_al16(dprobs) && sm_al16(ds) &&
         (!probs_drop || sm_al16(probs_drop)) && ds != dprobs) {
 #define CALLV(NC)                                                                                                  \
     hipLaunchKernelGGL(relpos_softmax_bwd_bf16_kernel<NC>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,        \
                        (hipStream_t)stream, (const unsigned short*)probs, (const unsigned short*)dprobs,          \
                        (unsigned short*)ds, (unsigned short*)dbd, T, p_bs, dp_bs, o_bs, scale, nrows,             \
-                       (const unsigned short*)probs_drop, dinv)
+                       (const unsigned short*)probs_drop, dinv, H, dbd_bsb, dbd_bsh)
         SM_DISPATCH_VEC(T, CALLV);
 #undef CALLV
         return (int)hipGetLastError();
@@ -798,7 +804,7 @@ extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const 
 #define CALL(NV)                                                                                                 \
     hipLaunchKernelGGL(relpos_softmax_bwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
                        (hipStream_t)stream, probs, probs_dtype, dprobs, dprobs_dtype, ds, dbd, out_dtype, T, p_bs, dp_bs, \
-                       o_bs, scale, nrows, probs_drop, dinv)
+                       o_bs, scale, nrows, probs_drop, dinv, H, dbd_bsb, dbd_bsh)
     SM_DISPATCH(T, CALL);
 #undef CALL
     return (int)hipGetLastError();

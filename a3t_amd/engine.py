@@ -482,18 +482,27 @@ class MLMEngine:
         self._side(lambda: ops.gemm(pdrop if pdrop is not None else probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                                     batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
                                     compute=cmp, colsum=sl[3 * d:] if fz else None, **csk))
+        # dBD is laid out head-major [H][B][T][T] (bf16 mode): the gradient of linear_pos, sum_b dbd[b,h]^T (q+v)[b,h], is then ONE
+        # token-reduction GEMM per head with K = B*T (split-K) instead of B*H products of K = T accumulated by atomics
+        hm = self.bf16
+        zbd = (T * T, B * T * T) if hm else zb
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
-            dbd = self.ws.get(self._t("tmp.dbd16"), (B, H, T, T), torch.bfloat16)
+            dbd = self.ws.get(self._t("tmp.dbd16"), (H, B, T, T), torch.bfloat16)
         else:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
         ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=pdrop,
-                               drop_p=c.attention_dropout_rate if pdrop is not None else 0.0)
+                               drop_p=c.attention_dropout_rate if pdrop is not None else 0.0, dbd_head_major=hm)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
             dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
-            ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                     c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
+            if hm:
+                tiles = ((T + 127) // 128) * ((dk + 127) // 128) * H
+                ops.gemm(dbd, qv, dP, T, dk, B * T, 1, T, 1, d, d, batch=H, batch_inner=H, a_bs=(0, B * T * T), b_bs=(0, dk),
+                         c_bs=(0, dk), acc=ACC_ATOMIC, splitk=ops._splitk_for(tiles, B * T), compute=cmp)
+            else:
+                ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
+                         c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
             if self.bf16:
                 dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
                 ops.cast_bf16(dP, dP16)
@@ -509,7 +518,7 @@ class MLMEngine:
                                               a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
                                               colsum=sl[2 * d:] if fz else None, **csk), want_event=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
-        ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
+        ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
                  c_bs=(T * d, dk), compute=cmp, colsum=sl[d:] if fz else None, **csk)
         if dk_done is not None:      # the dV / dK slices of dqkv come from the side stream
             torch.cuda.current_stream().wait_event(dk_done)

@@ -246,10 +246,11 @@ def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale, probs_drop=None, 
                                             _stream()), "softmax_fwd")
 
 
-def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, drop_p=0.0):
-    """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place)."""
+def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, drop_p=0.0, dbd_head_major=False):
+    """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place).  dbd_head_major: dbd is laid out [H][B][T][T]."""
+    bsb, bsh = (T * T, B * T * T) if dbd_head_major else (0, 0)
     L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _dt(probs), _ptr(dprobs), _dt(dprobs), _ptr(ds), _ptr(dbd), _dt(dbd), B, H,
-                                            T, T * T, T * T, T * T, scale, _ptr(probs_drop), drop_p, _stream()),
+                                            T, T * T, T * T, T * T, scale, _ptr(probs_drop), drop_p, bsb, bsh, _stream()),
             "softmax_bwd")
 
 
