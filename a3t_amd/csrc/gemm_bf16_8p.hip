@@ -148,24 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
             if (c_unit < total) set_tile_lanes();
         }
     };
-#ifdef G8_SIMPLE_ISSUE   // experiment: the probe's plain-GEMM address arithmetic on global_load_lds (no tails, no conv)
-    const unsigned voffS = (unsigned)(srow * p.K * 2) + schunk16;
     auto issue = [&](const int H, const int buf) __attribute__((always_inline)) {
-        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + w * 1024;
-        const bool live = c_unit < total;
-        const size_t rs = (size_t)p.K * 2;
-        const char* base = (H < 2) ? (const char*)p.A + (size_t)(c_tm * 256 + w * 8 + (H & 1) * 128) * rs
-                                   : (const char*)p.B + (size_t)(c_tn * 256 + ((w * 8) >> 5) * 64 + (((w * 8) >> 2) & 3) * 16 + (((w * 8) >> 4) & 1) * 4 + (H & 1) * 8) * rs;
-        const unsigned lo = (H < 2) ? voffS : (unsigned)((((srow >> 2) & 1) * 16 + (srow & 3)) * p.K * 2) + schunk16;
-        base = live ? base + (size_t)c_kt * 128 : (const char*)p.B;
-        const size_t qs = (H < 2) ? 64 * rs : 128 * rs;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lo), LDS_AS(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + qs + lo), LDS_AS(dst + 8192), 16, 0, 0);
-    };
-    auto issue_unused = [&](const int H, const int buf) __attribute__((always_inline)) {
-#else
-    auto issue = [&](const int H, const int buf) __attribute__((always_inline)) {
-#endif
         // (uniform address parts are recomputed here on purpose: hoisted out of the K loop they cost ~30 SGPRs and spill)
         int wv = w;
         unsigned a_rsb = a_rsb_, b_rsb = b_rsb_;
@@ -256,9 +239,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
     // ---- epilogue of quadrant (a, hb) of tile (tm, tn): lane (fr, g) owns rows a*128 + wr*64 + i*16 + fr (i = 0..3) x
     // the 8 columns wc*64 + g*16 + hb*8 .. +7
     auto epi = [&](const int a, const int hb, const int tm, const int tn, const int par) __attribute__((always_inline)) {
-#ifdef G8_NOEPI
-        return;
-#endif
         EPI_ARGS(q);
         // (everything derived from the lane id is recomputed here: hoisted out of the K loop these addresses would be spilled,
         //  and a scratch reload costs a vmcnt(0), i.e. the whole DMA pipeline)
@@ -478,16 +458,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
         }
     }
     if (pend) epi(1, 0, e_tm, e_tn, e_par);
-#ifdef G8_NOEPI   // (timing experiment: keep the accumulators alive)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[a][b][i][j]));
-#endif
     STAMP(st_k);
     WAIT_LGKM(0);
     if (wr == 0) BAR();
@@ -823,17 +793,19 @@ static void launch_8p_tn(const GP& pv, int grid, hipStream_t stream) {
 
 // weight gradients: reduction-strided operands, K (tokens) split over workgroups
 static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
-    // Opt-in (A3T_GEMM_8P_TN=1, or mode 1): its K loop runs 1.55 us per K-tile (1.39 PFLOP/s) but the 240 workgroups of a
-    // split-K grid finish together and their 15.7 M fp32 atomics cost 20-35 us with nothing to hide them behind: 153 / 165 us
-    // against 170 / 171 us for the two FFN weight gradients alone, and no gain inside the training step.
+    // Its K loop runs 1.55 us per K-tile (1.39 PFLOP/s) but the ~240 workgroups of a split-K grid finish together and their
+    // 15.7 M fp32 atomics cost 20-35 us with nothing to hide them behind, and a 128-KiB / 496-register workgroup shares its CU
+    // with nobody (the 128x128 weight-gradient kernel runs beside the main stream's kernels).  configs[1]'s FFN weight
+    // gradients: 153 / 165 us against 170 / 171 us alone, +1 ms per step inside the step; configs[3]'s (K = 28800, 90 K-tiles per
+    // workgroup): -1 ms per step.  Hence the margin below.  A3T_GEMM_8P_TN=0 / 1: never / whenever legal.
     static int tn_on = -1;
     if (tn_on < 0) {
         const char* e = getenv("A3T_GEMM_8P_TN");
-        tn_on = e ? atoi(e) : 0;
+        tn_on = e ? atoi(e) : 2;
     }
     const int mode = g8_mode();
-    if (!tn_on && mode != 1) return -1;
-    if (mode == 0 || batch != 1 || p.c_dtype != A3T_F32 || p.M % 8 != 0 || p.N % 8 != 0) return -1;
+    if (mode == 0 || tn_on == 0) return -1;
+    if (batch != 1 || p.c_dtype != A3T_F32 || p.M % 8 != 0 || p.N % 8 != 0) return -1;
     if (p.a_rs != 1 || p.b_rs != 1 || p.bias || p.R || p.S || p.colsum || p.act != A3T_ACT_NONE || p.drop_inv > 0.f) return -1;
     const bool wg = p.taps > 1;
     if (wg && ((p.N % p.taps) || ((p.N / p.taps) % 128) || p.Tseq <= 0 || p.Tseq >= 32768)) return -1;
@@ -847,9 +819,12 @@ static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
     if (splits < 1) splits = 1;
     if (splits > nkt / 16) splits = nkt / 16 > 0 ? nkt / 16 : 1;       // >= 16 K-tiles per workgroup
     if (splits > 1 && p.accumulate != A3T_ACC_ATOMIC) splits = 1;
-    if (mode == 2) {
+    if (mode == 2 && tn_on == 2) {
         const double fill = (double)p.M * p.N / ((double)tm * 256 * tn * 256);
         if (fill < 0.7 || tiles * splits < 160 || nkt / splits < 32) return -1;
+        const double t8 = (double)((nkt + splits - 1) / splits) * 1.55 + 35.0;      // us: K loop + the atomic burst
+        const double t128 = 2.0 * p.M * p.N * (double)p.K / 680e6;                 // us at the 128x128 kernel's ~680 TFLOP/s
+        if (t8 > 0.7 * t128) return -1;
     }
     GP pv = p;
     pv.tiles_n = (int)tn, pv.ntiles = (int)tiles, pv.splitk = splits;

@@ -680,6 +680,54 @@ def test_8phase_gemm_randomised_sweep_and_ab():
         lib.a3t_gemm_8p_mode(old)
 
 
+def test_8phase_tn_weight_gradients():
+    """The reduction-strided (TN) variant of the 8-phase GEMM: fused Conv1d weight gradients (output columns = (tap, c), token
+    shift per 128-column half, zeros across utterance boundaries) and Linear weight gradients, token counts that are NOT a
+    multiple of the 64-token K-tile, M / N tails, against fp32 torch math and the 128x128 kernel."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import BF16
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    old = lib.a3t_gemm_8p_mode(1)
+    try:
+        for (B, T, cin, cout, taps) in [(3, 200, 128, 512, 3), (5, 1120, 384, 1536, 3), (4, 264, 256, 264, 1), (2, 1000, 384, 1152, 1)]:
+            M = B * T
+            dy, x = rn(M, cout).bfloat16(), rn(M, cin).bfloat16()
+            outs = []
+            for mode in (0, 1):
+                lib.a3t_gemm_8p_mode(mode)
+                if taps > 1:
+                    dW = torch.zeros(cout, taps, cin, device=DEV)
+                    ops.conv_bwd_weight(dy, x, dW, T, 1, alpha=0.5, compute=BF16)
+                else:
+                    dW = torch.zeros(cout, cin, device=DEV)
+                    ops.linear_bwd_weight(dy, x, dW, alpha=0.5, compute=BF16)
+                outs.append((dW, lib.a3t_gemm_last_kernel().decode()))
+            torch.cuda.synchronize()
+            assert "8p_tn" in outs[1][1] and "8p" not in outs[0][1], outs[1][1]
+            if taps > 1:
+                xs, dyf = x.float().view(B, T, cin), dy.float().view(B, T, cout)
+                ref = torch.zeros(cout, taps, cin, device=DEV)
+                for t in range(taps):
+                    xsft = torch.zeros_like(xs)
+                    sh = t - 1
+                    if sh < 0:
+                        xsft[:, -sh:] = xs[:, :sh]
+                    elif sh > 0:
+                        xsft[:, :-sh] = xs[:, sh:]
+                    else:
+                        xsft = xs
+                    ref[:, t, :] = 0.5 * torch.einsum("btn,btc->nc", dyf, xsft)
+            else:
+                ref = 0.5 * dy.float().t() @ x.float()
+            for dW, _ in outs:
+                assert float((dW - ref).abs().max() / ref.abs().max()) < 1e-4
+    finally:
+        lib.a3t_gemm_8p_mode(old)
+
+
 def test_row_kernels_randomised_sweep():
     """75 random problems for the rel-pos softmax (T from 1 to 320 incl. T % 8 != 0, fully / partially padded
     utterances, fp32 and bf16 storage), LayerNorm (any M, D incl. the 16-byte vector widths) and GLU + depthwise conv
