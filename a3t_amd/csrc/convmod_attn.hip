@@ -711,7 +711,8 @@ template <int NC>
 __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
     const unsigned short* __restrict__ probs, const unsigned short* __restrict__ dprobs, unsigned short* __restrict__ ds,
     unsigned short* __restrict__ dbd, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs, float scale, int64_t nrows,
-    const unsigned short* __restrict__ pdrop, float dinv, int H, int64_t dbd_bsb, int64_t dbd_bsh) {
+    const unsigned short* __restrict__ pdrop, float dinv, int H, int64_t dbd_bsb, int64_t dbd_bsh, unsigned int rng_thr_,
+    unsigned int rng_key) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
@@ -741,6 +742,14 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
                 for (int e = 0; e < 8; ++e) {
                     const unsigned int h = (mw[e >> 1] >> (16 * (e & 1))) & 0x7fff;   // |x| != 0  (ignores -0)
                     dv[q][e] = h ? dv[q][e] * dinv : 0.f;
+                }
+            } else if (rng_thr_) {   // the forward's mask regenerated from the counter RNG (same index): 2 B / score less to read
+#pragma unroll
+                for (int e = 0; e < 8; e += 4) {
+                    bool kp[4];
+                    rng_keep4(rng_key, (unsigned int)(po + j0 + e), rng_thr_, kp);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) dv[q][e + f] = kp[f] ? dv[q][e + f] * dinv : 0.f;
                 }
             }
 #pragma unroll
@@ -784,10 +793,14 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
 extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprobs, int dprobs_dtype, void* ds,
                                       void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs,
                                       int64_t o_bs, float scale, const void* probs_drop, float drop_p, int64_t dbd_bsb,
-                                      int64_t dbd_bsh, void* stream) {
+                                      int64_t dbd_bsh, uint32_t drop_key, void* stream) {
     if (dbd_bsb == 0 && dbd_bsh == 0) dbd_bsb = (int64_t)H * o_bs, dbd_bsh = o_bs;     // default: [B][H][T][T] like ds
+    if (drop_p < 0.f || drop_p >= 1.f) return A3T_EINVAL;
     const float dinv = 1.f / (1.f - drop_p);
     if (drop_p == 0.f) probs_drop = nullptr;
+    // drop_p > 0 without probs_drop: the mask is regenerated from the counter RNG (key drop_key, element index
+    // z*p_bs + i*T + j as in a3t_relpos_softmax_fwd) -- bf16 vector kernel with the standard p_bs = T*T only
+    const unsigned int rthr = (drop_p > 0.f && !probs_drop) ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     int64_t nrows = (int64_t)B * H * T;
     if (probs_dtype == A3T_BF16 && dprobs_dtype == A3T_BF16 && out_dtype == A3T_BF16 && T % 8 == 0 && T <= 2048 &&
         p_bs % 8 == 0 && dp_bs % 8 == 0 && o_bs % 8 == 0 && dbd_bsb % 8 == 0 && dbd_bsh % 8 == 0 && sm_al16(probs) && sm_al16(dprobs) && sm_al16(ds) &&
@@ -796,11 +809,12 @@ extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const 
     hipLaunchKernelGGL(relpos_softmax_bwd_bf16_kernel<NC>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,        \
                        (hipStream_t)stream, (const unsigned short*)probs, (const unsigned short*)dprobs,          \
                        (unsigned short*)ds, (unsigned short*)dbd, T, p_bs, dp_bs, o_bs, scale, nrows,             \
-                       (const unsigned short*)probs_drop, dinv, H, dbd_bsb, dbd_bsh)
+                       (const unsigned short*)probs_drop, dinv, H, dbd_bsb, dbd_bsh, rthr, drop_key)
         SM_DISPATCH_VEC(T, CALLV);
 #undef CALLV
         return (int)hipGetLastError();
     }
+    if (rthr) return A3T_EINVAL;    // (the generic kernel reads the mask off probs_drop)
 #define CALL(NV)                                                                                                 \
     hipLaunchKernelGGL(relpos_softmax_bwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
                        (hipStream_t)stream, probs, probs_dtype, dprobs, dprobs_dtype, ds, dbd, out_dtype, T, p_bs, dp_bs, \

@@ -101,6 +101,13 @@ class MLMEngine:
         # (the exact-fp32 MFMA for that layer and its two gradients cost 0.55 ms); gradients use hi only.
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
         self.sfc_f32 = os.environ.get("A3T_SFC_F32", "1") != "0"
+        # Round 3, measured on one box (tools/step_ab.sh, ms per step, two runs each): baseline 50.69 / 50.76; attention-dropout mask
+        # of the softmax backward regenerated from the counter RNG instead of read off the dropped probabilities 50.62 / 50.33
+        # (default); head-major dBD + ONE batch-folded token reduction per head for the gradient of linear_pos 51.36 / 51.40 -- the
+        # GEMM is faster alone (111 -> ~50 us per layer, all GEMMs alone 43.2 -> 42.7 ms) but as one 432-workgroup split-K burst
+        # on the side stream it costs the main stream more than the 64 small products did: opt-in (A3T_ATTN_DBD_HM=1).
+        self.attn_hm = os.environ.get("A3T_ATTN_DBD_HM", "0") == "1"
+        self.attn_regen = os.environ.get("A3T_ATTN_REGEN_MASK", "1") != "0"
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
         # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
         # at the benchmark shape; whole eval forward 4.32 vs 4.74 ms at B = 8, 10.5 vs 11.3 ms at B = 32, 4+4 blocks), except
@@ -484,7 +491,7 @@ class MLMEngine:
                                     compute=cmp, colsum=sl[3 * d:] if fz else None, **csk))
         # dBD is laid out head-major [H][B][T][T] (bf16 mode): the gradient of linear_pos, sum_b dbd[b,h]^T (q+v)[b,h], is then ONE
         # token-reduction GEMM per head with K = B*T (split-K) instead of B*H products of K = T accumulated by atomics
-        hm = self.bf16
+        hm = self.bf16 and self.attn_hm
         zbd = (T * T, B * T * T) if hm else zb
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
@@ -492,8 +499,12 @@ class MLMEngine:
         else:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
-        ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=pdrop,
-                               drop_p=c.attention_dropout_rate if pdrop is not None else 0.0, dbd_head_major=hm)
+        adr = self._drop(c.attention_dropout_rate, tag + ".att") if pdrop is not None else None
+        # bf16 path: the attention-dropout mask comes back from the counter RNG (same key and index as the forward) instead
+        # of being read off the dropped probabilities: one T x T read less in the most HBM-bound kernel of the step
+        regen = self.bf16 and self.attn_regen and adr is not None and T % 8 == 0 and T <= 2048
+        ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
+                               drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
             dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
             if hm:

@@ -246,12 +246,14 @@ def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale, probs_drop=None, 
                                             _stream()), "softmax_fwd")
 
 
-def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, drop_p=0.0, dbd_head_major=False):
-    """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place).  dbd_head_major: dbd is laid out [H][B][T][T]."""
+def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, drop_p=0.0, dbd_head_major=False,
+                       drop_key=0):
+    """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place).  dbd_head_major: dbd is laid out [H][B][T][T].
+    drop_p > 0 with probs_drop=None: the mask is regenerated from (drop_key, index) instead of read off probs_drop."""
     bsb, bsh = (T * T, B * T * T) if dbd_head_major else (0, 0)
     L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _dt(probs), _ptr(dprobs), _dt(dprobs), _ptr(ds), _ptr(dbd), _dt(dbd), B, H,
-                                            T, T * T, T * T, T * T, scale, _ptr(probs_drop), drop_p, bsb, bsh, _stream()),
-            "softmax_bwd")
+                                            T, T * T, T * T, T * T, scale, _ptr(probs_drop), drop_p, bsb, bsh, drop_key,
+                                            _stream()), "softmax_bwd")
 
 
 def attn_fused_supported(dk, T):

@@ -177,7 +177,9 @@ int a3t_relpos_softmax_fwd(const void* ac, const void* bd, int scores_dtype, con
 int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprobs, int dprobs_dtype, void* ds,
                            void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
                            float scale, const void* probs_drop, float drop_p, int64_t dbd_bs_b, int64_t dbd_bs_h,
-                           void* stream);
+                           uint32_t drop_key, void* stream);
+/* drop_p > 0 with probs_drop == NULL (bf16 vector path): the dropout mask is regenerated from the counter RNG with drop_key
+ * and the forward's element index instead of being read off the saved dropped probabilities. */
 /* dbd_bs_b / dbd_bs_h: strides (elements) of the (b, h) blocks of dbd; 0 / 0 = the [B][H][T][T] layout of ds.  The
  * head-major layout [H][B][T][T] (dbd_bs_b = T*T, dbd_bs_h = B*T*T) makes the gradient of linear_pos
  * (attention.py:188: sum over the batch of dbd^T (q+v)) ONE reduction over K = B*T per head instead of B atomically

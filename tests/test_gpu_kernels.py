@@ -417,6 +417,14 @@ def test_relpos_softmax_bf16_scores(B, H, T):
     ops.relpos_softmax_bwd(probs, dpd.to(DEV).bfloat16(), ds, dbd, B, H, T, scale, probs_drop=pd, drop_p=pdrop_p)
     _close(ds, ac.grad, atol=6e-3, rtol=3e-2)
     _close(dbd, bd.grad, atol=6e-3, rtol=3e-2)
+    if T % 8 == 0:
+        # round 3: the same gradients with the mask REGENERATED from the counter RNG (no read of the dropped probabilities),
+        # into the head-major dBD layout [H][B][T][T] the engine uses
+        ds2 = torch.empty_like(ds)
+        dbd2 = torch.full((H, B, T, T), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.relpos_softmax_bwd(probs, dpd.to(DEV).bfloat16(), ds2, dbd2, B, H, T, scale, probs_drop=None, drop_p=pdrop_p,
+                               dbd_head_major=True, drop_key=key)
+        assert torch.equal(ds2, ds) and torch.equal(dbd2.permute(1, 0, 2, 3), dbd)
 
 
 @pytest.mark.parametrize("B,T,C,K", [(2, 150, 64, 7), (3, 130, 128, 31), (1, 70, 384, 5), (2, 1120, 384, 31)])
