@@ -120,7 +120,8 @@ def vocoder_rtf(dev, B=8, Tf=1000, reps=3, cpu=False):
     audio_s = B * Tf * 300 / 24000.0
     flops = 2.60e6 * B * Tf * 300
     res = dict(metric="vocoder RTF", rtf=dt / audio_s, ms=dt * 1e3, audio_seconds=audio_s, samples_per_s=B * Tf * 300 / dt,
-               tflops=flops / dt / 1e12, dtype="f32", finite=bool(torch.isfinite(wav).all()),
+               tflops=flops / dt / 1e12, frac=flops / dt / 1e12 / MFMA_PEAK["f32"], peak_tflops=MFMA_PEAK["f32"], dtype="f32",
+               finite=bool(torch.isfinite(wav).all()),
                workload=f"ParallelWaveGAN v1 generator, B={B} x {Tf} frames, hop 300, 24 kHz")
     if cpu:
         # CPU baseline + parity ("own CPU restatement, 1 utterance of 400 frames"): the oracle's pwg_forward on
