@@ -123,3 +123,28 @@ def test_embedding_bias_gets_its_gradient_with_dropout_on():
         torch.cuda.synchronize()
         dead = [k for k, v in st.g.items() if float(v.abs().max()) == 0.0]
         assert not dead, (compute, dead)
+
+
+def test_first_postnet_conv_gradient_with_split_forward_operand():
+    """bf16 mode runs the FIRST postnet conv on (hi, lo) = (bf16(before), bf16(before - hi)) in the forward pass but keeps only
+    hi for its weight gradient (engine.py, A3T_POST_F32_FIRST): the gradient of post.0.w must still track the fp32 engine's
+    (the operand mismatch is one bf16 ulp of the input and was not bounded by any test), as must sfc.w's, whose
+    forward now runs on the exact-fp32 MFMA while its gradient uses the bf16 operands."""
+    from a3t_amd.collate import synthetic_batch
+    from a3t_amd.engine import MLMEngine
+    c = _tiny(postnet_dropout_rate=0.0)
+    grads = {}
+    batch = synthetic_batch(c, 3, 96, 16, seed=9, device=DEV)
+    for compute in ("f32", "bf16"):
+        st = _store(c, seed=4)
+        e = MLMEngine(c, st, compute=compute, training=True, dropout=False)
+        e.forward(batch)
+        st.zero_grad()
+        e.backward()
+        torch.cuda.synchronize()
+        grads[compute] = {k: st.g[k].clone() for k in ("post.0.w", "post.1.w", "sfc.w", "sfc.b")}
+    for k, g32 in grads["f32"].items():
+        g16 = grads["bf16"][k]
+        rel = float((g16 - g32).norm() / g32.norm())
+        cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+        assert rel < 6e-2 and cos > 0.998, (k, rel, cos)
