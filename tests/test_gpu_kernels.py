@@ -296,10 +296,11 @@ def test_layernorm_bwd_bf16_input_copy_and_fused_column_sum(M, D):
 
 
 @pytest.mark.parametrize("layout", ["nt", "nn"])
-def test_gemm_256x256_pingpong_kernel(layout):
-    """Shapes that the dispatcher routes to gemm_bf16_t256_kernel (K/splitk >= 4096, >= 200 full 256x256 tiles):
+def test_gemm_large_k_many_tiles(layout):
+    """A large GEMM (K = 4096, 232 256x256 tiles with a ragged last row tile): the k-contiguous layout is what the
+    dispatcher's cost model routes to the persistent 8-phase kernel, the strided-W layout stays on the 128x128 kernel;
     bf16 operands, fp32 accumulate, checked against an fp32 matmul of the same bf16-rounded inputs.
-    Transpose-detecting (non-square operands, M != N) and with a ragged last row tile."""
+    Transpose-detecting (non-square operands, M != N)."""
     ops = _ops()
     from a3t_amd._lib import BF16
     M, N, K = 3904 + 256 * 13, 2048, 4096          # 7232 rows: 29 row tiles (last one partial: 64 rows), 8 col tiles
@@ -309,6 +310,8 @@ def test_gemm_256x256_pingpong_kernel(layout):
         W = (_rand(N, K, seed=2) * K ** -0.5).to(DEV).bfloat16()
         out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         ops.linear_fwd(x, W, out, bias=bias, compute=BF16)
+        from a3t_amd import _lib
+        assert "8p" in _lib.load().a3t_gemm_last_kernel().decode()
         ref = x.float() @ W.float().t() + bias
     else:
         W = (_rand(K, N, seed=2) * K ** -0.5).to(DEV).bfloat16()   # dx = dy @ W with dy := x, W stored [K][N]

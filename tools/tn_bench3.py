@@ -1,4 +1,4 @@
-"""Weight-gradient (TN, split-K atomics) GEMM sweep; run with A3T_GEMM_T256=0/1."""
+"""Weight-gradient (TN, split-K atomics) GEMM sweep; run with A3T_GEMM_8P_TN=0/1."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
