@@ -95,6 +95,8 @@ _SIGS = {
     "a3t_dropout": [_P, c_int, _P, c_int, c_int64, c_float, ctypes.c_uint32, c_float, _P],
     "a3t_gemm_8p_mode": [c_int],
     "a3t_gemm_8p_supported": [c_int, c_int, c_int, c_int, c_int],
+    "a3t_gemm_pn_mode": [c_int],
+    "a3t_gemm_pn_supported": [c_int, c_int, c_int, c_int, c_int],
     "a3t_dropout_bwd_cast": [_P, _P, c_int, _P, c_float, c_int, c_int, c_float, ctypes.c_uint32, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["a3t_version", "a3t_gemm_last_kernel", "a3t_gemm_keep_bytes"])

@@ -448,6 +448,7 @@ static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 static inline bool m8(int64_t v) { return (v % 8) == 0; }
 
 int a3t_gemm_bf16_8p(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_8p.hip
+int a3t_gemm_bf16_pn(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_pn.hip
 
 template <int LY, int ST, int WM, int CV, int WN = 2>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
@@ -481,6 +482,10 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
                  al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
     if (p.colsum && !pv.epi_vec) return -1;
 
+    if (!(pv.keep_in || pv.keep_out)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
+        const int rc = a3t_gemm_bf16_pn(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
+        if (rc != -1) return rc;
+    }
     {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
         const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;

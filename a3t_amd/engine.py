@@ -128,6 +128,7 @@ class MLMEngine:
             self.flat16 = torch.zeros(store.total, dtype=torch.bfloat16, device=self.dev)
             self.p16 = {k: self.flat16[o:o + math.prod(s)].view(s) for k, (o, s) in store.offsets.items()}
         self._ffn_plans = {}
+        self._lin_plans = {}
         self._wt = {}        # transposed FFN weight shadows (8-phase data gradients), built on demand
 
     # ------------------------------------------------------------------ helpers
@@ -164,10 +165,12 @@ class MLMEngine:
                 ops.cast_bf16_conv_t(self.store.flat, flat, src_off, dst_off, *shp)
 
     def _setup_wt(self, suf, shape):
-        """Transposed, tap-reversed bf16 shadows of every FFN weight `*.suf` of `shape` = [n][k][c] -> [c][k'][n]: the data
-        gradient of that conv becomes a k-contiguous conv of the output gradient (a3t_cast_bf16_conv_t), which the 8-phase GEMM
-        can run.  One transposing cast per step for all of them; only built when the 8-phase kernel would take the GEMM."""
-        names = [k for k in self.store.offsets if k.endswith("." + suf) and tuple(self.store.offsets[k][1]) == tuple(shape)]
+        """Transposed, tap-reversed bf16 shadows of every weight `*.suf` of `shape` = [n][k][c] -> [c][k'][n] (Linear: k = 1, stored
+        [n][c]): the data gradient of that conv / linear becomes a k-contiguous conv of the output gradient
+        (a3t_cast_bf16_conv_t), which the 8-phase and the 384-column panel GEMMs can run.  One transposing cast per step for all
+        of them; only built when one of those kernels would take the GEMM."""
+        stored = (tuple(shape), (shape[0], shape[2])) if shape[1] == 1 else (tuple(shape),)
+        names = [k for k in self.store.offsets if k.endswith("." + suf) and tuple(self.store.offsets[k][1]) in stored]
         if not names:
             return
         n = math.prod(shape)
@@ -191,7 +194,7 @@ class MLMEngine:
                 drop = ops.G8_DROP if (self.dropping and c.dropout_rate > 0) else 0
                 keep = ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_BIAS_ACT | drop | ops.G8_KEEP_OUT) and \
                     ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_KEEP_IN | ops.G8_COLSUM)
-                d1 = ops.gemm_8p_supported(M, c.adim, k * c.ff, k, 0)
+                d1 = ops.gemm_8p_supported(M, c.adim, k * c.ff, k, 0) or ops.gemm_pn_supported(M, c.adim, k * c.ff, k, 0)
                 if keep and "w2" not in self._wt:
                     self._setup_wt("w2", (c.adim, k, c.ff))
                 if d1 and "w1" not in self._wt:
@@ -199,6 +202,27 @@ class MLMEngine:
                 keep, d1 = keep and "w2" in self._wt, d1 and "w1" in self._wt
             self._ffn_plans[M] = (keep, d1)
         return self._ffn_plans[M]
+
+    def _lin_dgrad(self, dy, name, dx):
+        """dx = dy W for the Linear weight `name` ([out][in]).  When the 384-column panel GEMM would take the k-contiguous form
+        (in = 384 columns, A3T_LIN_DGRAD_T=0 turns it off) it runs as dx = dy (W^T)^T on the transposed bf16 shadow of W."""
+        suf = name.rsplit(".", 1)[1]
+        M = dy.shape[0]
+        key = (suf, M, dx.dtype)
+        if key not in self._lin_plans:
+            use = False
+            if self.bf16 and self.dev.type == "cuda" and os.environ.get("A3T_LIN_DGRAD_T", "1") != "0":
+                n_out, n_in = self.store.offsets[name][1]
+                use = ops.gemm_pn_supported(M, n_in, n_out, 1, ops.G8_F32_OR_RES if dx.dtype == torch.float32 else 0)
+                if use and suf not in self._wt:
+                    self._setup_wt(suf, (n_out, 1, n_in))
+                use = use and suf in self._wt and name in self._wt[suf][2]
+            self._lin_plans[key] = use
+        if self._lin_plans[key]:
+            wt = self._wt[suf][2][name]
+            ops.linear_fwd(dy, wt.view(wt.shape[0], wt.shape[2]), dx, compute=self.cmp)
+        else:
+            ops.linear_bwd_data(dy, self.W(name), dx, compute=self.cmp)
 
     def _act(self, name, shape):
         return self.ws.get(name, shape, self.adt)
@@ -435,7 +459,7 @@ class MLMEngine:
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".bo"], 1.0)
         self._side(lambda: ops.linear_bwd_weight(ga, ctx, gr[pre + ".wo"], compute=cmp))
         dctx = self._act("tmp.dctx", (M, d))
-        ops.linear_bwd_data(ga, self.W(pre + ".wo"), dctx, compute=cmp)
+        self._lin_dgrad(ga, pre + ".wo", dctx)
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
         dqkv = self._act(self._t("tmp.dqkv"), (M, 3 * d))
@@ -463,7 +487,7 @@ class MLMEngine:
             ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gr[pre + ".u"], gr[pre + ".v"], gr[pre + ".bqkv"])
             self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp))
             dy = self._act("tmp.dy", (M, d))
-            ops.linear_bwd_data(dqkv, self.W(pre + ".wqkv"), dy, compute=cmp)
+            self._lin_dgrad(dqkv, pre + ".wqkv", dy)
             self._pre_ln(ga, g, g16)
             self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
             self._sub_end()
@@ -542,7 +566,7 @@ class MLMEngine:
             self._bias_grad(dqkv, gbq)
         self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp))
         dy = self._act("tmp.dy", (M, d))
-        ops.linear_bwd_data(dqkv, self.W(pre + ".wqkv"), dy, compute=cmp)
+        self._lin_dgrad(dqkv, pre + ".wqkv", dy)
         self._pre_ln(ga, g, g16)
         self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
         self._sub_end()
@@ -599,7 +623,7 @@ class MLMEngine:
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".pb2"], 1.0)
         self._side(lambda: ops.linear_bwd_weight(ga, s, gr[pre + ".pw2"], compute=cmp))
         ds = self.ws.get("tmp.ds", (M, d))
-        ops.linear_bwd_data(ga, self.W(pre + ".pw2"), ds, compute=cmp)
+        self._lin_dgrad(ga, pre + ".pw2", ds)
         dz = self.ws.get("tmp.dz", (M, d))
         self._bn_bwd(tag, ds, pre + ".bn", ACT_SWISH, dz)
         dg = self._act(self._t("tmp.dg"), (M, 2 * d))
@@ -607,7 +631,7 @@ class MLMEngine:
                            dgsum=gr[pre + ".pb1"])
         self._side(lambda: ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp))
         dy = self._act("tmp.dy", (M, d))
-        ops.linear_bwd_data(dg, self.W(pre + ".pw1"), dy, compute=cmp)
+        self._lin_dgrad(dg, pre + ".pw1", dy)
         self._pre_ln(ga, g, g16)
         self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
         self._sub_end()

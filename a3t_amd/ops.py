@@ -125,6 +125,11 @@ def gemm_8p_supported(M, N, K, taps=1, flags=0):
     return bool(L.load().a3t_gemm_8p_supported(int(M), int(N), int(K), int(taps), int(flags)))
 
 
+def gemm_pn_supported(M, N, K, taps=1, flags=0):
+    """True when a3t_gemm runs this k-contiguous bf16 problem on the 384-column panel kernel (csrc/gemm_bf16_pn.hip)."""
+    return bool(L.load().a3t_gemm_pn_supported(int(M), int(N), int(K), int(taps), int(flags)))
+
+
 def gemm_keep_bytes(M, N):
     return int(L.load().a3t_gemm_keep_bytes(int(M), int(N)))
 

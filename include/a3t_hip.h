@@ -102,6 +102,11 @@ int a3t_gemm(const a3t_gemm_desc* d, void* stream);
  * residual, 32 column sums); bytes of a keep-bit image */
 int a3t_gemm_8p_supported(int M, int N, int K, int taps, int flags);
 int64_t a3t_gemm_keep_bytes(int M, int N);
+/* 1 when a3t_gemm runs the k-contiguous bf16 problem on the 160-row x 384-column panel kernel (csrc/gemm_bf16_pn.hip: every
+ * GEMM whose output is d_model = 384 wide -- the second FFN conv of multi_layer_conv.py:36-63, linear_out of
+ * attention.py:64-96, pointwise_conv2 of the conformer ConvolutionModule, and their data gradients through transposed
+ * weight shadows); same `flags` as above (4 and 8: never). */
+int a3t_gemm_pn_supported(int M, int N, int K, int taps, int flags);
 
 /* LayerNorm over the last dim (transformer/layer_norm.py:12-42 eps=1e-12; torch.nn.LayerNorm
  * eps=1e-5 in the speech embed, conformer/encoder.py:404).  mean/rstd: [M] saved for backward. */
@@ -319,6 +324,8 @@ const char* a3t_gemm_last_kernel(void);
 /* Kernel-selection override for A/B measurements and tests: 0 = never use the persistent 256x256 8-phase GEMM, 1 = whenever
  * the descriptor is legal for it, 2 = the built-in heuristic, -1 = re-read A3T_GEMM_8P.  Returns the previous mode. */
 int a3t_gemm_8p_mode(int mode);
+/* The same switch for the 384-column panel GEMM (A3T_GEMM_PN). */
+int a3t_gemm_pn_mode(int mode);
 
 #ifdef __cplusplus
 }

@@ -148,3 +148,129 @@ def test_first_postnet_conv_gradient_with_split_forward_operand():
         rel = float((g16 - g32).norm() / g32.norm())
         cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
         assert rel < 6e-2 and cos > 0.998, (k, rel, cos)
+
+
+def test_panel_gemm_kernel_against_the_128_kernel_and_torch():
+    """The 384-column panel GEMM (gemm_bf16_pn.hip: one 160-row panel x all 384 columns per workgroup) forced on: bit-identical
+    to the 128x128 kernel (same products in the same k order) with every epilogue it fuses -- bias, relu, dropout, alpha, fp32
+    residual, bf16 / fp32 store, column sums -- on M tails, several rounds of panels, Conv1d over time with 3 and 5 taps across
+    utterance boundaries, and within bf16 rounding of fp32 torch math."""
+    from a3t_amd import _lib, ops
+    from a3t_amd._lib import ACT_NONE, ACT_RELU, BF16
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    rn = lambda *s, sc=1.0: torch.randn(*s, device=DEV, generator=g) * sc
+    N = 384
+
+    def both(fn):
+        outs = []
+        old8, oldp = lib.a3t_gemm_8p_mode(0), lib.a3t_gemm_pn_mode(0)
+        try:
+            for mode in (0, 1):
+                lib.a3t_gemm_pn_mode(mode)
+                outs.append(fn())
+                outs.append(lib.a3t_gemm_last_kernel().decode())
+        finally:
+            lib.a3t_gemm_pn_mode(oldp)
+            lib.a3t_gemm_8p_mode(old8)
+        torch.cuda.synchronize()
+        return outs
+
+    rel = lambda a, b: float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-9))
+    for (M, K, act, f32out, res, drop, cs) in [(160, 128, ACT_NONE, False, False, False, False), (1000, 384, ACT_RELU, False, False, False, True),
+                                               (4099 * 8, 768, ACT_NONE, True, True, True, False), (45000, 256, ACT_NONE, False, False, True, True),
+                                               (777, 1152, ACT_RELU, True, True, False, True), (8, 128, ACT_NONE, True, False, False, True)]:
+        x, W, b = rn(M, K).bfloat16(), rn(N, K, sc=0.05).bfloat16(), rn(N)
+        R = rn(M, N) if res else None
+
+        def f():
+            o = torch.empty(M, N, device=DEV, dtype=torch.float32 if f32out else torch.bfloat16)
+            csum = torch.zeros(N, device=DEV) if cs else None
+            ops.gemm(x, W, o, M, N, K, K, 1, K, 1, N, bias=b, R=R, alpha=0.7, act=act, compute=BF16, drop=(0.1, 99) if drop else None,
+                     colsum=csum, colsum_scale=0.5)
+            return (o, csum)
+        (o0, c0), k0, (o1, c1), k1 = both(f)
+        assert "pn_kernel" in k1 and "pn_kernel" not in k0, (k0, k1)
+        assert torch.equal(o0, o1), (M, K, rel(o1, o0))
+        if cs:
+            assert rel(c1, c0) < 1e-5
+        if not drop:
+            ref = x.float() @ W.float().t() + b
+            ref = (torch.relu(ref) if act == ACT_RELU else ref) * 0.7 + (R if res else 0)
+            assert rel(o1, ref) < 1e-2
+    for (B, T, cin, taps) in [(3, 200, 128, 3), (7, 333, 256, 5), (5, 7, 128, 3)]:
+        M = B * T
+        h = rn(M, cin).bfloat16()
+        W2 = rn(N, taps, cin, sc=0.03).bfloat16()
+        b2, xres = rn(N), rn(M, N)
+
+        def f():
+            o = torch.empty(M, N, device=DEV)
+            ops.conv_fwd(h, W2, o, T, (taps - 1) // 2, bias=b2, R=xres, alpha=0.5, compute=BF16, drop=(0.1, 4242))
+            o2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            ops.conv_fwd(h, W2, o2, T, (taps - 1) // 2, compute=BF16)
+            return (o, o2)
+        (o0, p0), k0, (o1, p1), k1 = both(f)
+        assert "pn_kernel<true>" in k1 and "pn_kernel" not in k0, (k0, k1)
+        assert torch.equal(o0, o1) and torch.equal(p0, p1)
+        ref = torch.nn.functional.conv1d(h.float().view(B, T, cin).transpose(1, 2), W2.float().permute(0, 2, 1), padding=(taps - 1) // 2)
+        assert rel(p1, ref.transpose(1, 2).reshape(M, N)) < 1e-2
+    # problems the kernel must leave alone: another width, K not a multiple of 128, a ReLU' mask tensor, split K
+    old = lib.a3t_gemm_pn_mode(1)
+    try:
+        assert not ops.gemm_pn_supported(35840, 512, 2048) and not ops.gemm_pn_supported(35840, 384, 192)
+        assert ops.gemm_pn_supported(35840, 384, 4608, 3, ops.G8_BIAS_ACT | ops.G8_DROP | ops.G8_F32_OR_RES | ops.G8_COLSUM)
+        assert not ops.gemm_pn_supported(35840, 384, 4608, 3, ops.G8_KEEP_IN)
+    finally:
+        lib.a3t_gemm_pn_mode(old)
+
+
+def test_panel_gemm_inside_the_benchmark_step():
+    """BASELINE configs[1] at full size (B=32, T=1120 -> 35840 tokens = 224 panels): the library's cost model sends the second FFN
+    conv, the data gradient of the first (transposed w_1 shadow), linear_out / pointwise_conv2 and the Linear data gradients
+    (transposed shadows) to the panel kernel; the same step with all of that switched off gives the same loss and gradients."""
+    import os
+    from a3t_amd import _lib, ops
+    from a3t_amd.collate import synthetic_batch
+    from a3t_amd.config import config_c2
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    lib = _lib.load()
+    c = config_c2()
+    store = ParamStore(c, DEV)
+    xavier_init_(store, seed=0, bn_gamma=1.0)
+    batch = synthetic_batch(c, 32, 1000, 120, seed=4, device=DEV)
+    M = 32 * 1120
+    e_on = MLMEngine(c, store, compute="bf16", training=True, dropout=True)
+    ops.PROFILE = []
+    try:
+        l_on = float(e_on.forward(batch)["loss"])
+        store.zero_grad()
+        e_on.backward()
+        torch.cuda.synchronize()
+        kernels = [r[0] for r in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    n_pn = sum("pn_kernel" in k for k in kernels)
+    # per block: 2 FFN x (conv2 forward + conv1 data gradient) + linear_out, pw2 forward + 4 Linear data gradients = 10
+    assert n_pn >= 10 * (c.enc_blocks + c.dec_blocks), (n_pn, sorted(set(kernels)))
+    assert e_on._ffn_plan(M)[1] and e_on._lin_plans, (e_on._ffn_plan(M), e_on._lin_plans)
+    g_on = store.grad.clone()
+    old = lib.a3t_gemm_pn_mode(0)
+    os.environ["A3T_LIN_DGRAD_T"] = "0"
+    try:
+        e_off = MLMEngine(c, store, compute="bf16", training=True, dropout=True)
+        e_off.step_seed = e_on.step_seed - 1
+        l_off = float(e_off.forward(batch)["loss"])
+        store.zero_grad()
+        e_off.backward()
+        torch.cuda.synchronize()
+    finally:
+        lib.a3t_gemm_pn_mode(old)
+        del os.environ["A3T_LIN_DGRAD_T"]
+    assert not e_off._ffn_plan(M)[1] and not any(e_off._lin_plans.values())
+    rel = float((store.grad - g_on).norm() / g_on.norm())
+    print(f"[configs[1] full size] panel GEMM path vs 128x128 path: loss {l_on:.6f} / {l_off:.6f}, gradient rel. diff {rel:.2e}")
+    assert abs(l_off - l_on) <= 1e-6 * abs(l_on), (l_off, l_on)
+    assert rel < 1e-5, rel

@@ -161,6 +161,12 @@ def test_gemm_register_budget():
     for name, r in rows.items():
         assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs"] <= 256, (name, r["VGPRs"])
         assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0, (name, r)
+    # the 384-column panel kernel: same discipline (one 512-thread workgroup per CU, counted vmcnt waits in the K loop)
+    rows = json.load(open(path.replace("gemm_bf16_8p.resources.json", "gemm_bf16_pn.resources.json")))
+    assert len(rows) >= 2
+    for name, r in rows.items():
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs"] <= 256, (name, r["VGPRs"])
+        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0, (name, r)
 
 
 def test_sedit_driver_span_arithmetic_matches_reference():

@@ -24,5 +24,5 @@ for name, fl, e0, e1, shape in prof:
     a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += fl
 tot = sum(a[1] for a in agg.values())
 print(f"total gemm time {tot*1e3:.2f} ms, {sum(a[2] for a in agg.values())/tot/1e12:.1f} TF avg")
-for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"L{k[0]} MNKb,taps,sk={k[1]}: n={a[0]:3d} t={a[1]*1e3:7.2f} ms ({a[1]/tot*100:4.1f}%) avg {a[1]/a[0]*1e6:7.1f} us  {a[2]/a[1]/1e12:6.1f} TF")
