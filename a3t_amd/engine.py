@@ -182,25 +182,29 @@ class MLMEngine:
         ops.cast_bf16_conv_t(self.store.flat, flat, src, dst, *shape)
 
     def _ffn_plan(self, M):
-        """Which FFN GEMMs of an M-token batch go to the persistent 8-phase kernel (the library's cost model decides,
-        a3t_gemm_8p_supported): (keep, dgrad1) = the keep-bit protocol (forward conv 1 writes one bit per hidden activation,
+        """Which FFN GEMMs of an M-token batch go to the persistent 8-phase / panel kernels (the library's cost models decide,
+        a3t_gemm_8p_supported / a3t_gemm_pn_supported): (keep, dgrad1, dgrad2) = the keep-bit protocol (forward conv 1 writes one bit per hidden activation,
         the data gradient of conv 2 reads it through the transposed w_2), and the data gradient of conv 1 through the
         transposed w_1.  A3T_FFN_8P=0 turns both off."""
         if M not in self._ffn_plans:
             c = self.c
-            keep = d1 = False
+            keep = d1 = d2 = False
             if self.bf16 and self.dev.type == "cuda" and os.environ.get("A3T_FFN_8P", "1") != "0":
                 k = c.ff_kernel
                 drop = ops.G8_DROP if (self.dropping and c.dropout_rate > 0) else 0
                 keep = ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_BIAS_ACT | drop | ops.G8_KEEP_OUT) and \
                     ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_KEEP_IN | ops.G8_COLSUM)
                 d1 = ops.gemm_8p_supported(M, c.adim, k * c.ff, k, 0) or ops.gemm_pn_supported(M, c.adim, k * c.ff, k, 0)
-                if keep and "w2" not in self._wt:
+                # (no keep bits: the panel GEMM runs the data gradient of conv 2 on the transposed w_2 with the saved hidden
+                #  activation as its ReLU' mask, A3T_FFN_D2T=0 turns that off)
+                d2 = (not keep) and os.environ.get("A3T_FFN_D2T", "1") != "0" and \
+                    ops.gemm_pn_supported(M, c.ff, k * c.adim, k, ops.G8_SMASK | ops.G8_COLSUM)
+                if (keep or d2) and "w2" not in self._wt:
                     self._setup_wt("w2", (c.adim, k, c.ff))
                 if d1 and "w1" not in self._wt:
                     self._setup_wt("w1", (c.ff, k, c.adim))
-                keep, d1 = keep and "w2" in self._wt, d1 and "w1" in self._wt
-            self._ffn_plans[M] = (keep, d1)
+                keep, d1, d2 = keep and "w2" in self._wt, d1 and "w1" in self._wt, d2 and "w2" in self._wt
+            self._ffn_plans[M] = (keep, d1, d2)
         return self._ffn_plans[M]
 
     def _lin_dgrad(self, dy, name, dx):
@@ -379,6 +383,9 @@ class MLMEngine:
         if keep is not None:     # k-contiguous conv of ga with the transposed weights, masked by the forward's keep bits
             ops.conv_fwd(ga, self._wt["w2"][2][pre + ".w2"], dh, T, c.ff_kernel - 1 - pad, alpha=a_dh, compute=self.cmp,
                          keep_in=keep, colsum=gr[pre + ".b1"])
+        elif self._ffn_plan(M)[2]:
+            ops.conv_fwd(ga, self._wt["w2"][2][pre + ".w2"], dh, T, c.ff_kernel - 1 - pad, alpha=a_dh, compute=self.cmp,
+                         S=h, colsum=gr[pre + ".b1"])
         else:
             ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=a_dh,
                               compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)

@@ -108,15 +108,15 @@ def linear_bwd_weight(dy, x, dW, alpha=1.0, compute=F32):
 
 # ---- Conv1d over time as implicit-im2col GEMM; weights kept as Wk[N][taps][Cin] --------------
 def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None,
-             keep_out=None, keep_in=None, colsum=None):
+             keep_out=None, keep_in=None, colsum=None, S=None):
     M, Cin = x.shape
     N, taps, _ = Wk.shape
     gemm(x, Wk, out, M, N, taps * Cin, Cin, 1, taps * Cin, 1, N, b_ts=Cin, bias=bias, R=R, taps=taps, pad=pad,
          dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute, drop=drop, keep_out=keep_out, keep_in=keep_in,
-         colsum=colsum)
+         colsum=colsum, S=S)
 
 
-G8_BIAS_ACT, G8_DROP, G8_KEEP_OUT, G8_KEEP_IN, G8_F32_OR_RES, G8_COLSUM = 1, 2, 4, 8, 16, 32
+G8_BIAS_ACT, G8_DROP, G8_KEEP_OUT, G8_KEEP_IN, G8_F32_OR_RES, G8_COLSUM, G8_SMASK = 1, 2, 4, 8, 16, 32, 64
 
 
 def gemm_8p_supported(M, N, K, taps=1, flags=0):

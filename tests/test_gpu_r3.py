@@ -215,12 +215,33 @@ def test_panel_gemm_kernel_against_the_128_kernel_and_torch():
         assert torch.equal(o0, o1) and torch.equal(p0, p1)
         ref = torch.nn.functional.conv1d(h.float().view(B, T, cin).transpose(1, 2), W2.float().permute(0, 2, 1), padding=(taps - 1) // 2)
         assert rel(p1, ref.transpose(1, 2).reshape(M, N)) < 1e-2
-    # problems the kernel must leave alone: another width, K not a multiple of 128, a ReLU' mask tensor, split K
-    old = lib.a3t_gemm_pn_mode(1)
+    # wider outputs walk 384-column chunks (N = 768 / 1152 / 1536, a ragged N, an odd number of K-tiles); the ReLU' mask tensor S
+    for (M, Nw, K, taps, smask) in [(2000, 768, 384, 1, False), (3000, 1152, 192, 1, False), (1800, 1536, 384, 3, False),
+                                    (1800, 1536, 384, 3, True), (1234, 1000, 256, 1, True), (41000, 768, 128, 1, False)]:
+        cin = K // taps
+        T = 100 if taps > 1 else 0
+        a, W, b = rn(M, cin).bfloat16(), rn(Nw, taps, cin, sc=0.05).bfloat16(), rn(Nw)
+        S = rn(M, Nw).bfloat16() if smask else None
+
+        def f():
+            o = torch.empty(M, Nw, device=DEV, dtype=torch.bfloat16)
+            csum = torch.zeros(Nw, device=DEV)
+            if taps > 1:
+                ops.conv_fwd(a, W, o, T, 1, bias=None if smask else b, act=ACT_NONE if smask else ACT_RELU, alpha=0.8, compute=BF16,
+                             drop=None if smask else (0.1, 5), S=S, colsum=csum)
+            else:
+                ops.gemm(a, W, o, M, Nw, K, K, 1, K, 1, Nw, bias=b, S=S, alpha=0.8, compute=BF16, colsum=csum)
+            return (o, csum)
+        (o0, c0), k0, (o1, c1), k1 = both(f)
+        assert "pn_kernel" in k1 and "pn_kernel" not in k0, (k0, k1)
+        assert torch.equal(o0, o1) and rel(c1, c0) < 1e-5, (M, Nw, K, rel(o1, o0), rel(c1, c0))
+    # what the cost model (the default mode) takes and what the kernel must leave alone
+    old = lib.a3t_gemm_pn_mode(2)
     try:
-        assert not ops.gemm_pn_supported(35840, 512, 2048) and not ops.gemm_pn_supported(35840, 384, 192)
-        assert ops.gemm_pn_supported(35840, 384, 4608, 3, ops.G8_BIAS_ACT | ops.G8_DROP | ops.G8_F32_OR_RES | ops.G8_COLSUM)
-        assert not ops.gemm_pn_supported(35840, 384, 4608, 3, ops.G8_KEEP_IN)
+        flags = ops.G8_BIAS_ACT | ops.G8_DROP | ops.G8_F32_OR_RES | ops.G8_COLSUM
+        assert ops.gemm_pn_supported(35840, 384, 4608, 3, flags) and ops.gemm_pn_supported(35840, 1536, 1152, 3, ops.G8_SMASK | ops.G8_COLSUM)
+        assert not ops.gemm_pn_supported(35840, 512, 2048) and not ops.gemm_pn_supported(1000, 384, 4608, 3, flags)
+        assert not ops.gemm_pn_supported(35840, 384, 4608, 3, ops.G8_KEEP_IN) and not ops.gemm_pn_supported(35840, 384, 100)
     finally:
         lib.a3t_gemm_pn_mode(old)
 
@@ -255,7 +276,7 @@ def test_panel_gemm_inside_the_benchmark_step():
     n_pn = sum("pn_kernel" in k for k in kernels)
     # per block: 2 FFN x (conv2 forward + conv1 data gradient) + linear_out, pw2 forward + 4 Linear data gradients = 10
     assert n_pn >= 10 * (c.enc_blocks + c.dec_blocks), (n_pn, sorted(set(kernels)))
-    assert e_on._ffn_plan(M)[1] and e_on._lin_plans, (e_on._ffn_plan(M), e_on._lin_plans)
+    assert e_on._ffn_plan(M)[1] and e_on._ffn_plan(M)[2] and e_on._lin_plans, (e_on._ffn_plan(M), e_on._lin_plans)
     g_on = store.grad.clone()
     old = lib.a3t_gemm_pn_mode(0)
     os.environ["A3T_LIN_DGRAD_T"] = "0"
@@ -269,7 +290,7 @@ def test_panel_gemm_inside_the_benchmark_step():
     finally:
         lib.a3t_gemm_pn_mode(old)
         del os.environ["A3T_LIN_DGRAD_T"]
-    assert not e_off._ffn_plan(M)[1] and not any(e_off._lin_plans.values())
+    assert not any(e_off._ffn_plan(M)) and not any(e_off._lin_plans.values())
     rel = float((store.grad - g_on).norm() / g_on.norm())
     print(f"[configs[1] full size] panel GEMM path vs 128x128 path: loss {l_on:.6f} / {l_off:.6f}, gradient rel. diff {rel:.2e}")
     assert abs(l_off - l_on) <= 1e-6 * abs(l_on), (l_off, l_on)

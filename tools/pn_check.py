@@ -99,6 +99,30 @@ for (B, T, cin, taps) in [(3, 200, 128, 3), (7, 333, 256, 5)] + ([(32, 1120, 153
     bad += not ok
     print(f"   plain conv: vs 128^2 {rel(o1, o0):.1e} vs torch {et:.1e} {'ok' if ok else 'FAIL'}")
 
+# ---- wider outputs: column chunks of 384 (N = 768 / 1152 / 1536, and a ragged N), the ReLU' mask tensor S + column sums
+for (M, Nw, K, taps, smask) in [(2000, 768, 384, 1, False), (3000, 1152, 384, 1, False), (1800, 1536, 384, 3, False), (1800, 1536, 384, 3, True),
+                                (1234, 1000, 256, 1, True), (41000, 768, 128, 1, False)]:
+    cin = K // taps
+    T = 100 if taps > 1 else 0
+    a = rn(M, cin).bfloat16()
+    W = rn(Nw, taps, cin, sc=0.05).bfloat16()
+    b = rn(Nw)
+    S = rn(M, Nw).bfloat16() if smask else None
+
+    def f():
+        o = torch.empty(M, Nw, device=DEV, dtype=torch.bfloat16)
+        csum = torch.zeros(Nw, device=DEV)
+        if taps > 1:
+            ops.conv_fwd(a, W, o, T, 1, bias=None if smask else b, act=ACT_NONE if smask else ACT_RELU, alpha=0.8, compute=BF16,
+                         drop=None if smask else (0.1, 5), S=S, colsum=csum)
+        else:
+            ops.gemm(a, W, o, M, Nw, K, K, 1, K, 1, Nw, bias=b, S=S, alpha=0.8, compute=BF16, colsum=csum)
+        return (o, csum)
+    (o0, c0), k0, (o1, c1), k1 = both(f)
+    ok = "pn" in k1 and "pn" not in k0 and bool(torch.equal(o0, o1)) and rel(c1, c0) < 1e-4
+    bad += not ok
+    print(f"wide {M}x{Nw}x{K} taps={taps} S={smask}: {k1} bit-equal {bool(torch.equal(o0, o1))} colsum {rel(c1, c0):.1e} {'ok' if ok else 'FAIL'}")
+
 print("FAILED" if bad else "all ok")
 
 # ---- timing: the N = 384 GEMMs of configs[1] (B=32, T=1120)
@@ -106,6 +130,35 @@ if len(sys.argv) < 2:
     M, T = 35840, 1120
     xres = rn(M, N)
     b = rn(N)
+    h = rn(M, 1536).bfloat16()
+    for name, Nw, K, taps, kw in [("ffn conv1 fwd (bias+relu+drop)", 1536, 1152, 3, dict(relu=True, drop=True)),
+                                  ("ffn conv2 dgrad (S mask + colsum)", 1536, 1152, 3, dict(S=True, cs=True)),
+                                  ("qkv fwd (bias)", 1152, 384, 1, dict(bias=True)),
+                                  ("pw1 fwd (bias)", 768, 384, 1, dict(bias=True))]:
+        cin = K // taps
+        a = rn(M, cin).bfloat16()
+        W = rn(Nw, taps, cin, sc=0.03).bfloat16()
+        bw = rn(Nw)
+        o = torch.empty(M, Nw, device=DEV, dtype=torch.bfloat16)
+        csum = torch.zeros(Nw, device=DEV)
+
+        def run():
+            ekw = dict(bias=bw if (kw.get("relu") or kw.get("bias")) else None, act=ACT_RELU if kw.get("relu") else ACT_NONE, compute=BF16,
+                       drop=(0.1, 7) if kw.get("drop") else None)
+            if taps > 1:
+                ops.conv_fwd(a, W, o, T, 1, S=h if kw.get("S") else None, colsum=csum if kw.get("cs") else None, **ekw)
+            else:
+                ops.linear_fwd(a, W.view(Nw, cin), o, **ekw)
+        old8 = lib.a3t_gemm_8p_mode(0)
+        ts = []
+        for mode in (0, 1, 2):
+            lib.a3t_gemm_pn_mode(mode)
+            ts.append(timeit(run))
+            kn = lib.a3t_gemm_last_kernel().decode()
+        lib.a3t_gemm_8p_mode(old8)
+        fl = 2.0 * M * Nw * K
+        print(f"{name:42s} N={Nw:4d} K={K:5d}: 128^2 {ts[0]:6.1f} us ({fl/ts[0]/1e6:5.0f} TF)  panel {ts[1]:6.1f} us ({fl/ts[1]/1e6:5.0f} TF)  "
+              f"default {ts[2]:6.1f} us [{kn}]")
     for name, K, taps, kw in [("ffn conv2 fwd (bias+drop+R, fp32 out)", 4608, 3, dict(f32=True, R=True, drop=True)),
                               ("ffn conv1 dgrad (bf16 out)", 4608, 3, dict()),
                               ("linear_out / pw2 fwd (bias+drop+R, fp32)", 384, 1, dict(f32=True, R=True, drop=True)),
