@@ -29,6 +29,11 @@
 //   * a workgroup owns a panel and walks its 384-column chunks (N = 1536: four; the panel's rows stay in L2); the epilogue is a
 //     plain tail (bias -> relu -> ReLU' mask S -> dropout -> alpha -> fp32 residual -> store bf16 | fp32, column sums through
 //     LDS) that runs while the next tile's first K-tiles are already in flight.
+// Tried on top of this kernel and taken out again (round 3, tools/pn_check.py of those commits):
+//   * batched operands for the attention scores (64 x 1120 x 1120 x 192 = 21 tiles of 3 K-tiles per batch element): 80 us against
+//     73 us on the 128x128 kernel -- ~9 us of fill and epilogue per tile against 4.7 us of K loop;
+//   * a 320 x 192 geometry (4 x 2 waves, same wave tile) for probabilities x V / dS x K / dBD x P with a transposed second
+//     operand: 54 us against 55 us -- those products read a T x T matrix (160 MB per launch) and sit on the HBM roof already.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -101,12 +106,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
 
     // ---- epilogue of tile (panel `tile`, column chunk `chunk`): lane (fr, g) owns rows wr*80 + i*16 + fr (i = 0..4) x columns
     // chunk*384 + wc*96 + jl*32 + g*8 .. +7 (jl = 0..2); leaves the accumulators cleared
-    auto epi = [&](const int unit, const int chunk) __attribute__((always_inline)) {
+    auto epi = [&](const int tile, const int chunk) __attribute__((always_inline)) {
         EPI_ARGS(q);
-        const int panels = q->cgroup;          // panels per batch element (host)
-        const int z = unit / panels, tile = unit - z * panels;
-        const int z0 = z / q->batch_inner, z1 = z - z0 * q->batch_inner;
-        const int64_t zoff = z0 * q->c_bs0 + z1 * q->c_bs1;
         int lane = lane_, w = w_;
         asm volatile("" : "+v"(lane), "+s"(w));
         const int fr = lane & 15, g = lane >> 4, wr = w >> 2, wc = w & 3;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                const int64_t idx = zoff + (int64_t)m * q->c_rs + ncol;
+                const int64_t idx = (int64_t)m * q->c_rs + ncol;
                 if (q->S) {        // ReLU' mask: keep where the saved activation is positive
                     float sv[8];
                     if (!ok) {
@@ -195,10 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
         }
         if (q->colsum) {
             __syncthreads();
-            // (batched problems: the head's slice of the accumulator; slot 0 of a spread accumulator -- one atomic per
-            //  column and tile needs no spreading, the fold kernel sums all slots)
-            if (tid < PN_COLS && chunk * PN_COLS + tid < q->N)
-                atomicAdd(q->colsum + z1 * q->colsum_bs1 + chunk * PN_COLS + tid, q->colsum_scale * cs_l[tid]);
+            if (tid < PN_COLS && chunk * PN_COLS + tid < q->N) atomicAdd(q->colsum + chunk * PN_COLS + tid, q->colsum_scale * cs_l[tid]);
         }
     };
 
@@ -206,20 +204,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
     // of a tile runs AFTER the first K-tiles of the next tile have been requested: it hides their flight.
     bool pend = false;
     int e_tile = 0, e_chunk = 0;
-    for (int unit = blockIdx.x; unit * p.tiles_n < p.ntiles; unit += gridDim.x) {
+    for (int tile = blockIdx.x; tile * p.tiles_n < p.ntiles; tile += gridDim.x)
         for (int chunk = 0; chunk < p.tiles_n; ++chunk) {
-            // (per-tile scalars come from the kernarg segment again: kept across the K loop they would sit in spilled SGPRs)
-            EPI_ARGS(qt);
-            const int z = unit / qt->cgroup, tile = unit - z * qt->cgroup;      // batch element, panel inside it
-            const int z0 = z / qt->batch_inner, z1 = z - z0 * qt->batch_inner;
-            const unsigned a_zb = (unsigned)(z0 * qt->a_bs0 + z1 * qt->a_bs1) * 2u, b_zb = (unsigned)(z0 * qt->b_bs0 + z1 * qt->b_bs1) * 2u;
             unsigned voffB[6];
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const int R = (q % 3) * 64 + w * 8 + srow, hb = q / 3;
                 const int wcr = R / 48, r2 = R % 48, jl = r2 >> 4, rho = r2 & 15;
                 const int n = chunk * PN_COLS + wcr * 96 + jl * 32 + (rho >> 2) * 8 + hb * 4 + (rho & 3);
-                voffB[q] = n < qt->N ? b_zb + (unsigned)n * b_rsb + schunk16 : OOB;
+                voffB[q] = n < p.N ? (unsigned)n * b_rsb + schunk16 : OOB;
             }
             // per-lane row state of this panel: byte offset of the lane's three A rows and their positions inside the utterance
             unsigned voffA[3];
@@ -227,8 +220,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const int m = tile * PN_ROWS + (q * 8 + (q == 2 ? (w & 3) : w)) * 8 + srow;
-                voffA[q] = a_zb + (unsigned)m * a_rsb + schunk16;
-                tposA[q] = (m < qt->M) ? (CONV ? m % qt->Tseq : 0) : -(1 << 24);
+                voffA[q] = (unsigned)m * a_rsb + schunk16;
+                tposA[q] = (m < p.M) ? (CONV ? m % p.Tseq : 0) : -(1 << 24);
             }
             int a_kt = 0, a_tap = 0, a_c0 = 0;       // cursor of the A loader (uniform)
             auto issueA = [&](const int buf) __attribute__((always_inline)) {
@@ -327,13 +320,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
             };
             for (int kt = 0; kt < nk; kt += 2) {
                 ktile(kt, 0);
-                if (kt + 1 < nk) ktile(kt + 1, 1);      // (odd count: the requests already under way are zero fills, drained below)
+                ktile(kt + 1, 1);
             }
             if (wr == 0) BAR();    // both groups level again: every fragment read of this tile has retired
             WAIT_VM(0);            // (the trailing zero-fill DMA must not outlive the tile)
-            e_tile = unit, e_chunk = chunk, pend = true;
+            e_tile = tile, e_chunk = chunk, pend = true;
         }
-    }
     if (pend) epi(e_tile, e_chunk);
 }
 
@@ -363,19 +355,9 @@ extern "C" int a3t_gemm_pn_mode(int mode) {
     return old;
 }
 
-// bytes the buffer descriptors of A and B must span, and the largest output index + 1
-static void pn_extents(const GP& p, int batch, int64_t& a_bytes, int64_t& b_bytes, int64_t& c_elems) {
-    const int bi = p.batch_inner > 0 ? p.batch_inner : 1;
-    const int64_t n0 = batch / bi - 1, n1 = bi - 1;
-    a_bytes = (n0 * p.a_bs0 + n1 * p.a_bs1 + (int64_t)p.M * p.a_rs) * 2;
-    b_bytes = (n0 * p.b_bs0 + n1 * p.b_bs1 + (int64_t)p.N * p.b_rs) * 2;
-    c_elems = n0 * p.c_bs0 + n1 * p.c_bs1 + (int64_t)p.M * p.c_rs;
-}
-
 static bool pn_applicable(const GP& p, int batch, int ly) {
     const int mode = pn_mode();
-    if (mode == 0 || ly != 0 || batch < 1 || p.splitk != 1 || p.accumulate != A3T_ACC_STORE) return false;
-    if (batch > 1 && (p.taps > 1 || p.batch_inner < 1 || batch % p.batch_inner)) return false;
+    if (mode == 0 || ly != 0 || batch != 1 || p.splitk != 1 || p.accumulate != A3T_ACC_STORE) return false;
     if (p.N % 8 != 0 || p.K % 64 != 0 || p.c_rs % 8 != 0 || p.a_cs != 1 || p.b_cs != 1) return false;
     if (p.kshift_mode || p.keep_in || p.keep_out) return false;
     if (p.S && ((uintptr_t)p.S & 15)) return false;
@@ -385,16 +367,9 @@ static bool pn_applicable(const GP& p, int batch, int ly) {
     if (p.taps > 1 && (p.Kc % 64 != 0 || p.b_ts != p.Kc || p.Tseq <= 0)) return false;
     if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return false;
     if (p.bias && ((uintptr_t)p.bias & 15)) return false;
-    int64_t a_bytes, b_bytes, c_elems;
-    pn_extents(p, batch, a_bytes, b_bytes, c_elems);
-    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || c_elems >= (1ll << 32)) return false;
-    if (batch > 1 && ((p.a_bs0 | p.a_bs1 | p.b_bs0 | p.b_bs1 | p.c_bs0 | p.c_bs1) % 8 != 0 || p.a_bs0 < 0 || p.a_bs1 < 0 || p.b_bs0 < 0 ||
-                      p.b_bs1 < 0)) return false;
-    if (mode == 3 && (p.N != PN_COLS || batch > 1)) return false;
-    // Batched products (the attention scores: 64 x 1120 x 1120 x 192 = 7 panels x 3 chunks per batch element with 3 K-tiles each)
-    // are legal but never chosen: 80 us against 73 us on the 128x128 kernel (tools/pn_check.py) -- a tile's ~9 us of fill and
-    // epilogue against 4.7 us of K loop.
-    if (mode >= 2 && batch > 1) return false;
+    const int64_t a_bytes = ((int64_t)p.M * p.a_rs) * 2, b_bytes = ((int64_t)p.N * p.b_rs) * 2;
+    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || (int64_t)p.M * p.c_rs >= (1ll << 32)) return false;
+    if (mode == 3 && p.N != PN_COLS) return false;
     if (mode >= 2) {
         // Cost model fitted on MI355X (tools/probes/gemm_pn.hip, tools/pn_check.py): a tile (panel x 384-column chunk) costs ~1.55 us per
         // 64-wide K-tile plus ~8 us of pipeline fill and epilogue (dropout hashes and an fp32 residual add ~3 more; the later
@@ -449,14 +424,10 @@ int a3t_gemm_bf16_pn(const GP& p, int batch, int ly, hipStream_t stream) {
     GP pv = p;
     const int panels = (int)((p.M + PN_ROWS - 1) / PN_ROWS);
     pv.tiles_n = (p.N + PN_COLS - 1) / PN_COLS;
-    pv.cgroup = panels;                          // panels per batch element
-    pv.ntiles = batch * panels * pv.tiles_n;
-    if (pv.batch_inner < 1) pv.batch_inner = 1;
-    int64_t a_bytes, b_bytes, c_elems;
-    pn_extents(p, batch, a_bytes, b_bytes, c_elems);
-    pv.a_bytes = (unsigned)a_bytes, pv.b_bytes = (unsigned)b_bytes;
-    const int units = batch * panels;
-    const int grid = units < pn_cus() ? units : pn_cus();
+    pv.ntiles = panels * pv.tiles_n;
+    pv.a_bytes = (unsigned)(((int64_t)p.M * p.a_rs) * 2);
+    pv.b_bytes = (unsigned)(((int64_t)p.N * p.b_rs) * 2);
+    const int grid = panels < pn_cus() ? panels : pn_cus();
     const bool conv = p.taps > 1;
     if (conv)
         launch_pn<true>(pv, grid, stream);

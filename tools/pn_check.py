@@ -123,43 +123,6 @@ for (M, Nw, K, taps, smask) in [(2000, 768, 384, 1, False), (3000, 1152, 384, 1,
     bad += not ok
     print(f"wide {M}x{Nw}x{K} taps={taps} S={smask}: {k1} bit-equal {bool(torch.equal(o0, o1))} colsum {rel(c1, c0):.1e} {'ok' if ok else 'FAIL'}")
 
-# ---- batched products (attention scores): per-batch operand offsets, M / N tails inside a batch element, 3 K-tiles
-for (B, H, T, dk) in [(2, 2, 200, 64), (3, 2, 336, 192), (32, 2, 1120, 192)][:2 if len(sys.argv) > 1 else 3]:
-    d = H * dk
-    M = B * T
-    qu, qkv = rn(M, d).bfloat16(), rn(M, 3 * d).bfloat16()
-    P = rn(T, d).bfloat16()
-    kk = qkv.view(-1)[d:]
-
-    def f():
-        ac = torch.empty(B, H, T, T, device=DEV, dtype=torch.bfloat16)
-        bd = torch.empty(B, H, T, T, device=DEV, dtype=torch.bfloat16)
-        ops.gemm(qu, kk, ac, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(T * 3 * d, dk),
-                 c_bs=(H * T * T, T * T), compute=BF16)
-        ops.gemm(qu, P, bd, T, T, dk, d, 1, d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(0, dk),
-                 c_bs=(H * T * T, T * T), compute=BF16)
-        return (ac, bd)
-    (a0, b0), k0, (a1, b1), k1 = both(f)
-    ref = torch.einsum("bihd,bjhd->bhij", qu.float().view(B, T, H, dk), qkv.float().view(B, T, 3, H, dk)[:, :, 1])
-    ok = "pn" in k1 and "pn" not in k0 and bool(torch.equal(a0, a1)) and bool(torch.equal(b0, b1)) and rel(a1, ref) < 1e-2
-    bad += not ok
-    print(f"batched scores B={B} H={H} T={T} dk={dk}: {k1} bit-equal {bool(torch.equal(a0, a1))} {bool(torch.equal(b0, b1))} vs torch {rel(a1, ref):.1e} "
-          f"{'ok' if ok else 'FAIL'}")
-    if T == 1120:
-        def run():
-            ops.gemm(qu, kk, a1, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(T * 3 * d, dk),
-                     c_bs=(H * T * T, T * T), compute=BF16)
-        old8 = lib.a3t_gemm_8p_mode(0)
-        ts = []
-        for mode in (0, 1, 2):
-            lib.a3t_gemm_pn_mode(mode)
-            ts.append(timeit(run))
-            kn = lib.a3t_gemm_last_kernel().decode()
-        lib.a3t_gemm_pn_mode(2)
-        lib.a3t_gemm_8p_mode(old8)
-        fl = 2.0 * T * T * dk * B * H
-        print(f"scores 64 x 1120 x 1120 x 192: 128^2 {ts[0]:6.1f} us ({fl/ts[0]/1e6:5.0f} TF)  panel {ts[1]:6.1f} us ({fl/ts[1]/1e6:5.0f} TF)  default {ts[2]:6.1f} us [{kn}]")
-
 print("FAILED" if bad else "all ok")
 
 # ---- timing: the N = 384 GEMMs of configs[1] (B=32, T=1120)
