@@ -198,10 +198,22 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
     const bool a_fast = (CONV == 1) ? A_KC : (A_KC && TAPS > 1 && (p.Kc % BK == 0));
     const bool b_fast = (CONV == 1) ? !B_KC : (!B_KC && !WG && TAPS > 1 && (p.Kc % BK == 0));
     const bool ks_fast = p.Tseq >= BK;
+    // CONV == 1 walks the K-tiles TAPS INNERMOST: K-tile kt = (channel block kt / TAPS, tap kt % TAPS).  The taps of one channel
+    // block read the same rows shifted by a token -- L2 / L1 hits; tap-major order fetched the whole operand from HBM once per
+    // tap (profiles/r03_hbm_traffic_per_kernel.json before the change: 318 MB per launch of the first FFN conv against 140 MB
+    // algorithmic).  The weights ([n][tap][c]) are addressed to match; the sum is the same set of products in another order.
+    // (CONV == 2 takes the same order whenever its operands run on the uniform (tap, channel) tracking: every k-contiguous conv
+    //  with whole channel blocks sums in ONE order on all three kernel families -- bit-identical results, tests/test_gpu_*.py)
+    const bool TAP_INNER = (CONV == 1) || (CONV == 2 && !WG && TAPS > 1 && (a_fast || b_fast));
     int u_tap = 0, u_cc = 0;
     if (a_fast || b_fast) {
-        u_tap = (kt0 * BK) / p.Kc;
-        u_cc = kt0 * BK - u_tap * p.Kc;
+        if (TAP_INNER) {
+            u_tap = kt0 % TAPS;
+            u_cc = (kt0 / TAPS) * BK;
+        } else {
+            u_tap = (kt0 * BK) / p.Kc;
+            u_cc = kt0 * BK - u_tap * p.Kc;
+        }
     }
     auto issue = [&](int k0, int stage) {   // NOTE: called for consecutive tiles only (running state above)
         unsigned char* sA = smem + stage * STAGE_BYTES;
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
             const bool split = (CONV == 2) && (TAPS > 1 && p.b_ts != p.Kc);   // (weights are [n][tap][c]: b_ts == Kc, no split)
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                const int kg = k0 + b_sw[q];
+                const int kg = (TAP_INNER && TAPS > 1 ? u_tap * p.Kc + u_cc : k0) + b_sw[q];
                 int64_t koff = kg;
                 if (split) {
                     int tap = kg / p.Kc, cc = kg - tap * p.Kc;
@@ -281,8 +293,12 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
             }
         }
         if (a_fast || b_fast) {
-            u_cc += BK;
-            if (u_cc >= p.Kc) u_cc -= p.Kc, ++u_tap;
+            if (TAP_INNER) {
+                if (++u_tap == TAPS) u_tap = 0, u_cc += BK;
+            } else {
+                u_cc += BK;
+                if (u_cc >= p.Kc) u_cc -= p.Kc, ++u_tap;
+            }
         }
     };
 

@@ -138,9 +138,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
     set_tile_lanes();
     auto advance = [&]() __attribute__((always_inline)) {
         ++c_unit, ++c_kt;
-        if (CONV) {
-            c_c0 += 64;
-            if (c_c0 == p.Kc) c_c0 = 0, ++c_tap;
+        if (CONV) {       // taps innermost (the K-tiles of one channel block read the same rows shifted by a token: cache hits
+            ++c_tap;      //  instead of one HBM pass per tap; same order as the 128x128 and the panel kernels: identical sums)
+            if (c_tap == p.taps) c_tap = 0, c_c0 += 64;
         }
         if (c_kt == nk) {
             c_kt = 0, c_tap = 0, c_c0 = 0;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_kernel(GP p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_AS(dst + q * 8192), 16, ok ? vb : OOB, so, 0, 0);
             }
         } else {
-            const unsigned so = (unsigned)(h * 8) * b_rsb + (unsigned)c_kt * 128u;
+            const unsigned so = (unsigned)(h * 8) * b_rsb + (CONV ? (unsigned)(c_tap * p.Kc + c_c0) * 2u : (unsigned)c_kt * 128u);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const bool ok = live && (nB0 + h * 8 + q * 128 < p.N);

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
     const unsigned schunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
     const unsigned a_rsb = (unsigned)p.a_rs * 2u, b_rsb = (unsigned)p.b_rs * 2u;
     const int Tq = CONV ? p.Tseq : 1;
+    const unsigned tap_magic = CONV ? (1u << 20) / (unsigned)p.taps + 1u : 0u;      // kt / taps = (kt * magic) >> 20 for kt < 2^10
 
     // ---- fragment reads: row (lane&15) of a 16-row block, chunk (s*4 + (lane>>4)) ^ (row & 7)
     const int fr = lane & 15, g = lane >> 4;
@@ -236,17 +237,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_AS(dst), 16, ok ? voffA[q] + (unsigned)shift * a_rsb : OOB, so, 0, 0);
                 }
                 ++a_kt;
-                if (CONV) {
-                    a_c0 += 64;
-                    if (a_c0 == p.Kc) a_c0 = 0, ++a_tap;
+                if (CONV) {       // taps innermost: the K-tiles of one 64-channel block read the same panel rows shifted by a token --
+                    ++a_tap;      // L2 (mostly L1) hits; tap-major order fetched the panel from HBM once per tap (384 vs 160 MB per launch)
+                    if (a_tap == p.taps) a_tap = 0, a_c0 += 64;
                 }
             };
             auto issueB = [&](const int hb, const int kt, const int buf) __attribute__((always_inline)) {
                 const bool live = kt < nk;
+                // k offset of K-tile kt in the weight rows [tap][channel]: (kt % taps) * Kc + (kt / taps) * 64
+                const unsigned cb = CONV ? ((unsigned)kt * tap_magic) >> 20 : 0u;
+                const unsigned kof = CONV ? ((unsigned)kt - cb * (unsigned)p.taps) * (unsigned)p.Kc + cb * 64u : (unsigned)kt * 64u;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     unsigned char* dst = smem + buf * BUF_BYTES + A_BYTES + hb * BH_BYTES + (q * 8 + w) * 1024;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_AS(dst), 16, live ? voffB[hb * 3 + q] : OOB, (unsigned)kt * 128u, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_AS(dst), 16, live ? voffB[hb * 3 + q] : OOB, kof * 2u, 0, 0);
                 }
             };
             bf16x8 fa[5][2], fbx[3], fby[3];
