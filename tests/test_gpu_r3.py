@@ -235,6 +235,17 @@ def test_panel_gemm_kernel_against_the_128_kernel_and_torch():
         (o0, c0), k0, (o1, c1), k1 = both(f)
         assert "pn_kernel" in k1 and "pn_kernel" not in k0, (k0, k1)
         assert torch.equal(o0, o1) and rel(c1, c0) < 1e-5, (M, Nw, K, rel(o1, o0), rel(c1, c0))
+    # the randomised GEMM / conv sweep with the kernel forced on for every problem it accepts (ragged M, N < 384 and N tails,
+    # dilation, K-tile counts from 1 up): against fp32 torch math
+    import fuzz_gemm as mod
+    old8, oldp = lib.a3t_gemm_8p_mode(0), lib.a3t_gemm_pn_mode(1)
+    try:
+        fails, seen = mod.run(seed=23, n_cases=80, verbose=False)
+    finally:
+        lib.a3t_gemm_pn_mode(oldp)
+        lib.a3t_gemm_8p_mode(old8)
+    assert fails == 0
+    assert sum(v for k, v in seen.items() if k.startswith("gemm_bf16_pn_kernel")) >= 12, seen
     # what the cost model (the default mode) takes and what the kernel must leave alone
     old = lib.a3t_gemm_pn_mode(2)
     try:

@@ -29,7 +29,7 @@ F=$(find gpurun_out/r03_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1
 W=$(find gpurun_out/r03_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/traffic_summary.py $F $W gpurun_out/r03_hbm_traffic_per_kernel.json > gpurun_out/r03_traffic.log
 find gpurun_out/r03_pmc_FETCH_SIZE gpurun_out/r03_pmc_WRITE_SIZE -name "*.csv" -size +2M -delete
-# SQ counters: FFN GEMM classes of configs[1] (128x128 kernel) and configs[3] (8-phase kernel)
+# SQ counters: FFN GEMM classes of configs[1] (128x128 and panel kernels) and configs[3] (8-phase kernel)
 cd /tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
@@ -45,5 +45,7 @@ PYTHONPATH=. python tools/g8_c4_shapes.py > gpurun_out/r03_g8_c4_shapes.txt 2>&1
 PYTHONPATH=. python tools/g8_tn_check.py > gpurun_out/r03_g8_tn_check.txt 2>&1
 PYTHONPATH=. python tools/mel_floor.py > gpurun_out/r03_mel_floor.txt 2>&1
 tools/probes/gemm8p > gpurun_out/r03_gemm8p_probe.txt 2>&1
+PYTHONPATH=. python tools/pn_check.py > gpurun_out/r03_pn_check.txt 2>&1
+tools/probes/gemm_pn > gpurun_out/r03_gemm_pn_probe.txt 2>&1
 tail -1 gpurun_out/r03_bench_n1.json | cut -c1-500
 tail -12 gpurun_out/r03_evidence.log
