@@ -28,6 +28,8 @@
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+#include <type_traits>
 #include "../../include/a3t_hip.h"
 #include "dtype_io.h"
 
@@ -62,6 +64,11 @@ struct AttnArgs {
     float scale;
     unsigned int drop_thr, drop_key;
     float drop_inv;
+    int use_redo;         // forward, 16-query kernel: only recompute blocks whose attn_redo flag is set
+    // forward, training: un-normalised probabilities exp(s - m_ref) for the materialised backward (a3t_attn_fwd_train)
+    u16* probs;           // [B][H][T][T]
+    u16* pdrop;           // the same after attention dropout (NULL without dropout)
+    float* rowscale;      // [B][H][T]: 1 / row sum, the factor that normalises a row of probs / pdrop
 };
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -77,6 +84,8 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 // Out-of-range rows read this page instead of branching around the load: a conditional load costs a branch AND a
 // vmcnt(0) at the join, which serialises every prefetch behind it.
 static __device__ __attribute__((aligned(16))) unsigned int attn_zero_page[8];
+// per 128-query block of the last a3t_attn_fwd launch: 1 = the fixed-reference kernel overflowed, recompute with the rescaling one
+static __device__ int attn_redo[1 << 16];
 __device__ __forceinline__ bf16x8 ld_frag_g(const u16* p, bool ok) {
     const u16* src = ok ? p : (const u16*)attn_zero_page;
     return *(const bf16x8*)src;
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
         wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
+    if (p.use_redo && attn_redo[wi & 0xffff] == 0) return;
     const int bh = wi / NQB, qb = wi - bh * NQB;
     const int b = bh / p.H, h = bh - b * p.H;
     const int Q0 = qb * 128, q0 = Q0 + 16 * w, i = q0 + lq;
@@ -392,6 +402,789 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
         }
         if (lg == 0) p.lse[(int64_t)bh * T + i] = l > 0.f ? m_run + __logf(l) : __builtin_inff();
     }
+}
+
+// =====================================================================================================================
+// Forward, software-pipelined and group-staggered (round 4).  Same tiles, fragments and LDS images as attn_fwd16_kernel;
+// what changes is WHEN things run.  The 16-query kernel above is a dependency chain per key block (S -> LDS skew ->
+// softmax -> PV -> barrier) that all eight waves walk in lockstep: MFMA idle during the softmax, VALU idle during the
+// products, ~5500 cycles per 32-key step against 576 cycles of MFMA issue per wave.  Here a step is split in two halves,
+//     M(s): S(s) = K (q+u)^T, the two new band blocks of step s, PV(s-1)       (36 MFMAs, 36 KiB of LDS fragments)
+//     V(s): skewed band read, online softmax of step s, dropout, P(s) -> bf16   (VALU only)
+// and waves 4-7 run ONE s_barrier behind waves 0-3 (every SIMD holds one wave of each group), so that while one group
+// multiplies the other exponentiates: the matrix pipe and the VALU of a SIMD are both busy all the time.  P(s) is
+// carried to the next M half in 4 registers; the O rescale of the deferred-max rule is decided in V(s), when PV(s-1) is
+// complete and PV(s) not begun (the safe order).  DMA for step s+1 (K(s+1), V(s), Pext ring tile s+5) is issued at the
+// start of the even global half 2s by all eight waves and waited for (vmcnt(0)) at the end of the odd half 2s+1 -- a
+// full step of flight time; every buffer it overwrites was last read in half 2s-1.
+// =====================================================================================================================
+#define ATT_BAR()                               \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        asm volatile("s_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+#define ATT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// S / band MFMA with the query fragment pinned to the accumulator half of the register file (B may be an AGPR): the
+// allocator otherwise keeps 48 fragment registers in the 128 arch VGPRs and spills.  asm => no latency tracking: callers
+// pad with mfma_settle() before a VALU / DS instruction reads the accumulator.
+__device__ __forceinline__ void mfma16_qa(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma16_qv(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+#ifndef A3T_QU
+#define A3T_QU mfma16_qa
+#endif
+#ifndef A3T_QV
+#define A3T_QV mfma16_qa
+#endif
+__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 3"); }
+// O *= alpha IN PLACE in the accumulator registers, through a 16-byte LDS slot of this lane, executed only when `need`
+// (wave-uniform) is set -- the branch is INSIDE the asm on purpose.  Every formulation that lets the compiler see two
+// definitions of the accumulators (a C++ multiply on the cold path, per-element asm operands, an `if` around this asm)
+// gives O a second set of registers and moves all of it between the two sets on every step of the hot path (48
+// v_accvgpr_mov per step and 48 registers at d_k = 192).
+__device__ __forceinline__ void acc_scale4_if(f32x4& acc, float alpha, unsigned lds_addr, int need) {
+    float t0, t1, t2, t3;
+    asm volatile(
+        "s_cmp_eq_u32 %[nd], 0\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "ds_write_b128 %[ad], %[acc]\n\t"
+        "ds_read_b32 %[t0], %[ad]\n\tds_read_b32 %[t1], %[ad] offset:4\n\tds_read_b32 %[t2], %[ad] offset:8\n\tds_read_b32 %[t3], %[ad] offset:12\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f32 %[t0], %[t0], %[al]\n\tv_mul_f32 %[t1], %[t1], %[al]\n\tv_mul_f32 %[t2], %[t2], %[al]\n\tv_mul_f32 %[t3], %[t3], %[al]\n\t"
+        "ds_write_b32 %[ad], %[t0]\n\tds_write_b32 %[ad], %[t1] offset:4\n\tds_write_b32 %[ad], %[t2] offset:8\n\tds_write_b32 %[ad], %[t3] offset:12\n\t"
+        "ds_read_b128 %[acc], %[ad]\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        "1:"
+        : [acc] "+v"(acc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [ad] "v"(lds_addr), [al] "v"(alpha), [nd] "s"(__builtin_amdgcn_readfirstlane(need))
+        : "memory", "scc");
+}
+__device__ __forceinline__ int opaque_v(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+#ifdef A3T_PP_ASM_MFMA
+#define PPM(acc, a, b) mfma16_qa(acc, a, b)
+#define PP_DRAIN() mfma_drain()
+#define PP_SETTLE() mfma_settle()
+#else   // builtins: the compiler tracks MFMA latency itself and may keep fragments / accumulators in either half of the file
+#define PPM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
+#define PP_DRAIN() ((void)0)
+#define PP_SETTLE() ((void)0)
+#endif
+template <int NDB, int EXP = 0>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgs p) {
+    using D = DT16<NDB>;
+    constexpr int DK = D::DK, KS = NDB, NDT = 2 * NDB, TB = D::BYTES, CPR = D::CPR, RB = D::RB;
+    constexpr int NP = TB / 1024, NPW = (NP + 7) / 8;      // 1-KiB DMA pieces per tile / per wave
+    constexpr int NPV = (NDT + 3) / 4, NST = KS + NPV;      // M half = KS stages of S + band, NPV stages of 4 PV tiles
+    constexpr bool LOWSW = (CPR % 8) != 0;                  // swizzle < 4: chunk 4 kk + PI sits at a fixed 64 kk bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Kb = smem;                            // [2]
+    unsigned char* Vb = smem + 2 * TB;                   // [2]
+    unsigned char* Pr = smem + 4 * TB;                   // 6 ring slots of 32-row Pext tiles
+    float* sc = (float*)(smem + 10 * TB);                // [8 waves][16][SC16_LD]: ring of four 16-column band blocks
+    unsigned int* kmw = (unsigned int*)(sc + 8 * 16 * SC16_LD);   // [128] key-mask words
+    unsigned char* xrow = (unsigned char*)(kmw + 128);   // [8 waves][DK] bf16: row q0 + 16 of (q+v), lane 15 of the upper half
+
+    const int tid = threadIdx.x, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+    const int PI = ((lg & 1) << 1) | (lg >> 1);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = (EXP & 16) ? 0 : (w >> 2);           // 0: leading group, 1: one barrier behind
+    const int T = p.T, NQB = (T + 127) / 128, NS = (T + 31) / 32;
+    int wi = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
+    }
+    const int bh = wi / NQB, qb = wi - bh * NQB;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int Q0 = qb * 128, q0 = Q0 + 16 * w, i = q0 + lq;
+    const int XB = T - Q0 - 128;
+    const u16* quB = p.qu + (int64_t)b * T * p.ldq + h * DK;
+    const u16* qvB = p.qv + (int64_t)b * T * p.ldq + h * DK;
+    const u16* kB = p.k + (int64_t)b * T * p.ldkv + h * DK;
+    const u16* vB = p.v + (int64_t)b * T * p.ldkv + h * DK;
+    const u16* pB = p.pos + h * DK;
+    const uint8_t* mkB = p.keymask + (int64_t)b * T;
+    float* scw = sc + w * 16 * SC16_LD;
+
+    // ---- DMA geometry.  Tiles arrive through buffer descriptors whose range check supplies every zero: rows past the end
+    // of the utterance, band rows x < 0, x == T (xr = -1) and x - T - 1 >= T all land beyond num_records (the row offset
+    // sits in voffset: the check ignores soffset).  Piece q of this wave = 1 KiB = 64 lanes x 16 B.
+    const unsigned ldkv2 = (unsigned)p.ldkv * 2u, ldp2 = (unsigned)p.ldp * 2u;
+    const int kvbytes = (int)((unsigned)(T - 1) * ldkv2 + DK * 2u), pbytes = (int)((unsigned)(T - 1) * ldp2 + DK * 2u);
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kB, 0, kvbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vB, 0, kvbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)pB, 0, pbytes, 0x00020000);
+    unsigned voffK[2], dcol[2];      // (NPW <= 2; a template-sized array captured by the lambdas below loses the host stub for NDB = 1)
+    int drow[2];
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+        const int ci = (q * 8 + w) * 64 + lane;
+        const int row = ci / CPR, pos = ci - row * CPR;
+        drow[q] = row;
+        dcol[q] = (unsigned)((pos ^ D::sw(row)) * 16);
+        voffK[q] = (unsigned)row * ldkv2 + dcol[q];
+    }
+    auto issue_kv = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s) __attribute__((always_inline)) {
+        const unsigned step = (unsigned)(32 * s) * ldkv2;
+#pragma unroll
+        for (int q = 0; q < NPW; ++q)
+            if (q * 8 + w < NP)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_AS(tile + (q * 8 + w) * 1024), 16, voffK[q] + step, 0, 0, 0);
+    };
+    auto issue_p = [&](int u) __attribute__((always_inline)) {
+        unsigned char* tile = Pr + (u % 6) * TB;
+#pragma unroll
+        for (int q = 0; q < NPW; ++q)
+            if (q * 8 + w < NP) {
+                const int x = XB + 32 * u + drow[q];
+                const int xr = x < T ? x : x - T - 1;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, LDS_AS(tile + (q * 8 + w) * 1024), 16, (unsigned)xr * ldp2 + dcol[q], 0, 0, 0);
+            }
+    };
+    // everything step idx+1 needs that is not resident yet: K(idx+1), V(idx) (PV(idx) runs in M(idx+1)), ring tile idx+5
+    auto issue_step = [&](int idx) __attribute__((always_inline)) {
+        if (EXP & 1) return;
+        issue_kv(rK, Kb + ((idx + 1) & 1) * TB, idx + 1);
+        issue_kv(rV, Vb + (idx & 1) * TB, idx);
+        issue_p(idx + 5);
+    };
+
+    issue_kv(rK, Kb, 0);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) issue_p(u);
+    issue_kv(rV, Vb + TB, 1 << 20);                      // "V(-1)" = zeros: step 0 multiplies it by P(-1) = 0
+    if (EXP & 1) issue_kv(rV, Vb, 0), issue_kv(rK, Kb + TB, 1), issue_p(5);
+    bf16x8 fqu[KS], fqv[KS];                             // (q+u)[i]; (q+v)[i], turned into (q+v)[i+1] when the band crosses x = T
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int off = 32 * kk + 8 * PI;
+        fqu[kk] = ld_frag_g(quB + (int64_t)i * p.ldq + off, i < T);
+        fqv[kk] = ld_frag_g(qvB + (int64_t)i * p.ldq + off, i < T);
+    }
+    if (lane < CPR) {
+        const int r16 = q0 + 16;
+        *(uint4*)(xrow + w * DK * 2 + lane * 16) = *(const uint4*)(r16 < T ? qvB + (int64_t)r16 * p.ldq + lane * 8 : (const u16*)attn_zero_page);
+    }
+    for (int sb = w; sb < NS; sb += 8) {
+        const int jl = 32 * sb + (lane & 31);
+        const bool kvalid = (jl < T) && (mkB[jl < T ? jl : 0] != 0);
+        const unsigned int vmw = (unsigned int)__ballot(kvalid);
+        if (lane == 0) kmw[sb] = vmw;
+    }
+    __syncthreads();
+
+    // (q+v)[i] -> (q+v)[i+1], in place: lane lq takes the fragment of lane lq + 1 (same k-chunk group), lane 15 the row
+    // q0 + 16 parked in LDS.  Happens once per wave, when its band blocks cross x = T.
+    bool upper = false;
+    auto to_upper = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const uint4 x = *(const uint4*)(xrow + w * DK * 2 + (4 * kk + PI) * 16);
+            uint4 f = __builtin_bit_cast(uint4, fqv[kk]);
+            f.x = (unsigned)__builtin_amdgcn_update_dpp((int)x.x, (int)f.x, 0x101, 0xf, 0xf, false);
+            f.y = (unsigned)__builtin_amdgcn_update_dpp((int)x.y, (int)f.y, 0x101, 0xf, 0xf, false);
+            f.z = (unsigned)__builtin_amdgcn_update_dpp((int)x.z, (int)f.z, 0x101, 0xf, 0xf, false);
+            f.w = (unsigned)__builtin_amdgcn_update_dpp((int)x.w, (int)f.w, 0x101, 0xf, 0xf, false);
+            fqv[kk] = __builtin_bit_cast(bf16x8, f);
+        }
+        upper = true;
+    };
+    // per-lane LDS byte offsets of this lane's fragments inside a tile image (rows lq and 16 + lq share the swizzle)
+    int koff[LOWSW ? 1 : KS], voff[LOWSW ? 2 : NDT];
+    {
+        const int sw = D::sw(lq);
+        if (LOWSW) koff[0] = lq * RB + ((PI ^ sw) << 4);
+        else
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) koff[LOWSW ? 0 : kk] = lq * RB + (((4 * kk + PI) ^ sw) << 4);
+        const int r0 = 4 * lg + (lq >> 2), e = (lq & 3) >> 1, in = 8 * (lq & 1), swv = D::sw(r0);
+        if (LOWSW) voff[0] = r0 * RB + ((e ^ swv) << 4) + in, voff[1] = r0 * RB + (((2 + e) ^ swv) << 4) + in;
+        else
+#pragma unroll
+            for (int d = 0; d < NDT; ++d) voff[LOWSW ? 0 : d] = r0 * RB + (((2 * d + e) ^ swv) << 4) + in;
+    }
+    // base = byte offset of (tile + row block) in smem, already combined with koff[0] / made opaque by the caller when LOWSW
+    auto frag_k = [&](const int base, const int kk) __attribute__((always_inline)) -> bf16x8 {
+        if (LOWSW) return *(const bf16x8*)(smem + base + 64 * kk);
+        return *(const bf16x8*)(smem + base + koff[LOWSW ? 0 : kk]);
+    };
+    auto kbase = [&](const int tile_off) __attribute__((always_inline)) -> int { return LOWSW ? opaque_v(tile_off + koff[0]) : tile_off; };
+    // vb0 / vb1: opaque per-step bases (LOWSW: even / odd output tile)
+    auto frag_v = [&](const int vb0, const int vb1, const int d) __attribute__((always_inline)) -> bf16x8 {
+        const unsigned char* a0 = LOWSW ? smem + ((d & 1) ? vb1 : vb0) + 64 * (d >> 1) : smem + vb0 + voff[LOWSW ? 0 : d];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0 + 16 * RB));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    // block n of the band (16 x-rows, base x = XB + 16 n) lies in the (q+v)[i+1] half iff x >= T  <=>  16 n >= Q0 + 128
+    {
+        const int n = 7 - w;
+        if (16 * n >= Q0 + 128) to_upper();
+        const int slot = kbase(4 * TB + ((n >> 1) % 6) * TB + 16 * (n & 1) * RB);
+        f32x4 acc = zero4();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(slot, kk), fqv[kk], acc, 0, 0, 0);
+        *(float4*)(scw + lq * SC16_LD + 16 * (n & 3) + 4 * lg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    if (grp == 0) issue_step(0);                         // global half 0 (group 1 issues its share before its extra barrier)
+
+    f32x4 O[NDT];
+#pragma unroll
+    for (int d = 0; d < NDT; ++d) O[d] = zero4();
+    float m_run = -1e30f, l_run = 0.f;
+    const float NEG_INF = -__builtin_inff();
+    const unsigned int ibase = (unsigned int)(((int64_t)bh * T + i) * T);
+    bf16x8 pf = zero_frag();
+    f32x4 sa0, sa1;
+    float sv[8];
+
+    // One M half.  Fragments are read from LDS PD stages ahead of the MFMAs that use them (PD + 1 staging sets of four
+    // fragments); sched_barriers pin the order, the compiler's own counted lgkmcnt waits then come out right.
+    // MIXED: the one step of a wave whose first new band block still belongs to (q+v)[i] and whose second one to (q+v)[i+1].
+    constexpr int PD = 2;
+    auto mhalf = [&](auto MIXED, const int s) __attribute__((always_inline)) {
+        constexpr bool mixed = decltype(MIXED)::value;
+        const int n0 = 7 - w + 2 * s;
+        const int Kt = kbase((s & 1) * TB), Kt16 = LOWSW ? Kt : Kt + 16 * RB;
+        const int vt = 2 * TB + ((s + 1) & 1) * TB;                       // V(s-1)
+        const int vb0 = LOWSW ? opaque_v(vt + voff[0]) : vt, vb1 = LOWSW ? opaque_v(vt + voff[1]) : vt;
+        const int blk1 = kbase(4 * TB + (((n0 + 1) >> 1) % 6) * TB + 16 * ((n0 + 1) & 1) * RB);
+        const int blk2 = kbase(4 * TB + (((n0 + 2) >> 1) % 6) * TB + 16 * ((n0 + 2) & 1) * RB);
+        bf16x8 st[PD + 1][4];
+        f32x4 b1 = zero4(), b2 = zero4();
+        sa0 = zero4(), sa1 = zero4();
+        auto rd = [&](const int t) __attribute__((always_inline)) {
+            const int sl = t % (PD + 1);
+            if (t < KS) {
+                if (EXP & 8) return;
+                st[sl][0] = frag_k(Kt, t);
+                st[sl][1] = frag_k(Kt16, LOWSW ? t + (16 * RB) / 64 : t);
+                st[sl][2] = frag_k(blk1, t);
+                if (!mixed) st[sl][3] = frag_k(blk2, t);
+            } else if (t < NST) {
+                if (EXP & 4) return;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * (t - KS) + e < NDT) st[sl][e] = frag_v(vb0, vb1, 4 * (t - KS) + e);
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < PD; ++t) {
+            rd(t);
+            PHASE_FENCE();
+        }
+#pragma unroll
+        for (int t = 0; t < NST; ++t) {
+            if (!(mixed && t + PD >= KS)) rd(t + PD);     // (mixed: the PV fragments are fetched after the second band chain)
+            PHASE_FENCE();
+            const int sl = t % (PD + 1);
+            if (t < KS) {
+                if (!(EXP & 8)) {
+                    PPM(sa0, st[sl][0], fqu[t]);
+                    PPM(sa1, st[sl][1], fqu[t]);
+                    PPM(b1, st[sl][2], fqv[t]);
+                    if (!mixed) PPM(b2, st[sl][3], fqv[t]);
+                }
+                if (t == KS - 1) {
+                    PHASE_FENCE();
+                    if (mixed) {
+                        PP_SETTLE();
+                        to_upper();
+#pragma unroll
+                        for (int kk = 0; kk < KS; ++kk) PPM(b2, frag_k(blk2, kk), fqv[kk]);
+#pragma unroll
+                        for (int u = KS; u < KS + PD && u < NST; ++u) rd(u);
+                    }
+                    PP_SETTLE();
+                    *(float4*)(scw + lq * SC16_LD + 16 * ((n0 + 1) & 3) + 4 * lg) = make_float4(b1[0], b1[1], b1[2], b1[3]);
+                    *(float4*)(scw + lq * SC16_LD + 16 * ((n0 + 2) & 3) + 4 * lg) = make_float4(b2[0], b2[1], b2[2], b2[3]);
+                    // skewed band read: (query ii, key kk) <- band column 15 - ii + kk of blocks n0 .. n0+2; issued here so that
+                    // its latency runs under PV(s-1) and the barrier
+                    const int c0 = 16 * (n0 & 3) + 15 - lq + 4 * lg;
+                    const float* srow = scw + lq * SC16_LD;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) sv[r] = srow[(c0 + (r & 3) + 16 * (r >> 2)) & 63];
+                }
+            } else if (!(EXP & 4)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * (t - KS) + e < NDT) PPM(O[4 * (t - KS) + e], st[sl][e], pf);
+            }
+            PHASE_FENCE();
+        }
+        PP_DRAIN();
+    };
+    typedef std::integral_constant<bool, false> FalseT;
+    typedef std::integral_constant<bool, true> TrueT;
+
+    if (grp == 1) {
+        issue_step(0);
+        ATT_BAR();
+    }
+    for (int s = 0; s < NS; ++s) {
+        // ================================ M half: S(s), band(s), PV(s-1) ==============================================
+        if (grp == 0 && s > 0) issue_step(s);
+        {
+            const int n0 = 7 - w + 2 * s;
+            const bool up1 = 16 * (n0 + 1) >= Q0 + 128, up2 = 16 * (n0 + 2) >= Q0 + 128;
+            if (up1 && !upper) to_upper();
+            if (up1 == up2) mhalf(FalseT(), s);
+            else mhalf(TrueT(), s);
+        }
+        if (grp == 1) ATT_WAIT_VM0();                     // end of global half 2s+1: what was issued in half 2s has landed
+        ATT_BAR();
+        // ================================ V half: softmax(s) ==========================================================
+        if (grp == 1 && s + 1 < NS) issue_step(s + 1);    // global half 2(s+1)
+        if (EXP & 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sv[r] = (r < 4 ? sa0[r & 3] : sa1[r & 3]) + sv[r];
+            pf = pack_frag(sv);
+        } else {
+            const unsigned int vm = kmw[s];
+            float mloc = NEG_INF;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int kk = (r & 3) + 16 * (r >> 2) + 4 * lg;
+                const float x = ((r < 4 ? sa0[r & 3] : sa1[r & 3]) + sv[r]) * p.scale;
+                sv[r] = ((vm >> kk) & 1u) ? x : NEG_INF;
+                mloc = fmaxf(mloc, sv[r]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            {   // deferred-max rescale, branch-free in C++ (alpha = 1 unless some row's maximum grew by more than 8)
+                const int need = __any(mloc > m_run + 8.f) ? 1 : 0;
+                const float mnew = need ? fmaxf(m_run, mloc) : m_run;
+                const float alpha = __expf(m_run - mnew);
+                l_run *= alpha;
+                m_run = mnew;
+                // (PV(s-1) drained before the barrier; the LDS slot is this lane's float4 of band block n0, dead since the skew read)
+                const unsigned slot = (unsigned)(uintptr_t)LDS_AS(scw + lq * SC16_LD + 16 * ((7 - w + 2 * s) & 3) + 4 * lg);
+#pragma unroll
+                for (int d = 0; d < NDT; ++d) acc_scale4_if(O[d], alpha, slot, need);
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                sv[r] = __expf(sv[r] - m_run);
+                psum += sv[r];
+            }
+            l_run += psum;
+            if (p.drop_thr) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    bool kp[4];
+                    rng_keep4(p.drop_key, ibase + (unsigned int)(32 * s + 16 * g + 4 * lg), p.drop_thr, kp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sv[4 * g + e] = kp[e] ? sv[4 * g + e] * p.drop_inv : 0.f;
+                }
+            }
+            pf = pack_frag(sv);
+        }
+        if (grp == 0) ATT_WAIT_VM0();                     // end of global half 2s+1
+        ATT_BAR();
+    }
+    // ---- tail: PV(NS-1).  Group 1 runs it one half later; group 0 keeps the barrier count equal.
+    if (!(EXP & 4)) {
+        const int vt = 2 * TB + ((NS - 1) & 1) * TB;
+        const int vb0 = LOWSW ? vt + voff[0] : vt, vb1 = LOWSW ? vt + voff[1] : vt;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) PPM(O[d], frag_v(vb0, vb1, d), pf);
+        PP_DRAIN();
+    }
+    if (!(EXP & 16)) ATT_BAR();
+
+    float l = l_run;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float invl = l > 0.f ? 1.f / l : 0.f;
+    if (i < T) {
+        u16* o = p.ctx + ((int64_t)b * T + i) * p.ldo + h * DK + 4 * lg;
+#pragma unroll
+        for (int d = 0; d < NDT; ++d) {
+            uint2 v2;
+            v2.x = io_pack2(O[d][0] * invl, O[d][1] * invl);
+            v2.y = io_pack2(O[d][2] * invl, O[d][3] * invl);
+            *(uint2*)(o + 16 * d) = v2;
+        }
+        if (lg == 0) p.lse[(int64_t)bh * T + i] = l > 0.f ? m_run + __logf(l) : __builtin_inff();
+    }
+}
+
+__device__ __forceinline__ void st4_bf16(u16* dst, float a, float b, float c, float d);
+// =====================================================================================================================
+// Forward, round 4: 4 waves x 32 queries, ONE wave per SIMD with the whole 512-entry register file, 32x32x16 MFMAs.
+// Why not more waves: at d_k = 192 a wave's resident set is O (16 q x 192 -> 48 registers per 16 queries), (q+u) and
+// (q+v) fragments (24 + 24 per 16 queries) plus staging; with 16 queries per wave and two waves per SIMD that is > 256
+// registers (measured: 35-80 spills, and a spill reload is a vector-memory load whose vmcnt wait also waits for every
+// tile DMA in flight -- 516 us instead of 290).  With 32 queries per wave every LDS fragment feeds twice the MFMA work
+// (LDS fragment traffic per flop halves) and nothing spills; what one wave per SIMD loses -- another wave to fill its
+// stalls -- is bought back by software pipelining INSIDE the wave: iteration s issues the products of step s+1
+// (S = K (q+u)^T and the new band block) while the VALU exponentiates step s, then PV(s).
+// No running maximum: the reference maximum of a row is fixed at the first key tile that holds a valid key (tiles in
+// front of it are skipped altogether; the key mask does not depend on the query, so that tile is the same for the whole
+// workgroup) and P = exp(s - m_ref) is used as is -- bf16 and fp32 carry 8 exponent bits, a probability of e^60 is as
+// precise as one of 1.  A row whose later scores exceed m_ref by more than ~88 overflows l to +inf; the workgroup then
+// raises its redo flag and the launcher's second kernel (the rescaling 16-query kernel above, which exits at once for
+// every block whose flag is clear) recomputes that block.  This takes the max tracking, its cross-lane reductions and
+// the O rescale (a second definition of the accumulators = 96 register moves per step) out of the loop.
+// =====================================================================================================================
+template <int NDB>
+struct DT32 {   // 32-row x DK tile, DMA-filled (1-KiB pieces = 64 lanes x 16 B, lane-linear image), XOR-swizzled 16-byte chunks
+    static constexpr int DK = 32 * NDB, CPR = DK / 8, RB = DK * 2, BYTES = 32 * RB, NP = BYTES / 1024;
+    static constexpr int SWB = (CPR % 8 == 0) ? 3 : 2;
+    // rows r and r+1 sit in different bank halves for free (RB = 64 NDB bytes); the swizzle spreads the rows of one parity:
+    // bit-reversed so that rows r, r+2 (transposed reads) differ in the HIGH chunk bit and 8 consecutive same-parity rows
+    // (ds_read_b128 lane groups) in all of them
+    __device__ static __forceinline__ int sw(int row) {
+        const int v = row >> 1;
+        if (SWB == 3) return ((v & 1) << 2) | (v & 2) | ((v >> 2) & 1);
+        return ((v & 1) << 1) | ((v >> 1) & 1);
+    }
+    // A / B fragment of a 32x32x16 MFMA, k-contiguous operand: row lr, k = 16 kk + 8 lh .. +7
+    __device__ static __forceinline__ bf16x8 rows(const unsigned char* tile, int lr, int c) {
+        return *(const bf16x8*)(tile + lr * RB + ((c ^ sw(lr)) << 4));
+    }
+};
+
+
+__device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int NDB, bool DROP, bool SAVE>
+__global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
+    using D = DT32<NDB>;
+    constexpr int DK = D::DK, KS = DK / 16, TB = D::BYTES, CPR = D::CPR, RB = D::RB, NPW = D::NP / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Kb = smem;                            // [2]
+    unsigned char* Vb = smem + 2 * TB;                   // [2]
+    unsigned char* Pr = smem + 4 * TB;                   // 6 ring slots of 32-row Pext tiles
+    float* sc = (float*)(smem + 10 * TB);                // [4 waves][32][SC_LD] band scratch: two 32-column blocks
+    unsigned int* kmw = (unsigned int*)(sc + 4 * 32 * SC_LD);   // [136] key-mask words
+
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, NQB = (T + 127) / 128, NS = (T + 31) / 32;
+    int wi = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
+    }
+    const int bh = wi / NQB, qb = wi - bh * NQB;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int Q0 = qb * 128, q0 = Q0 + 32 * w, i = q0 + lr;
+    const int X0 = T - 32 - Q0;                          // band block u covers x in [X0 + 32 (u - 3), +32)
+    const u16* quB = p.qu + (int64_t)b * T * p.ldq + h * DK;
+    const u16* qvB = p.qv + (int64_t)b * T * p.ldq + h * DK;
+    const u16* kB = p.k + (int64_t)b * T * p.ldkv + h * DK;
+    const u16* vB = p.v + (int64_t)b * T * p.ldkv + h * DK;
+    const u16* pB = p.pos + h * DK;
+    const uint8_t* mkB = p.keymask + (int64_t)b * T;
+    float* scw = sc + w * 32 * SC_LD;
+
+    // ---- key-mask words; the first tile with a valid key (the same for every query: the mask is per key) ----------------
+    for (int sb = w; sb <= NS; sb += 4) {
+        const int jl = 32 * sb + lr;
+        const bool kvalid = (jl < T) && (mkB[jl < T ? jl : 0] != 0);
+        const unsigned int vmw = (unsigned int)__ballot(kvalid);
+        if (lane == 0) kmw[sb] = vmw;
+    }
+    __syncthreads();
+    int s0 = 0;
+    while (s0 < NS && kmw[s0] == 0) ++s0;
+    s0 = __builtin_amdgcn_readfirstlane(s0);
+    if (s0 >= NS) {                                       // no valid key at all: zero context, lse = +inf
+        if (i < T) {
+            u16* o = p.ctx + ((int64_t)b * T + i) * p.ldo + h * DK;
+            for (int c = lh * 4; c < DK; c += 8) *(uint2*)(o + c) = make_uint2(0, 0);
+            if (lh == 0) p.lse[(int64_t)bh * T + i] = __builtin_inff();
+            if (SAVE) {
+                if (lh == 0) p.rowscale[(int64_t)bh * T + i] = 0.f;
+                for (int c = lh * 4; c < T; c += 8) {
+                    *(uint2*)(p.probs + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+                    if (DROP) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+                }
+            }
+        }
+        if (tid == 0) attn_redo[wi & 0xffff] = 0;
+        return;
+    }
+    if (SAVE && i < T)                                    // key tiles in front of the first valid one are skipped: their probabilities are 0
+        for (int c = lh * 4; c < 32 * s0; c += 8) {
+            *(uint2*)(p.probs + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+            if (DROP) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+        }
+
+    // ---- DMA geometry: buffer descriptors whose range check supplies every zero (rows past the utterance, band rows
+    // x < 0, x == T (xr = -1), x - T - 1 >= T all land beyond num_records; the row offset sits in voffset) ---------------
+    const unsigned ldkv2 = (unsigned)p.ldkv * 2u, ldp2 = (unsigned)p.ldp * 2u;
+    const int kvbytes = (int)((unsigned)(T - 1) * ldkv2 + DK * 2u), pbytes = (int)((unsigned)(T - 1) * ldp2 + DK * 2u);
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kB, 0, kvbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vB, 0, kvbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)pB, 0, pbytes, 0x00020000);
+    unsigned voffK[3], dcol[3];
+    int drow[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int ci = (q * 4 + w) * 64 + lane;
+        const int row = ci / CPR, pos = ci - row * CPR;
+        drow[q] = row;
+        dcol[q] = (unsigned)((pos ^ D::sw(row)) * 16);
+        voffK[q] = (unsigned)row * ldkv2 + dcol[q];
+    }
+    auto issue_kv = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s) __attribute__((always_inline)) {
+        const unsigned step = (unsigned)(32 * s) * ldkv2;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < NPW || (q * 4 + w) * 1024 < TB)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_AS(tile + (q * 4 + w) * 1024), 16, voffK[q] + step, 0, 0, 0);
+    };
+    auto issue_p = [&](int u) __attribute__((always_inline)) {
+        unsigned char* tile = Pr + (u % 6) * TB;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < NPW || (q * 4 + w) * 1024 < TB) {
+                const int x = X0 + 32 * (u - 3) + drow[q];
+                const int xr = x < T ? x : x - T - 1;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, LDS_AS(tile + (q * 4 + w) * 1024), 16, (unsigned)xr * ldp2 + dcol[q], 0, 0, 0);
+            }
+    };
+    // K(s0), K(s0+1), V(s0), ring tiles s0 .. s0+5
+    issue_kv(rK, Kb + (s0 & 1) * TB, s0);
+    issue_kv(rK, Kb + ((s0 + 1) & 1) * TB, s0 + 1);
+    issue_kv(rV, Vb + (s0 & 1) * TB, s0);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) issue_p(s0 + u);
+
+    bf16x8 fqu[KS], fqvL[KS], fqvU[KS];                  // (q+u)[i]; (q+v)[i] for the x < T half of the band, (q+v)[i+1] for x > T
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+        const int off = 16 * kk + 8 * lh;
+        fqu[kk] = ld_frag_g(quB + (int64_t)i * p.ldq + off, i < T);
+        fqvL[kk] = ld_frag_g(qvB + (int64_t)i * p.ldq + off, i < T);
+        fqvU[kk] = ld_frag_g(qvB + (int64_t)(i + 1) * p.ldq + off, i + 1 < T);
+    }
+    __syncthreads();                                      // (waits for the DMA: vmcnt(0) + barrier)
+
+    // ---- fragment addressing -------------------------------------------------------------------------------------------
+    const int swr = D::sw(lr);
+    auto frag_rows = [&](const unsigned char* tile, const int kk) __attribute__((always_inline)) -> bf16x8 {
+        return *(const bf16x8*)(tile + lr * RB + (((2 * kk + lh) ^ swr) << 4));
+    };
+    // transposed fragment A[m = col0 + (lane&31)][k slots e<4: row krow0 + 4 lh + e, e>=4: row krow0 + 8 + 4 lh + e-4]
+    const int gq = lane >> 4, pp = lane & 15;
+    const int tr_r0 = 4 * (gq >> 1) + (pp >> 2), tr_c = 16 * (gq & 1) + 4 * (pp & 3);
+    auto frag_cols = [&](const unsigned char* tile, const int krow0, const int col0) __attribute__((always_inline)) -> bf16x8 {
+        const int r0 = krow0 + tr_r0, r1 = r0 + 8, col = col0 + tr_c;
+        const unsigned char* a0 = tile + r0 * RB + (((col >> 3) ^ D::sw(r0)) << 4) + (col & 7) * 2;
+        const unsigned char* a1 = tile + r1 * RB + (((col >> 3) ^ D::sw(r1)) << 4) + (col & 7) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a1));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto use_upper = [&](int u) -> bool { return (u - 3) * 32 >= 32 + Q0; };
+    // band block u (32 band rows x this wave's 32 queries) -> fp32 scratch half (u & 1), stored [query][band column]
+    auto band_mm = [&](int u) __attribute__((always_inline)) -> f32x16 {
+        const unsigned char* slot = Pr + (u % 6) * TB;
+        f32x16 acc = zero16();
+        if (use_upper(u)) {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc = mfma32(frag_rows(slot, kk), fqvU[kk], acc);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) acc = mfma32(frag_rows(slot, kk), fqvL[kk], acc);
+        }
+        return acc;
+    };
+    auto band_store = [&](int u, const f32x16& acc) __attribute__((always_inline)) {
+        float* row = scw + lr * SC_LD + 32 * (u & 1) + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(float4*)(row + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    };
+    // (query lr, key kk) <- band column 31 - lr + kk of blocks u (columns 0..31) and u + 1 (32..63), u = s - w + 3
+    auto band_read = [&](int u, float* bd) __attribute__((always_inline)) {
+        const int c0 = 32 * (u & 1) + 31 - lr + 4 * lh;
+        const float* srow = scw + lr * SC_LD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bd[r] = srow[(c0 + (r & 3) + 8 * (r >> 2)) & 63];
+    };
+    auto s_mm = [&](const unsigned char* Kt) __attribute__((always_inline)) -> f32x16 {
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) acc = mfma32(frag_rows(Kt, kk), fqu[kk], acc);
+        return acc;
+    };
+
+    // ---- prologue: S(s0), both band blocks of step s0, the reference maximum ---------------------------------------------
+    const float sl2 = p.scale * 1.4426950408889634f;     // exponentials in base 2: p = exp2(s sl2 - m2)
+    f32x16 Sc = s_mm(Kb + (s0 & 1) * TB);
+    float bd[16];
+    {
+        const int u = s0 - w + 3;
+        band_store(u, band_mm(u));
+        band_store(u + 1, band_mm(u + 1));
+        band_read(u, bd);
+    }
+    float m2;
+    {
+        const unsigned int vm = kmw[s0];
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if ((vm >> kk) & 1u) mx = fmaxf(mx, (Sc[r] + bd[r]) * sl2);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        m2 = mx;                                          // finite: tile s0 holds a valid key
+    }
+
+#ifdef A3T_ATTN_TIMING
+    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define TSTAMP(k) do { PHASE_FENCE(); const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; PHASE_FENCE(); } while (0)
+#else
+#define TSTAMP(k) ((void)0)
+#endif
+    f32x16 O[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) O[d] = zero16();
+    float l_run = 0.f;
+    const unsigned int ibase = (unsigned int)(((int64_t)bh * T + i) * T);
+
+    // One iteration = KS + NDB stages of two MFMAs each: stages 0 .. KS-1 multiply step s+1 (S and the new band block, two
+    // independent accumulator chains), stages KS .. KS+NDB-1 are PV(s).  Fragments are fetched from LDS two stages ahead
+    // (three staging pairs); the softmax of step s is cut into slices that ride on the first KS stages, the hand-over of step
+    // s+1 (band block to the scratch, skewed read back) on the PV stages.  sched_barriers pin the slices to their stages --
+    // left alone the scheduler emits [12 dependent MFMAs][12 dependent MFMAs][softmax][PV] with a one-deep LDS lookahead.
+    auto iteration = [&](auto UP, const int s) __attribute__((always_inline)) {
+        constexpr bool up = decltype(UP)::value;
+        constexpr int NSTG = KS + NDB;
+        const unsigned char* Kt = Kb + ((s + 1) & 1) * TB;
+        const unsigned char* Vt = Vb + (s & 1) * TB;
+        const int un = s + 1 - w + 4;                     // the one new band block of step s+1
+        const unsigned char* slot = Pr + (un % 6) * TB;
+        const unsigned int vm = kmw[s] >> (4 * lh);       // bit (r & 3) + 8 (r >> 2) = this lane's key of register r
+        bf16x8 st[3][2];
+        f32x16 Sn = zero16(), Bn = zero16();
+        float pv[16];
+        bf16x8 pf0, pf1;
+        float psum = 0.f;
+        auto rd = [&](const int t) __attribute__((always_inline)) {
+            if (t < KS) {
+                st[t % 3][0] = frag_rows(Kt, t);
+                st[t % 3][1] = frag_rows(slot, t);
+            } else if (t < NSTG) {
+                st[t % 3][0] = frag_cols(Vt, 0, 32 * (t - KS));
+                st[t % 3][1] = frag_cols(Vt, 16, 32 * (t - KS));
+            }
+        };
+        auto expo = [&](const int r) __attribute__((always_inline)) {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[r] + bd[r], sl2, -m2));
+            pv[r] = ((vm >> ((r & 3) + 8 * (r >> 2))) & 1u) ? e : 0.f;
+            psum += pv[r];
+        };
+        u16* prow = SAVE ? p.probs + ((int64_t)bh * T + (i < T ? i : 0)) * T + 32 * s + 4 * lh : nullptr;
+        u16* drow_ = (SAVE && DROP) ? p.pdrop + ((int64_t)bh * T + (i < T ? i : 0)) * T + 32 * s + 4 * lh : nullptr;
+        const bool rowok = i < T;
+        auto save4 = [&](u16* base, const int g) __attribute__((always_inline)) {   // this lane's 4 consecutive keys of quad g
+            if (rowok && 32 * s + 8 * g + 4 * lh < T) st4_bf16(base + 8 * g, pv[4 * g], pv[4 * g + 1], pv[4 * g + 2], pv[4 * g + 3]);
+        };
+        auto drop4 = [&](const int g) __attribute__((always_inline)) {
+            if (SAVE) save4(prow, g);
+            if (DROP) {
+                bool kp[4];
+                rng_keep4(p.drop_key, ibase + (unsigned int)(32 * s + 8 * g + 4 * lh), p.drop_thr, kp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pv[4 * g + e] = kp[e] ? pv[4 * g + e] * p.drop_inv : 0.f;
+                if (SAVE) save4(drow_, g);
+            }
+        };
+        // softmax slices over the KS product stages: exponentials first, then the dropout quads, then the packing
+        constexpr int EXS = KS >= 8 ? KS - 4 : (KS > 1 ? KS - 1 : 1);        // stages that carry exponentials
+        auto slice = [&](const int t) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (r * EXS / 16 == t) expo(r);
+            if (KS >= 8) {
+                if (t >= KS - 4) drop4(t - (KS - 4));
+            } else if (t == KS - 1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) drop4(g);
+            }
+            if (t == KS - 1) pf0 = pack_frag(pv), pf1 = pack_frag(pv + 8);
+        };
+        rd(0);
+        rd(1);
+        PHASE_FENCE();
+#pragma unroll
+        for (int t = 0; t < NSTG; ++t) {
+            if (t == KS) TSTAMP(2);
+            rd(t + 2);
+            if (t < KS) {
+                Sn = mfma32(st[t % 3][0], fqu[t], Sn);
+                Bn = mfma32(st[t % 3][1], up ? fqvU[t] : fqvL[t], Bn);
+                slice(t);
+            } else {
+                const int d = t - KS;
+                O[d] = mfma32(st[t % 3][0], pf0, O[d]);
+                O[d] = mfma32(st[t % 3][1], pf1, O[d]);
+                if (d == 0) band_store(un, Bn);
+                if (d == 1 || NDB == 1) band_read(un - 1, bd);
+            }
+            PHASE_FENCE();
+        }
+        TSTAMP(3);
+        l_run += psum;
+        Sc = Sn;
+    };
+    typedef std::integral_constant<bool, false> FalseT;
+    typedef std::integral_constant<bool, true> TrueT;
+
+    for (int s = s0; s < NS; ++s) {
+        // resident: K(s+1), V(s), ring tiles s+1 .. s+5; registers: Sc = S(s), bd = band values of step s
+        TSTAMP(0);
+        issue_kv(rK, Kb + (s & 1) * TB, s + 2);           // all three targets were last read in iteration s-1
+        issue_kv(rV, Vb + ((s + 1) & 1) * TB, s + 1);
+        issue_p(s + 6);
+        TSTAMP(1);
+        if (use_upper(s + 1 - w + 4)) iteration(TrueT(), s);
+        else iteration(FalseT(), s);
+        __syncthreads();                                  // DMA of this iteration landed (vmcnt(0)), everyone done reading
+        TSTAMP(4);
+    }
+#ifdef A3T_ATTN_TIMING
+    if (lane == 0 && p.dbd) {
+        unsigned long long* o = (unsigned long long*)p.dbd + ((int64_t)blockIdx.x * 4 + w) * 8;
+        o[0] = tacc[0], o[1] = tacc[1], o[2] = tacc[2], o[3] = tacc[3], o[4] = tacc[4], o[5] = (unsigned long long)(NS - s0);
+    }
+#endif
+
+    float l = l_run + __shfl_xor(l_run, 32, 64);
+    const bool bad = !(l < 3.0e38f);                      // +inf / NaN: some score exceeded the reference maximum by > ~88
+    const float invl = l > 0.f ? 1.f / l : 0.f;
+    if (i < T) {
+        u16* o = p.ctx + ((int64_t)b * T + i) * p.ldo + h * DK + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                st4_bf16(o + 32 * d + 8 * g, O[d][4 * g] * invl, O[d][4 * g + 1] * invl, O[d][4 * g + 2] * invl, O[d][4 * g + 3] * invl);
+        if (lh == 0) p.lse[(int64_t)bh * T + i] = (m2 + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+        if (SAVE && lh == 0) p.rowscale[(int64_t)bh * T + i] = invl;
+    }
+    const int anybad = __syncthreads_or(bad && i < T);
+    if (tid == 0) attn_redo[wi & 0xffff] = anybad ? 1 : 0;
 }
 
 // =====================================================================================================================
@@ -869,15 +1662,53 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
 
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
+// A3T_ATTN_FWD=16: the rescaling 16-query kernel alone (round 2); =pp: the staggered 16-query experiment; default: the
+// 32-query one-wave-per-SIMD kernel + the 16-query kernel as its overflow fixup
+static int attn_fwd_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("A3T_ATTN_FWD");
+        mode = (e && !strcmp(e, "16")) ? 0 : (e && !strcmp(e, "pp")) ? 1 : 2;
+    }
+    return mode;
+}
+
 template <int NDB>
 static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     constexpr int TB = DT16<NDB>::BYTES;
-    constexpr int lds = 10 * TB + 8 * 16 * SC16_LD * 4 + 4 * 128;
+    constexpr int lds = 10 * TB + 8 * 16 * SC16_LD * 4 + 4 * 128 + 8 * 64 * NDB;
     // (the attribute is per device: set it on every launch -- a process that drives several GPUs would otherwise launch on
     //  its second device without the raised LDS limit)
-    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int nqb = (a.T + 127) / 128;
-    hipLaunchKernelGGL(attn_fwd16_kernel<NDB>, dim3((unsigned)(a.B * a.H * nqb)), dim3(512), lds, s, a);
+    const unsigned grid = (unsigned)(a.B * a.H * nqb);
+    const int mode = attn_fwd_mode();
+    if (mode == 1) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(attn_fwd_pp_kernel<NDB>, dim3(grid), dim3(512), lds, s, a);
+        return (int)hipGetLastError();
+    }
+    AttnArgs a16 = a;
+    if (a.probs && !(mode == 2 && grid <= (1u << 16))) return A3T_EINVAL;   // only the fixed-reference kernel can save probabilities
+    if (mode == 2 && grid <= (1u << 16)) {
+        constexpr int TB32 = DT32<NDB>::BYTES;
+        constexpr int lds32 = 10 * TB32 + 4 * 32 * SC_LD * 4 + 136 * 4;
+#define A3T_L32(DR, SV)                                                                                                              \
+    do {                                                                                                                             \
+        (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);   \
+        hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV>), dim3(grid), dim3(256), lds32, s, a);                                    \
+    } while (0)
+        if (a.probs) {
+            if (a.drop_thr) A3T_L32(true, true);
+            else A3T_L32(false, true);
+        } else {
+            if (a.drop_thr) A3T_L32(true, false);
+            else A3T_L32(false, false);
+        }
+#undef A3T_L32
+        a16.use_redo = 1;        // the same grid again: a block exits at once unless its row sums overflowed
+    }
+    (void)hipFuncSetAttribute((const void*)attn_fwd16_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(attn_fwd16_kernel<NDB>, dim3(grid), dim3(512), lds, s, a16);
     return (int)hipGetLastError();
 }
 
@@ -984,10 +1815,35 @@ extern "C" int a3t_attn_bwd_finish(const void* dqu, const void* dqvl, const void
     return (int)hipGetLastError();
 }
 
-extern "C" int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
-                            const uint8_t* keymask, void* ctx, float* lse, int B, int H, int T, int dk, int64_t ldq,
-                            int64_t ldkv, int64_t ldp, int64_t ldo, float scale, float drop_p, uint32_t drop_key,
-                            void* stream) {
+#ifdef A3T_ATTN_TIMING
+static void* g_attn_timing_buf = nullptr;
+extern "C" void a3t_attn_timing_buf(void* ptr) { g_attn_timing_buf = ptr; }
+#endif
+__global__ __launch_bounds__(256) void attn_scale_rows_kernel(const u16* __restrict__ x, const float* __restrict__ rs,
+                                                              u16* __restrict__ y, int H, int T, int dk, int64_t n4) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // group of 4 consecutive columns
+    if (e >= n4) return;
+    const int d4 = H * dk / 4;
+    const int64_t r = e / d4;
+    const int c = (int)(e - r * d4) * 4, h = c / dk;
+    const int64_t b = r / T;
+    const float f = rs[(b * H + h) * T + (r - b * T)];
+    const uint2 v = *(const uint2*)(x + r * (H * dk) + c);
+    st4_bf16(y + r * (H * dk) + c, io_bf2f(v.x & 0xffff) * f, io_bf2f(v.x >> 16) * f, io_bf2f(v.y & 0xffff) * f, io_bf2f(v.y >> 16) * f);
+}
+
+extern "C" int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y, int B, int H, int T, int dk, void* stream) {
+    if (dk % 4) return A3T_EINVAL;
+    const int64_t n4 = (int64_t)B * T * H * dk / 4;
+    hipLaunchKernelGGL(attn_scale_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const u16*)x,
+                       rowscale, (u16*)y, H, T, dk, n4);
+    return (int)hipGetLastError();
+}
+
+static int attn_fwd_impl(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                         const uint8_t* keymask, void* ctx, float* lse, void* probs, void* probs_drop, float* rowscale, int B,
+                         int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo, float scale, float drop_p,
+                         uint32_t drop_key, void* stream) {
     if (!attn_shape_ok(dk, T)) return A3T_EINVAL;
     if (!(al16(qu) && al16(qv) && al16(k) && al16(v) && al16(pos) && al16(ctx))) return A3T_EINVAL;
     if ((ldq % 8) || (ldkv % 8) || (ldp % 8) || (ldo % 4)) return A3T_EINVAL;
@@ -995,6 +1851,10 @@ extern "C" int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const
     AttnArgs a = {};
     a.qu = (const u16*)qu, a.qv = (const u16*)qv, a.k = (const u16*)k, a.v = (const u16*)v, a.pos = (const u16*)pos;
     a.keymask = keymask, a.ctx = (u16*)ctx, a.lse = lse;
+    a.probs = (u16*)probs, a.pdrop = (u16*)probs_drop, a.rowscale = rowscale;
+#ifdef A3T_ATTN_TIMING
+    a.dbd = (u16*)g_attn_timing_buf;
+#endif
     a.B = B, a.H = H, a.T = T, a.ldq = ldq, a.ldkv = ldkv, a.ldp = ldp, a.ldo = ldo, a.scale = scale;
     a.drop_thr = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
     a.drop_key = drop_key, a.drop_inv = 1.f / (1.f - drop_p);
@@ -1007,4 +1867,22 @@ extern "C" int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const
         case 6: return launch_fwd16<6>(a, s);
     }
     return A3T_EINVAL;
+}
+
+extern "C" int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                            const uint8_t* keymask, void* ctx, float* lse, int B, int H, int T, int dk, int64_t ldq,
+                            int64_t ldkv, int64_t ldp, int64_t ldo, float scale, float drop_p, uint32_t drop_key,
+                            void* stream) {
+    return attn_fwd_impl(qu, qv, k, v, pos, keymask, ctx, lse, nullptr, nullptr, nullptr, B, H, T, dk, ldq, ldkv, ldp, ldo, scale,
+                         drop_p, drop_key, stream);
+}
+
+extern "C" int a3t_attn_fwd_train(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                                  const uint8_t* keymask, void* ctx, float* lse, void* probs, void* probs_drop,
+                                  float* rowscale, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp,
+                                  int64_t ldo, float scale, float drop_p, uint32_t drop_key, void* stream) {
+    if (!probs || !rowscale || (drop_p > 0.f && !probs_drop) || (T % 8)) return A3T_EINVAL;
+    if (((uintptr_t)probs & 7) || ((uintptr_t)probs_drop & 7)) return A3T_EINVAL;
+    return attn_fwd_impl(qu, qv, k, v, pos, keymask, ctx, lse, probs, drop_p > 0.f ? probs_drop : nullptr, rowscale, B, H, T, dk, ldq,
+                         ldkv, ldp, ldo, scale, drop_p, drop_key, stream);
 }

@@ -712,10 +712,11 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
     const unsigned short* __restrict__ probs, const unsigned short* __restrict__ dprobs, unsigned short* __restrict__ ds,
     unsigned short* __restrict__ dbd, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs, float scale, int64_t nrows,
     const unsigned short* __restrict__ pdrop, float dinv, int H, int64_t dbd_bsb, int64_t dbd_bsh, unsigned int rng_thr_,
-    unsigned int rng_key) {
+    unsigned int rng_key, const float* __restrict__ rowscale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
+    const float rs = rowscale ? rowscale[row] : 1.f;       // probs hold exp(s - m_ref) un-normalised (a3t_attn_fwd_train)
     const int64_t zz = row / T;
     const int i = (int)(row - zz * T);
     const int64_t po = zz * p_bs + (int64_t)i * T;
@@ -735,6 +736,10 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
         if (c < nch) {
             unpack8(*(const uint4*)(probs + po + j0), pv[q]);
             unpack8(*(const uint4*)(dr + j0), dv[q]);
+            if (rowscale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[q][e] *= rs;
+            }
             if (pdrop) {
                 const uint4 m = *(const uint4*)(pdrop + po + j0);
                 const unsigned int mw[4] = {m.x, m.y, m.z, m.w};
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(256) void relpos_softmax_bwd_bf16_kernel(
 extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprobs, int dprobs_dtype, void* ds,
                                       void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs,
                                       int64_t o_bs, float scale, const void* probs_drop, float drop_p, int64_t dbd_bsb,
-                                      int64_t dbd_bsh, uint32_t drop_key, void* stream) {
+                                      int64_t dbd_bsh, uint32_t drop_key, const float* rowscale, void* stream) {
     if (dbd_bsb == 0 && dbd_bsh == 0) dbd_bsb = (int64_t)H * o_bs, dbd_bsh = o_bs;     // default: [B][H][T][T] like ds
     if (drop_p < 0.f || drop_p >= 1.f) return A3T_EINVAL;
     const float dinv = 1.f / (1.f - drop_p);
@@ -809,12 +814,12 @@ extern "C" int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const 
     hipLaunchKernelGGL(relpos_softmax_bwd_bf16_kernel<NC>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,        \
                        (hipStream_t)stream, (const unsigned short*)probs, (const unsigned short*)dprobs,          \
                        (unsigned short*)ds, (unsigned short*)dbd, T, p_bs, dp_bs, o_bs, scale, nrows,             \
-                       (const unsigned short*)probs_drop, dinv, H, dbd_bsb, dbd_bsh, rthr, drop_key)
+                       (const unsigned short*)probs_drop, dinv, H, dbd_bsb, dbd_bsh, rthr, drop_key, rowscale)
         SM_DISPATCH_VEC(T, CALLV);
 #undef CALLV
         return (int)hipGetLastError();
     }
-    if (rthr) return A3T_EINVAL;    // (the generic kernel reads the mask off probs_drop)
+    if (rthr || rowscale) return A3T_EINVAL;    // (the generic kernel reads the mask off probs_drop and takes normalised probabilities)
 #define CALL(NV)                                                                                                 \
     hipLaunchKernelGGL(relpos_softmax_bwd_kernel<NV>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0,           \
                        (hipStream_t)stream, probs, probs_dtype, dprobs, dprobs_dtype, ds, dbd, out_dtype, T, p_bs, dp_bs, \

@@ -114,12 +114,18 @@ class MLMEngine:
         # when it has too few workgroups to hide its 94-us latency floor (B <= 2: +1..2 %); the two-pass backward does not
         # beat the materialised backward.  Hence the default "auto": forward-only passes (need_grad=False)
         # use the fused kernel when it launches >= 64 workgroups; training steps stay materialised.
-        # A3T_FUSED_ATTN=0: never; =fwd: every forward-only pass; =1: fused forward AND backward.
+        # A3T_FUSED_ATTN=0: never; =fwd: every forward-only pass; =1: fused forward AND (flash, recomputing) backward.
+        # Round 4: training steps under "auto" take the fused FORWARD too (a3t_attn_fwd_train: one launch instead of two score
+        # GEMMs + softmax + probs @ V, no logits in HBM); it stores the un-normalised probabilities exp(s - m_ref) (+ their
+        # dropped copy and 1 / row sum) that the materialised backward consumes -- a flash backward has to recompute them,
+        # 10-11 score-sized products against 7, and loses at d_k = 192.  A3T_FUSED_ATTN_TRAIN=0 switches it off.
         fa = os.environ.get("A3T_FUSED_ATTN", "auto")
         self.fused_attn = self.bf16 and fa == "1"
         self.fused_attn_fwd_only = self.bf16 and fa == "fwd"
         self.fused_attn_auto = self.bf16 and fa == "auto"
+        self.fused_attn_train = self.bf16 and fa == "auto" and os.environ.get("A3T_FUSED_ATTN_TRAIN", "1") != "0"
         self._fused_now = self.fused_attn
+        self._fused_train_now = False
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -428,6 +434,23 @@ class MLMEngine:
             self.sv[tag + ".fused"] = (keymask, lse, adr)
             return xo
         self.sv.pop(tag + ".fused", None)
+        self.sv.pop(tag + ".rs", None)
+        if self._fused_train_now and ops.attn_fused_supported(dk, T):
+            # fused forward, materialised backward: probabilities stay un-normalised (1 / row sum in `rs`)
+            adr = self._drop(c.attention_dropout_rate, tag + ".att")
+            probs = self._act(tag + ".probs", (B, H, T, T))
+            pdrop = self._act(tag + ".pdrop", (B, H, T, T)) if adr else None
+            ctx = self._act(tag + ".ctx", (M, d))
+            lse = self.ws.get(tag + ".lse", (B, H, T))
+            rs = self.ws.get(tag + ".rs", (B, H, T))
+            ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk),
+                               drop=adr or (0.0, 0))
+            xo = self.ws.get(tag + ".xo", (M, d))
+            ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
+                           drop=self._drop(c.dropout_rate, tag + ".o"))
+            self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos, pdrop)
+            self.sv[tag + ".rs"] = rs
+            return xo
         # score-sized scratch: fp32 in fp32 mode; bf16 logits (fp32 softmax math) in bf16 mode
         sdt = torch.bfloat16 if self.bf16 else torch.float32
         ac = self.ws.get("tmp.ac", (B, H, T, T), sdt)
@@ -502,6 +525,11 @@ class MLMEngine:
         dkk = dqkv.view(-1)[d:]
         dvv = dqkv.view(-1)[2 * d:]
         sdt = torch.bfloat16 if self.bf16 else torch.float32
+        rs = self.sv.get(tag + ".rs")      # fused training forward: probs / pdrop are exp(s - m_ref), rs = 1 / row sum
+        dctx_v = dctx
+        if rs is not None:                 # dV = pdrop^T (rs * dctx): fold the row normalisation into the small operand
+            dctx_v = self._act(self._t("tmp.dctxs"), (M, d))
+            ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
         dpr = self.ws.get("tmp.ac", (B, H, T, T), sdt)      # reuse the score buffers
         zb = (H * T * T, T * T)
         # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
@@ -517,7 +545,7 @@ class MLMEngine:
         sl = self._arena_slot("bwd32", tag + ".bsl", S * 4 * d) if fz else None
         csk = dict(colsum_bs1=dk, colsum_slots=S, colsum_ss=4 * d)
         # (independent of the dprobs -> softmax-backward chain: runs beside it on the side stream)
-        self._side(lambda: ops.gemm(pdrop if pdrop is not None else probs, dctx, dvv, T, dk, T, 1, T, 1, d, 3 * d,
+        self._side(lambda: ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                                     batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
                                     compute=cmp, colsum=sl[3 * d:] if fz else None, **csk))
         # dBD is laid out head-major [H][B][T][T] (bf16 mode): the gradient of linear_pos, sum_b dbd[b,h]^T (q+v)[b,h], is then ONE
@@ -535,7 +563,7 @@ class MLMEngine:
         # of being read off the dropped probabilities: one T x T read less in the most HBM-bound kernel of the step
         regen = self.bf16 and self.attn_regen and adr is not None and T % 8 == 0 and T <= 2048
         ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
-                               drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0)
+                               drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0, rowscale=rs)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
             dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
             if hm:
@@ -677,6 +705,8 @@ class MLMEngine:
         self.dims = (B, Tm, Tp, T)
         self._fused_now = self.fused_attn or (self.fused_attn_fwd_only and not need_grad) or \
             (self.fused_attn_auto and not need_grad and B * c.heads * ((T + 127) // 128) >= 64)
+        nblk = B * c.heads * ((T + 127) // 128)
+        self._fused_train_now = self.fused_attn_train and need_grad and not self._fused_now and 64 <= nblk <= 65536 and T <= 2048
         self.step_seed += 1
         self.refresh_weights()
         self._arena_clear("fwd64")

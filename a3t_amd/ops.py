@@ -252,13 +252,13 @@ def relpos_softmax_fwd(ac, bd, keymask, probs, B, H, T, scale, probs_drop=None, 
 
 
 def relpos_softmax_bwd(probs, dprobs, ds, dbd, B, H, T, scale, probs_drop=None, drop_p=0.0, dbd_head_major=False,
-                       drop_key=0):
+                       drop_key=0, rowscale=None):
     """ds/dbd share a dtype; ds may be dprobs itself (fp32 in place).  dbd_head_major: dbd is laid out [H][B][T][T].
     drop_p > 0 with probs_drop=None: the mask is regenerated from (drop_key, index) instead of read off probs_drop."""
     bsb, bsh = (T * T, B * T * T) if dbd_head_major else (0, 0)
     L.check(L.load().a3t_relpos_softmax_bwd(_ptr(probs), _dt(probs), _ptr(dprobs), _dt(dprobs), _ptr(ds), _ptr(dbd), _dt(dbd), B, H,
                                             T, T * T, T * T, T * T, scale, _ptr(probs_drop), drop_p, bsb, bsh, drop_key,
-                                            _stream()), "softmax_bwd")
+                                            _ptr(rowscale), _stream()), "softmax_bwd")
 
 
 def attn_fused_supported(dk, T):
@@ -275,6 +275,23 @@ def attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=(0.0, 0)):
     vv = qkv.view(-1)[2 * d:]
     L.check(L.load().a3t_attn_fwd(_ptr(qu), _ptr(qv), _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(ctx), _ptr(lse),
                                   B, H, T, dk, d, 3 * d, d, d, scale, drop[0], drop[1], _stream()), "attn_fwd")
+
+
+def attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, probs_drop, rowscale, B, H, T, scale, drop=(0.0, 0)):
+    """a3t_attn_fwd for training steps: also stores un-normalised probabilities (probs, probs_drop [B][H][T][T] bf16) and
+    rowscale [B][H][T] = 1 / row sum for the materialised backward."""
+    d = qu.shape[1]
+    dk = d // H
+    kk = qkv.view(-1)[d:]
+    vv = qkv.view(-1)[2 * d:]
+    L.check(L.load().a3t_attn_fwd_train(_ptr(qu), _ptr(qv), _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(ctx), _ptr(lse),
+                                        _ptr(probs), _ptr(probs_drop), _ptr(rowscale), B, H, T, dk, d, 3 * d, d, d, scale,
+                                        drop[0], drop[1], _stream()), "attn_fwd_train")
+
+
+def attn_scale_rows(x, rowscale, y, B, H, T):
+    d = x.shape[1]
+    L.check(L.load().a3t_attn_scale_rows(_ptr(x), _ptr(rowscale), _ptr(y), B, H, T, d // H, _stream()), "attn_scale_rows")
 
 
 def attn_delta(dctx, ctx, delta, B, H, T):

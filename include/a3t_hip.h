@@ -182,7 +182,9 @@ int a3t_relpos_softmax_fwd(const void* ac, const void* bd, int scores_dtype, con
 int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprobs, int dprobs_dtype, void* ds,
                            void* dbd, int out_dtype, int B, int H, int T, int64_t p_bs, int64_t dp_bs, int64_t o_bs,
                            float scale, const void* probs_drop, float drop_p, int64_t dbd_bs_b, int64_t dbd_bs_h,
-                           uint32_t drop_key, void* stream);
+                           uint32_t drop_key, const float* rowscale, void* stream);
+/* rowscale (optional, bf16 vector path): [B*H*T] fp32; probs then hold UN-normalised probabilities exp(s - m_ref) as
+ * written by a3t_attn_fwd_train and row r of probs is multiplied by rowscale[r] (= 1 / its row sum) on load. */
 /* drop_p > 0 with probs_drop == NULL (bf16 vector path): the dropout mask is regenerated from the counter RNG with drop_key
  * and the forward's element index instead of being read off the saved dropped probabilities. */
 /* dbd_bs_b / dbd_bs_h: strides (elements) of the (b, h) blocks of dbd; 0 / 0 = the [B][H][T][T] layout of ds.  The
@@ -202,6 +204,19 @@ int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, c
                  void* ctx, float* lse, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo,
                  float scale, float drop_p, uint32_t drop_key, void* stream);
 
+/* The same forward for TRAINING steps whose backward runs on materialised probabilities (a3t_relpos_softmax_bwd + the
+ * batched GEMMs): besides ctx / lse it stores, per score, probs = exp(s - m_ref) (bf16, UN-normalised: the reference
+ * maximum of a row is fixed at the first key tile that holds a valid key, there is no rescaling pass), probs_drop = the
+ * same after attention dropout (x 1/(1-p); NULL when drop_p == 0) and rowscale [B][H][T] = 1 / sum_j probs, the factor
+ * a consumer applies per row.  No logits (ac, bd) and no second softmax kernel: one launch replaces two GEMMs, the
+ * softmax and probs @ V of attention.py:190-209, 78-96.  probs / probs_drop: [B][H][T][T], 8-byte aligned, T % 8 == 0. */
+int a3t_attn_fwd_train(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
+                       const uint8_t* keymask, void* ctx, float* lse, void* probs, void* probs_drop, float* rowscale,
+                       int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo, float scale,
+                       float drop_p, uint32_t drop_key, void* stream);
+/* y[r][h*dk + c] = x[r][h*dk + c] * rowscale[(b*H + h)*T + i], r = b*T + i: folds the row normalisation of
+ * a3t_attn_fwd_train's probabilities into the dctx operand of dV = probs_drop^T dctx (attention.py:96 backward). */
+int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y, int B, int H, int T, int dk, void* stream);
 /* Backward of a3t_attn_fwd (the autograd graph of attention.py:167-209 restated): probabilities are recomputed from
  * lse, nothing T x T is read.
  *   a3t_attn_delta: delta[b][h][i] = sum_d dctx * ctx (= sum_j dP_ij P_ij, with or without dropout).

@@ -310,8 +310,8 @@ def test_forward_only_passes_take_the_fused_kernel_by_default(monkeypatch):
     small = {k: v[:2].contiguous() for k, v in batch.items()}
     eng.forward(small, need_grad=False)                             # 8 workgroups: materialised
     assert not any(k.endswith(".fused") for k in eng.sv)
-    eng.forward(batch, need_grad=True)                              # gradients wanted: materialised
-    assert not any(k.endswith(".fused") for k in eng.sv)
+    eng.forward(batch, need_grad=True)                              # gradients wanted: fused forward that saves probabilities
+    assert not any(k.endswith(".fused") for k in eng.sv) and sum(k.endswith(".rs") for k in eng.sv) == 3
     eng.fused_attn_auto = False
     mat_after = eng.forward(batch, need_grad=False)["after"].float()
     scale = float(mat_after.abs().max())
@@ -320,3 +320,88 @@ def test_forward_only_passes_take_the_fused_kernel_by_default(monkeypatch):
         _, _, ra = O.forward_loss(O.to_torch_state(state), cpu_batch, oc, False)
     err = (fused_after.cpu().reshape(ra.shape) - ra)
     assert float(err.pow(2).mean().sqrt()) < 1e-2 * scale and float(err.abs().max()) < 6e-2 * scale
+
+
+# ---- round 4: the training forward (a3t_attn_fwd_train) -------------------------------------------------------------------
+@pytest.mark.parametrize("drop_p", [0.0, 0.2])
+@pytest.mark.parametrize("B,H,T,dk,lengths", CASES[:4] + [(2, 2, 328, 192, [328, 0]), (1, 2, 296, 64, [200])])
+def test_training_forward_saves_probabilities_the_materialised_backward_can_use(B, H, T, dk, lengths, drop_p):
+    """probs * rowscale = the exact softmax (bf16 accuracy), probs_drop = probs under the counter-RNG mask x 1/(1-p) (the mask
+    a3t_relpos_softmax_fwd draws), ctx / lse identical to a3t_attn_fwd, all-masked utterances -> zeros, rowscale 0."""
+    from a3t_amd import ops
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=5 * T + dk, lengths=lengths)
+    if lengths is not None and len(lengths) == 1:       # a hole in the middle of the key mask and masked leading tiles
+        keymask[0, :40] = 0
+        keymask[0, 120:150] = 0
+    d = H * dk
+    drop = (drop_p, 0x1234567)
+    ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+    ctx2 = torch.zeros_like(ctx)
+    lse, lse2 = torch.zeros(B, H, T, device=DEV), torch.zeros(B, H, T, device=DEV)
+    probs = torch.full((B, H, T, T), 9.0, device=DEV, dtype=torch.bfloat16)
+    pdrop = torch.full((B, H, T, T), 9.0, device=DEV, dtype=torch.bfloat16) if drop_p else None
+    rs = torch.full((B, H, T), -1.0, device=DEV)
+    ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk), drop=drop)
+    ops.attn_fwd(qu, qv, qkv, P, keymask, ctx2, lse2, B, H, T, 1.0 / math.sqrt(dk), drop=drop)
+    torch.cuda.synchronize()
+    assert torch.equal(ctx, ctx2) and torch.equal(lse, lse2)
+    _, pr, rlse = _exact(qkv, qu, qv, P, keymask, B, H, T, dk)
+    got = probs.float().cpu().double() * rs.cpu().double()[..., None]
+    assert bool(torch.isfinite(got).all())
+    err = float((got - pr).abs().max())
+    print(f"[B{B} H{H} T{T} dk{dk} p{drop_p}] normalised saved probabilities: max err {err:.2e}")
+    assert err < 6e-3                                  # bf16 probabilities (relative 2^-9) of rows that sum to 1
+    valid = torch.isfinite(rlse)
+    assert float(rs.cpu()[~valid].abs().max() if (~valid).any() else 0.0) == 0.0
+    if drop_p:
+        mat, mprobs, mpdrop = _materialised(qkv, qu, qv, P, keymask, B, H, T, dk, drop)
+        keep = (mpdrop.float().cpu() != 0) | (mprobs.float().cpu() == 0)
+        want = probs.float().cpu() * keep / (1.0 - drop_p)
+        gotd = pdrop.float().cpu()
+        rel = float(((gotd - want).abs() / (want.abs() + 1e-20)).max())
+        assert rel < 1e-2, rel                        # same mask; one more bf16 rounding
+
+
+@pytest.mark.parametrize("dropout", [False, True])
+def test_engine_training_step_with_the_fused_forward_matches_the_materialised_step(dropout, monkeypatch):
+    """Default training path of round 4 (fused forward that saves un-normalised probabilities + materialised backward) against
+    the fully materialised step: same dropout masks, loss and every parameter gradient to bf16 accuracy."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.params import ParamStore
+    monkeypatch.delenv("A3T_FUSED_ATTN", raising=False)
+    oc = O.A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
+    c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab,
+                  dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
+    state = O.procedural_state(O.param_shapes(oc), 5)
+    B = 16
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(oc, B=B, T_mel=232, T_phn=24, seed=9, lengths=[232] * 10 + [141, 77, 200, 99, 232, 8],
+                                                        text_lengths=[24] * 10 + [17, 9, 24, 11, 24, 3]).items()}
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("A3T_FUSED_ATTN_TRAIN", fused)
+        store = ParamStore(c, DEV)
+        store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+        eng = MLMEngine(c, store, compute="bf16", training=True, dropout=dropout)
+        assert eng.fused_attn_train == (fused == "1")
+        loss = float(eng.forward(batch)["loss"])
+        assert sum(k.endswith(".rs") for k in eng.sv) == (3 if fused == "1" else 0)
+        store.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        res[fused] = (loss, store.state_dict(grads=True))
+    l0, g0 = res["0"]
+    l1, g1 = res["1"]
+    print(f"loss materialised {l0:.5f} fused-forward {l1:.5f}")
+    assert abs(l0 - l1) < 5e-3 * abs(l0), (l0, l1)
+    bad = []
+    for k in g0:
+        a, b_ = g1[k].double().flatten(), g0[k].double().flatten()
+        nb = float(b_.norm())
+        if nb < 1e-6 or k.endswith("depthwise_conv.bias") or k.endswith("linear_k.bias"):
+            continue
+        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
+        ratio = float(a.norm()) / nb
+        if cos < 0.985 or not (0.93 < ratio < 1.07):
+            bad.append((k, round(cos, 4), round(ratio, 4)))
+    assert not bad, bad[:10]
