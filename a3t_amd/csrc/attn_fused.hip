@@ -85,7 +85,19 @@ __device__ __forceinline__ bf16x8 zero_frag() {
 // vmcnt(0) at the join, which serialises every prefetch behind it.
 static __device__ __attribute__((aligned(16))) unsigned int attn_zero_page[8];
 // per 128-query block of the last a3t_attn_fwd launch: 1 = the fixed-reference kernel overflowed, recompute with the rescaling one
+#ifndef A3T_SAVE_AUX
+#define A3T_SAVE_AUX 0   // (nt = 2 measured: 348 us instead of 290 -- the L2 merges the 32-byte pieces of a line)
+#endif
 static __device__ int attn_redo[1 << 16];
+
+// LDS-DMA piece (64 lanes x 16 B -> 1 KiB at lds_addr) as inline asm ON PURPOSE: for the builtin the compiler tracks "an LDS
+// write is in flight" and, because every tile pointer is an offset into the one dynamic LDS array, puts a vmcnt wait for ALL
+// outstanding DMA in front of the next LDS read that might alias -- i.e. in the middle of the iteration that issued it
+// (measured: +80 us per launch).  The kernels below wait for their DMA themselves (counted vmcnt + s_barrier).
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, const void* lds_ptr, unsigned voff) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_AS(lds_ptr));
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(r) : "memory");
+}
 __device__ __forceinline__ bf16x8 ld_frag_g(const u16* p, bool ok) {
     const u16* src = ok ? p : (const u16*)attn_zero_page;
     return *(const bf16x8*)src;
@@ -943,22 +955,24 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         dcol[q] = (unsigned)((pos ^ D::sw(row)) * 16);
         voffK[q] = (unsigned)row * ldkv2 + dcol[q];
     }
+    auto issue_kv1 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s, const int q) __attribute__((always_inline)) {
+        if (q < NPW || (q * 4 + w) * 1024 < TB)
+            dma16(r, tile + (q * 4 + w) * 1024, voffK[q] + (unsigned)(32 * s) * ldkv2);
+    };
+    auto issue_p1 = [&](int u, const int q) __attribute__((always_inline)) {
+        if (q < NPW || (q * 4 + w) * 1024 < TB) {
+            const int x = X0 + 32 * (u - 3) + drow[q];
+            const int xr = x < T ? x : x - T - 1;
+            dma16(rP, Pr + (u % 6) * TB + (q * 4 + w) * 1024, (unsigned)xr * ldp2 + dcol[q]);
+        }
+    };
     auto issue_kv = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s) __attribute__((always_inline)) {
-        const unsigned step = (unsigned)(32 * s) * ldkv2;
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (q < NPW || (q * 4 + w) * 1024 < TB)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_AS(tile + (q * 4 + w) * 1024), 16, voffK[q] + step, 0, 0, 0);
+        for (int q = 0; q < 3; ++q) issue_kv1(r, tile, s, q);
     };
     auto issue_p = [&](int u) __attribute__((always_inline)) {
-        unsigned char* tile = Pr + (u % 6) * TB;
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-            if (q < NPW || (q * 4 + w) * 1024 < TB) {
-                const int x = X0 + 32 * (u - 3) + drow[q];
-                const int xr = x < T ? x : x - T - 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, LDS_AS(tile + (q * 4 + w) * 1024), 16, (unsigned)xr * ldp2 + dcol[q], 0, 0, 0);
-            }
+        for (int q = 0; q < 3; ++q) issue_p1(u, q);
     };
     // K(s0), K(s0+1), V(s0), ring tiles s0 .. s0+5
     issue_kv(rK, Kb + (s0 & 1) * TB, s0);
@@ -975,20 +989,33 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         fqvL[kk] = ld_frag_g(qvB + (int64_t)i * p.ldq + off, i < T);
         fqvU[kk] = ld_frag_g(qvB + (int64_t)(i + 1) * p.ldq + off, i + 1 < T);
     }
-    __syncthreads();                                      // (waits for the DMA: vmcnt(0) + barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA (invisible to the compiler) and the fragment loads
+    __syncthreads();
 
     // ---- fragment addressing -------------------------------------------------------------------------------------------
     const int swr = D::sw(lr);
     auto frag_rows = [&](const unsigned char* tile, const int kk) __attribute__((always_inline)) -> bf16x8 {
         return *(const bf16x8*)(tile + lr * RB + (((2 * kk + lh) ^ swr) << 4));
     };
-    // transposed fragment A[m = col0 + (lane&31)][k slots e<4: row krow0 + 4 lh + e, e>=4: row krow0 + 8 + 4 lh + e-4]
+    // transposed fragment A[m = col0 + (lane&31)][k slots e<4: row krow0 + 4 lh + e, e>=4: row krow0 + 8 + 4 lh + e-4], col0 = 32 d.
+    // Chunk of this lane's column = 4 d + c0 (c0 < 4); the swizzle XORs c0 with its low two bits and, when it has three
+    // bits, d's parity with its third: 64 (d ^ b) = 64 d + 64 b (1 - 2 (d & 1)) -> one per-lane base per (row set, parity of d),
+    // everything else is an immediate offset
     const int gq = lane >> 4, pp = lane & 15;
     const int tr_r0 = 4 * (gq >> 1) + (pp >> 2), tr_c = 16 * (gq & 1) + 4 * (pp & 3);
-    auto frag_cols = [&](const unsigned char* tile, const int krow0, const int col0) __attribute__((always_inline)) -> bf16x8 {
-        const int r0 = krow0 + tr_r0, r1 = r0 + 8, col = col0 + tr_c;
-        const unsigned char* a0 = tile + r0 * RB + (((col >> 3) ^ D::sw(r0)) << 4) + (col & 7) * 2;
-        const unsigned char* a1 = tile + r1 * RB + (((col >> 3) ^ D::sw(r1)) << 4) + (col & 7) * 2;
+    int trb[2][2][2];                                     // [krow0 / 16][row r0 | r0 + 8][parity of d]
+#pragma unroll
+    for (int kr = 0; kr < 2; ++kr)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int r = 16 * kr + 8 * hf + tr_r0, sw = D::sw(r);
+            const int base = r * RB + ((((tr_c >> 3) ^ sw) & 3) << 4) + (tr_c & 7) * 2;
+            const int bflip = (D::SWB == 3) ? ((sw >> 2) & 1) * 64 : 0;
+            trb[kr][hf][0] = base + bflip, trb[kr][hf][1] = base - bflip;
+        }
+    auto frag_cols = [&](const int vt, const int kr, const int d) __attribute__((always_inline)) -> bf16x8 {   // vt: tile offset in smem
+        const unsigned char* a0 = smem + (vt + trb[kr][0][d & 1]) + 64 * d;
+        const unsigned char* a1 = smem + (vt + trb[kr][1][d & 1]) + 64 * d;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a1));
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1051,11 +1078,15 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     }
 
 #ifdef A3T_ATTN_TIMING
-    unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+    unsigned long long tacc[32] = {}, tprev = __builtin_readcyclecounter();
 #define TSTAMP(k) do { PHASE_FENCE(); const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; PHASE_FENCE(); } while (0)
 #else
 #define TSTAMP(k) ((void)0)
 #endif
+    const int ttb = (int)((unsigned)T * (unsigned)T * 2u);
+    const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(SAVE ? (void*)(p.probs + (int64_t)bh * T * T) : (void*)p.ctx, 0, ttb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSD = __builtin_amdgcn_make_buffer_rsrc((SAVE && DROP) ? (void*)(p.pdrop + (int64_t)bh * T * T) : (void*)p.ctx, 0, ttb, 0x00020000);
+    const unsigned svoff = i < T ? ((unsigned)i * (unsigned)T + 8u * lh) * 2u : 0x80000000u;
     f32x16 O[NDB];
 #pragma unroll
     for (int d = 0; d < NDB; ++d) O[d] = zero16();
@@ -1067,48 +1098,64 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     // (three staging pairs); the softmax of step s is cut into slices that ride on the first KS stages, the hand-over of step
     // s+1 (band block to the scratch, skewed read back) on the PV stages.  sched_barriers pin the slices to their stages --
     // left alone the scheduler emits [12 dependent MFMAs][12 dependent MFMAs][softmax][PV] with a one-deep LDS lookahead.
-    auto iteration = [&](auto UP, const int s) __attribute__((always_inline)) {
+    constexpr int NSTG = KS + NDB;
+    bf16x8 st[3][2];
+    bf16x8 pf0, pf1;
+    f32x16 Sn, Bn;
+    auto rd = [&](const int t, const unsigned char* Kt, const unsigned char* slot, const int Vt) __attribute__((always_inline)) {
+        if (t < KS) {
+            st[t % 3][0] = frag_rows(Kt, t);
+            st[t % 3][1] = frag_rows(slot, t);
+        } else if (t < NSTG) {
+            st[t % 3][0] = frag_cols(Vt, 0, t - KS);
+            st[t % 3][1] = frag_cols(Vt, 1, t - KS);
+        }
+    };
+    // product stages of step s+1 + the softmax of step s; two copies (the new band block takes (q+v)[i] or (q+v)[i+1]).  The PV
+    // stages below exist ONCE: with two copies of them the accumulators O get two register homes and 96 moves per iteration.
+    auto products = [&](auto UP, const int s) __attribute__((always_inline)) {
         constexpr bool up = decltype(UP)::value;
-        constexpr int NSTG = KS + NDB;
         const unsigned char* Kt = Kb + ((s + 1) & 1) * TB;
-        const unsigned char* Vt = Vb + (s & 1) * TB;
+        const int Vt = 2 * TB + (s & 1) * TB;
         const int un = s + 1 - w + 4;                     // the one new band block of step s+1
         const unsigned char* slot = Pr + (un % 6) * TB;
         const unsigned int vm = kmw[s] >> (4 * lh);       // bit (r & 3) + 8 (r >> 2) = this lane's key of register r
-        bf16x8 st[3][2];
-        f32x16 Sn = zero16(), Bn = zero16();
+        Sn = zero16(), Bn = zero16();
         float pv[16];
-        bf16x8 pf0, pf1;
         float psum = 0.f;
-        auto rd = [&](const int t) __attribute__((always_inline)) {
-            if (t < KS) {
-                st[t % 3][0] = frag_rows(Kt, t);
-                st[t % 3][1] = frag_rows(slot, t);
-            } else if (t < NSTG) {
-                st[t % 3][0] = frag_cols(Vt, 0, 32 * (t - KS));
-                st[t % 3][1] = frag_cols(Vt, 16, 32 * (t - KS));
-            }
-        };
         auto expo = [&](const int r) __attribute__((always_inline)) {
             const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[r] + bd[r], sl2, -m2));
             pv[r] = ((vm >> ((r & 3) + 8 * (r >> 2))) & 1u) ? e : 0.f;
             psum += pv[r];
         };
-        u16* prow = SAVE ? p.probs + ((int64_t)bh * T + (i < T ? i : 0)) * T + 32 * s + 4 * lh : nullptr;
-        u16* drow_ = (SAVE && DROP) ? p.pdrop + ((int64_t)bh * T + (i < T ? i : 0)) * T + 32 * s + 4 * lh : nullptr;
-        const bool rowok = i < T;
-        auto save4 = [&](u16* base, const int g) __attribute__((always_inline)) {   // this lane's 4 consecutive keys of quad g
-            if (rowok && 32 * s + 8 * g + 4 * lh < T) st4_bf16(base + 8 * g, pv[4 * g], pv[4 * g + 1], pv[4 * g + 2], pv[4 * g + 3]);
+        // saved probabilities go out as buffer stores: always exactly one instruction per PAIR of quads (rows / columns outside
+        // the tensor are dropped by the range check), so the end-of-iteration wait can be COUNTED -- vmcnt(number of stores)
+        // waits for the tile DMAs issued before them and not for the write acknowledgements.  A lane holds keys 4 lh .. +3 of
+        // quads 2 h, 2 h + 1; v_permlane32_swap trades one quad with lane +-32 so that it stores 8 consecutive keys (16 B) and
+        // a row gets a full 32-byte sector per instruction (8-byte pieces: 290 us instead of 235 for the two saved tensors).
+        auto save8 = [&](const __amdgpu_buffer_rsrc_t& r, const int hq) __attribute__((always_inline)) {
+            typedef int v4i_ __attribute__((ext_vector_type(4)));
+            const int g0 = 2 * hq, g1 = g0 + 1;
+            const unsigned a0 = io_pack2(pv[4 * g0], pv[4 * g0 + 1]), a1 = io_pack2(pv[4 * g0 + 2], pv[4 * g0 + 3]);
+            const unsigned b0 = io_pack2(pv[4 * g1], pv[4 * g1 + 1]), b1 = io_pack2(pv[4 * g1 + 2], pv[4 * g1 + 3]);
+            const auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            // lanes < 32: own quad g0 (keys 16 hq + 0..3) + the partner's g0 (keys + 4..7); lanes >= 32: partner's g1 + own g1 (keys 16 hq + 8..15)
+            v4i_ dta;
+            dta[0] = (int)x0[0], dta[1] = (int)x1[0], dta[2] = (int)x0[1], dta[3] = (int)x1[1];
+            const unsigned vo = (32 * s + 16 * hq + 8 * lh < T) ? svoff + (unsigned)(64 * s + 32 * hq) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(dta, r, vo, 0, A3T_SAVE_AUX);
         };
         auto drop4 = [&](const int g) __attribute__((always_inline)) {
-            if (SAVE) save4(prow, g);
             if (DROP) {
                 bool kp[4];
                 rng_keep4(p.drop_key, ibase + (unsigned int)(32 * s + 8 * g + 4 * lh), p.drop_thr, kp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pv[4 * g + e] = kp[e] ? pv[4 * g + e] * p.drop_inv : 0.f;
-                if (SAVE) save4(drow_, g);
             }
+        };
+        auto dsave = [&](const int g) __attribute__((always_inline)) {
+            if (SAVE && DROP && (g & 1)) save8(rSD, g >> 1);
         };
         // softmax slices over the KS product stages: exponentials first, then the dropout quads, then the packing
         constexpr int EXS = KS >= 8 ? KS - 4 : (KS > 1 ? KS - 1 : 1);        // stages that carry exponentials
@@ -1117,56 +1164,83 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r)
                 if (r * EXS / 16 == t) expo(r);
             if (KS >= 8) {
-                if (t >= KS - 4) drop4(t - (KS - 4));
+                if (t == KS - 5 && SAVE) save8(rSP, 0), save8(rSP, 1);           // (all sixteen exponentials are done after stage EXS - 1 = KS - 5)
+                if (t >= KS - 4) drop4(t - (KS - 4)), dsave(t - (KS - 4));
             } else if (t == KS - 1) {
+                if (SAVE) save8(rSP, 0), save8(rSP, 1);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) drop4(g);
+                for (int g = 0; g < 4; ++g) drop4(g), dsave(g);
             }
             if (t == KS - 1) pf0 = pack_frag(pv), pf1 = pack_frag(pv + 8);
         };
-        rd(0);
-        rd(1);
+        rd(0, Kt, slot, Vt);
+        rd(1, Kt, slot, Vt);
         PHASE_FENCE();
 #pragma unroll
-        for (int t = 0; t < NSTG; ++t) {
-            if (t == KS) TSTAMP(2);
-            rd(t + 2);
-            if (t < KS) {
-                Sn = mfma32(st[t % 3][0], fqu[t], Sn);
-                Bn = mfma32(st[t % 3][1], up ? fqvU[t] : fqvL[t], Bn);
-                slice(t);
-            } else {
-                const int d = t - KS;
-                O[d] = mfma32(st[t % 3][0], pf0, O[d]);
-                O[d] = mfma32(st[t % 3][1], pf1, O[d]);
-                if (d == 0) band_store(un, Bn);
-                if (d == 1 || NDB == 1) band_read(un - 1, bd);
+        for (int t = 0; t < KS; ++t) {
+            TSTAMP(5 + t);
+            rd(t + 2, Kt, slot, Vt);
+            Sn = mfma32(st[t % 3][0], fqu[t], Sn);
+            Bn = mfma32(st[t % 3][1], up ? fqvU[t] : fqvL[t], Bn);
+            // this iteration's tile DMA, one 1-KiB piece per stage (an LDS-DMA instruction holds the issue port for 50-150
+            // cycles: under the MFMAs here, not in front of them): K(s+2), V(s+1), ring tile s+6 -- all three targets were
+            // last read in iteration s-1
+            if (KS >= 9) {
+                if (t < 3) issue_kv1(rK, Kb + (s & 1) * TB, s + 2, t);
+                else if (t < 6) issue_kv1(rV, Vb + ((s + 1) & 1) * TB, s + 1, t - 3);
+                else if (t < 9) issue_p1(s + 6, t - 6);
+            } else if (t == 0) {
+                issue_kv(rK, Kb + (s & 1) * TB, s + 2);
+                issue_kv(rV, Vb + ((s + 1) & 1) * TB, s + 1);
+                issue_p(s + 6);
             }
+            slice(t);
+            PHASE_FENCE();
+        }
+        l_run += psum;
+    };
+    auto pv_stages = [&](const int s) __attribute__((always_inline)) {
+        const int Vt = 2 * TB + (s & 1) * TB;
+        const int un = s + 1 - w + 4;
+#pragma unroll
+        for (int t = KS; t < NSTG; ++t) {
+            TSTAMP(5 + t);
+            rd(t + 2, nullptr, nullptr, Vt);
+            const int d = t - KS;
+            O[d] = mfma32(st[t % 3][0], pf0, O[d]);
+            O[d] = mfma32(st[t % 3][1], pf1, O[d]);
+            if (d == 0) band_store(un, Bn);
+            if (d == 1 || NDB == 1) band_read(un - 1, bd);
             PHASE_FENCE();
         }
         TSTAMP(3);
-        l_run += psum;
         Sc = Sn;
     };
     typedef std::integral_constant<bool, false> FalseT;
     typedef std::integral_constant<bool, true> TrueT;
+    constexpr int NSV = SAVE ? (DROP ? 4 : 2) : 0;      // probability stores per iteration
 
     for (int s = s0; s < NS; ++s) {
         // resident: K(s+1), V(s), ring tiles s+1 .. s+5; registers: Sc = S(s), bd = band values of step s
         TSTAMP(0);
-        issue_kv(rK, Kb + (s & 1) * TB, s + 2);           // all three targets were last read in iteration s-1
-        issue_kv(rV, Vb + ((s + 1) & 1) * TB, s + 1);
-        issue_p(s + 6);
         TSTAMP(1);
-        if (use_upper(s + 1 - w + 4)) iteration(TrueT(), s);
-        else iteration(FalseT(), s);
-        __syncthreads();                                  // DMA of this iteration landed (vmcnt(0)), everyone done reading
+        if (use_upper(s + 1 - w + 4)) products(TrueT(), s);
+        else products(FalseT(), s);
+        pv_stages(s);
+        // the DMA of this iteration has landed (it is older than the NSV probability stores), everyone is done reading
+        PHASE_FENCE();
+        if (NSV == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if (NSV == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        PHASE_FENCE();
         TSTAMP(4);
     }
 #ifdef A3T_ATTN_TIMING
     if (lane == 0 && p.dbd) {
-        unsigned long long* o = (unsigned long long*)p.dbd + ((int64_t)blockIdx.x * 4 + w) * 8;
-        o[0] = tacc[0], o[1] = tacc[1], o[2] = tacc[2], o[3] = tacc[3], o[4] = tacc[4], o[5] = (unsigned long long)(NS - s0);
+        unsigned long long* o = (unsigned long long*)p.dbd + ((int64_t)blockIdx.x * 4 + w) * 32;
+        for (int e = 0; e < 31; ++e) o[e] = tacc[e];
+        o[31] = (unsigned long long)(NS - s0);
     }
 #endif
 

@@ -16,6 +16,11 @@ qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=1)
 ctx = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
 lse = torch.zeros(B, H, T, device="cuda")
 fn = lambda: ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=DROP)
+if os.environ.get("TRAIN") == "1":
+    probs = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+    pdrop = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+    rs = torch.zeros(B, H, T, device="cuda")
+    fn = lambda: ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk), drop=DROP)
 x = torch.randn(4096, 4096, device="cuda")
 for _ in range(20):
     x @ x          # clocks up
@@ -29,4 +34,4 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
-print(f"EXP={os.environ.get('A3T_ATTN_EXP', '0')} MODE={os.environ.get('A3T_ATTN_FWD', '32')} fwd {us:.1f} us  {3 * 2.0 * B * H * T * T * dk / us / 1e6:.0f} TFLOP/s")
+print(f"TRAIN={os.environ.get('TRAIN', '0')} EXP={os.environ.get('A3T_ATTN_EXP', '0')} MODE={os.environ.get('A3T_ATTN_FWD', '32')} fwd {us:.1f} us  {3 * 2.0 * B * H * T * T * dk / us / 1e6:.0f} TFLOP/s")
