@@ -96,6 +96,8 @@ _SIGS = {
     "a3t_replicate_pad": [_P, _P, c_int64, c_int64, c_int, c_int, _P],
     "a3t_bias_act": [_P, _P, c_int64, c_int, c_int, c_float, _P],
     "a3t_dropout": [_P, c_int, _P, c_int, c_int64, c_float, ctypes.c_uint32, c_float, _P],
+    "a3t_collate_paint": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "a3t_segment_colsum": [_P, _P, c_int, c_int, c_int, _P],
     "a3t_gemm_8p_mode": [c_int],
     "a3t_gemm_8p_supported": [c_int, c_int, c_int, c_int, c_int],
     "a3t_gemm_pn_mode": [c_int],

@@ -6,6 +6,7 @@ numpy global RNG, segment ids) is inherently host-side in the reference too (Dat
 it is restated here in vectorised numpy.  Feature extraction (STFT -> mel -> log10) runs on the
 GPU through liba3t_hip (a3t_amd/features.py) when a device is given.
 """
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -73,6 +74,46 @@ def phones_masking(T_mel: int, speech_nonpad: np.ndarray, align_start: np.ndarra
     return mp & speech_nonpad.astype(bool)
 
 
+def masking_plan(T_mel: int, align_lens: Sequence[int], mlm_prob: float, mean_phn_span: int, P: int,
+                 span_boundary: Optional[np.ndarray] = None):
+    """The host half of phones_masking for the on-device collate: consumes the numpy global RNG exactly like phones_masking
+    (same calls in the same order) and returns what it decided as integers -- sel [B][P] uint8 (phone j of utterance b is
+    masked) and explicit frame spans mspan [B][S][2] int32 / nms [B] (span_boundary, mean_phn_span == 0, mlm_prob == 1)."""
+    B = len(align_lens)
+    sel = np.zeros((B, max(P, 1)), dtype=np.uint8)
+    spans = [[] for _ in range(B)]
+    if mlm_prob == 1.0:
+        for b in range(B):
+            spans[b].append((0, T_mel))
+    elif mean_phn_span == 0:
+        span = min(T_mel * mlm_prob // 3, 50)
+        noise = random_spans_noise_mask(T_mel, mlm_prob, span)
+        edges = np.flatnonzero(np.diff(np.concatenate([[0], noise.astype(np.int8), [0]])))
+        runs = list(zip(edges[0::2], edges[1::2]))
+        for b in range(B):
+            spans[b].extend(runs)
+    else:
+        for b in range(B):
+            if span_boundary is not None:
+                sb = np.asarray(span_boundary[b]).astype(np.int64)
+                spans[b].extend(zip(sb[0::2], sb[1::2]))
+                continue
+            L = int(align_lens[b])
+            if L < 2:
+                continue
+            sel[b, :L] = random_spans_noise_mask(L, mlm_prob, mean_phn_span)
+    S = max(1, max(len(x) for x in spans))
+    mspan = np.zeros((B, S, 2), dtype=np.int32)
+    nms = np.zeros(B, dtype=np.int32)
+    for b in range(B):
+        nms[b] = len(spans[b])
+        for q, (s0, e0) in enumerate(spans[b]):
+            # python slice semantics of mp[b, s:e]: negative indices count from the end, out-of-range ones clip
+            s0, e0, _ = slice(int(s0), int(e0)).indices(T_mel)
+            mspan[b, q] = (s0, e0)
+    return sel, mspan, nms
+
+
 def get_segment_pos(T_mel: int, T_phn: int, align_start, align_end, align_lens, sega_emb: bool = True):
     """collate_fn.py:330-343 (later phones overwrite earlier ones where spans overlap)."""
     B = len(align_lens)
@@ -104,7 +145,8 @@ class MLMCollateFn:
     text_segment_pos, speech_lengths, text_lengths))."""
 
     def __init__(self, feats_extract, float_pad_value=0.0, int_pad_value=0, not_sequence=(), mlm_prob=0.8,
-                 mean_phn_span=8, attention_window=0, pad_speech=False, sega_emb=False, duration_collect=False):
+                 mean_phn_span=8, attention_window=0, pad_speech=False, sega_emb=False, duration_collect=False,
+                 device_out=False):
         if attention_window or duration_collect:
             raise NotImplementedError("longformer window / duration collect are outside the A3T recipe path")
         self.feats_extract = feats_extract
@@ -114,6 +156,10 @@ class MLMCollateFn:
         self.mlm_prob = mlm_prob
         self.mean_phn_span = mean_phn_span
         self.sega_emb = sega_emb
+        # device_out (extension): with a GPU feature extractor the whole batch dict is built and RETURNED
+        # on the device -- features never visit the host, masks / segment ids are painted by a3t_collate_paint from the
+        # integer span lists; only the numpy-RNG draws run on the host.  Same values, bit for bit, as the host path.
+        self.device_out = bool(device_out)
 
     def __call__(self, data):
         uids = [u for u, _ in data]
@@ -122,14 +168,19 @@ class MLMCollateFn:
         for k in ("text", "align_start", "align_end"):
             if k not in ds[0]:
                 raise NotImplementedError("speech-only batches are outside the A3T recipe path")
-        speech = pad_list([d["speech"] for d in ds], self.float_pad_value)
         slen = np.array([d["speech"].shape[0] for d in ds], dtype=np.int64)
+        if self.device_out and getattr(self.feats_extract, "device", None) is not None and \
+                torch.device(self.feats_extract.device).type == "cuda" and ds[0]["speech"].ndim == 1:
+            return uids, self._device_pipeline(ds, slen)
+        speech = pad_list([d["speech"] for d in ds], self.float_pad_value)
         text = pad_list([d["text"] for d in ds], self.int_pad_value)
         tlen = np.array([d["text"].shape[0] for d in ds], dtype=np.int64)
         a_s = pad_list([d["align_start"] for d in ds], self.float_pad_value)
         a_e = pad_list([d["align_end"] for d in ds], self.float_pad_value)
         alen = np.array([d["align_start"].shape[0] for d in ds], dtype=np.int64)
         feats, flen = self.feats_extract(torch.from_numpy(speech), torch.from_numpy(slen))
+        if self.device_out and feats.is_cuda:
+            return uids, self._finish_on_device(ds, feats, flen, text, tlen, a_s, a_e, alen, slen)
         feats = feats.cpu()
         flen_np = flen.cpu().numpy()
         fs_ = align_to_frames(a_s, self.feats_extract.fs, self.feats_extract.hop_length)
@@ -148,6 +199,91 @@ class MLMCollateFn:
                    text_segment_pos=torch.from_numpy(tp), speech_lengths=torch.from_numpy(slen),
                    text_lengths=torch.from_numpy(tlen))
         return uids, out
+
+
+def _collate_finish_on_device(self, ds, feats, flen, text, tlen, a_s, a_e, alen, slen):
+    from . import ops
+    dev = feats.device
+    flen_np = flen.cpu().numpy() if flen.is_cuda else flen.numpy()       # (lengths are computed on the host: no sync)
+    fe_x = self.feats_extract
+    fs_ = align_to_frames(a_s, fe_x.fs, fe_x.hop_length)
+    fe_ = align_to_frames(a_e, fe_x.fs, fe_x.hop_length)
+    max_slen = int(flen_np.max())
+    B, T_phn, P = text.shape[0], text.shape[1], fs_.shape[1]
+    sb = pad_list([d["span_boundary"] for d in ds], 0) if "span_boundary" in ds[0] else None
+    sel, mspan, nms = masking_plan(max_slen, alen, self.mlm_prob, self.mean_phn_span, P, sb)
+    # one small H2D copy for all the integer side inputs
+    ints = np.concatenate([fs_.reshape(-1), fe_.reshape(-1), alen.astype(np.int32), mspan.reshape(-1), nms,
+                           flen_np.astype(np.int32), tlen.astype(np.int32)]).astype(np.int32)
+    di = torch.from_numpy(ints).to(dev, non_blocking=True)
+    o = 0
+    def take(n, shape):
+        nonlocal o
+        v = di[o:o + n].view(shape)
+        o += n
+        return v
+    d_fs, d_fe = take(B * P, (B, P)), take(B * P, (B, P))
+    d_alen = take(B, (B,))
+    d_ms = take(mspan.size, mspan.shape)
+    d_nms, d_flen, d_tlen = take(B, (B,)), take(B, (B,)), take(B, (B,))
+    d_sel = torch.from_numpy(sel).to(dev, non_blocking=True)
+    masked = torch.empty(B, max_slen, dtype=torch.uint8, device=dev)
+    smask = torch.empty(B, max_slen, dtype=torch.uint8, device=dev)
+    tmask = torch.empty(B, T_phn, dtype=torch.uint8, device=dev)
+    sp = torch.empty(B, max_slen, dtype=torch.int64, device=dev)
+    tp = torch.empty(B, T_phn, dtype=torch.int64, device=dev)
+    ops.collate_paint(d_fs, d_fe, d_alen, d_sel, d_ms, d_nms, d_flen, d_tlen, masked, smask, tmask, sp, tp, self.sega_emb)
+    return dict(speech=feats[:, :max_slen], text=torch.from_numpy(text).to(dev, non_blocking=True),
+                masked_position=masked.view(torch.bool), speech_mask=smask.view(torch.bool)[:, None, :],
+                text_mask=tmask.view(torch.bool)[:, None, :], speech_segment_pos=sp, text_segment_pos=tp,
+                speech_lengths=torch.from_numpy(slen).to(dev, non_blocking=True),
+                text_lengths=torch.from_numpy(tlen).to(dev, non_blocking=True))
+
+
+def _collate_device_pipeline(self, ds, slen):
+    """device_out with raw waveforms: utterances are padded straight into a pinned staging buffer in chunks, each chunk goes
+    to the device asynchronously and through STFT -> mel -> log10 while the host pads the next one (the host-side memcpy of
+    4 B / sample is the longest stage; PCIe and the GPU hide behind it)."""
+    fe_x = self.feats_extract
+    dev = torch.device(fe_x.device)
+    B, N = len(ds), int(slen.max())
+    key = (B, N)
+    if getattr(self, "_pin_key", None) != key:
+        self._pin = torch.empty(B, N, dtype=torch.float32).pin_memory()
+        self._pin_key = key
+    pin = self._pin
+    pnp = pin.numpy()
+    nchunk = int(os.environ.get("A3T_COLLATE_CHUNKS", "1"))   # measured (tools/collate_time.py): 1 chunk 6.1 ms, 2: 6.6, 4: 6.9, 8: 8.4 -- the memcpy is 1.3 ms
+    chunk = max(1, (B + nchunk - 1) // nchunk)
+    ev = getattr(self, "_pin_ev", None)
+    if ev is not None:
+        ev.synchronize()          # the previous call's copies out of the staging buffer are done
+    feats, flens = [], []
+    for c0 in range(0, B, chunk):
+        c1 = min(B, c0 + chunk)
+        for i in range(c0, c1):
+            n = int(slen[i])
+            pnp[i, :n] = ds[i]["speech"]
+            if n < N:
+                pnp[i, n:] = self.float_pad_value
+        xd = pin[c0:c1].to(dev, non_blocking=True)
+        f, fl = fe_x(xd, torch.from_numpy(slen[c0:c1]))
+        feats.append(f)
+        flens.append(fl)
+    self._pin_ev = torch.cuda.Event()
+    self._pin_ev.record()
+    feats = torch.cat(feats, 0) if len(feats) > 1 else feats[0]
+    flen = torch.cat(flens, 0)
+    text = pad_list([d["text"] for d in ds], self.int_pad_value)
+    tlen = np.array([d["text"].shape[0] for d in ds], dtype=np.int64)
+    a_s = pad_list([d["align_start"] for d in ds], self.float_pad_value)
+    a_e = pad_list([d["align_end"] for d in ds], self.float_pad_value)
+    alen = np.array([d["align_start"].shape[0] for d in ds], dtype=np.int64)
+    return self._finish_on_device(ds, feats, flen, text, tlen, a_s, a_e, alen, slen)
+
+
+MLMCollateFn._finish_on_device = _collate_finish_on_device
+MLMCollateFn._device_pipeline = _collate_device_pipeline
 
 
 def synthetic_batch(c: A3TConfig, B: int, T_mel: int, T_phn: int, seed: int, device="cpu") -> Dict[str, torch.Tensor]:

@@ -88,6 +88,13 @@ static __device__ __attribute__((aligned(16))) unsigned int attn_zero_page[8];
 #ifndef A3T_SAVE_AUX
 #define A3T_SAVE_AUX 0   // (nt = 2 measured: 348 us instead of 290 -- the L2 merges the 32-byte pieces of a line)
 #endif
+#if defined(A3T_SAVE_EXP) && A3T_SAVE_EXP == 1      // experiment: no store instruction at all
+#define A3T_SAVE_STORE(d, r, vo) asm volatile("" ::"v"(d), "v"(vo))
+#elif defined(A3T_SAVE_EXP) && A3T_SAVE_EXP == 2    // experiment: every store hits the same 1 KiB
+#define A3T_SAVE_STORE(d, r, vo) __builtin_amdgcn_raw_buffer_store_b128(d, r, (vo) == 0x80000000u ? (vo) : (unsigned)(lane * 16), 0, 0)
+#else
+#define A3T_SAVE_STORE(d, r, vo) __builtin_amdgcn_raw_buffer_store_b128(d, r, vo, 0, A3T_SAVE_AUX)
+#endif
 static __device__ int attn_redo[1 << 16];
 
 // LDS-DMA piece (64 lanes x 16 B -> 1 KiB at lds_addr) as inline asm ON PURPOSE: for the builtin the compiler tracks "an LDS
@@ -881,9 +888,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kb = smem;                            // [2]
     unsigned char* Vb = smem + 2 * TB;                   // [2]
-    unsigned char* Pr = smem + 4 * TB;                   // 6 ring slots of 32-row Pext tiles
-    float* sc = (float*)(smem + 10 * TB);                // [4 waves][32][SC_LD] band scratch: two 32-column blocks
+    unsigned char* Pr = smem + 4 * TB;                   // 5 ring slots of 32-row Pext tiles
+    float* sc = (float*)(smem + 9 * TB);                 // [4 waves][32][SC_LD] band scratch: two 32-column blocks
     unsigned int* kmw = (unsigned int*)(sc + 4 * 32 * SC_LD);   // [136] key-mask words
+    unsigned char* stg = (unsigned char*)(kmw + 136);    // SAVE: [4 waves][2 tensors][32 rows][64 B] probability tiles on their way out
 
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -963,7 +971,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         if (q < NPW || (q * 4 + w) * 1024 < TB) {
             const int x = X0 + 32 * (u - 3) + drow[q];
             const int xr = x < T ? x : x - T - 1;
-            dma16(rP, Pr + (u % 6) * TB + (q * 4 + w) * 1024, (unsigned)xr * ldp2 + dcol[q]);
+            dma16(rP, Pr + (u % 5) * TB + (q * 4 + w) * 1024, (unsigned)xr * ldp2 + dcol[q]);
         }
     };
     auto issue_kv = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s) __attribute__((always_inline)) {
@@ -974,12 +982,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) issue_p1(u, q);
     };
-    // K(s0), K(s0+1), V(s0), ring tiles s0 .. s0+5
+    // K(s0), K(s0+1), V(s0), ring tiles s0 .. s0+4 (tile s0+5 takes tile s0's slot once the prologue is through with it)
     issue_kv(rK, Kb + (s0 & 1) * TB, s0);
     issue_kv(rK, Kb + ((s0 + 1) & 1) * TB, s0 + 1);
     issue_kv(rV, Vb + (s0 & 1) * TB, s0);
 #pragma unroll
-    for (int u = 0; u < 6; ++u) issue_p(s0 + u);
+    for (int u = 0; u < 5; ++u) issue_p(s0 + u);
 
     bf16x8 fqu[KS], fqvL[KS], fqvU[KS];                  // (q+u)[i]; (q+v)[i] for the x < T half of the band, (q+v)[i+1] for x > T
 #pragma unroll
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     auto use_upper = [&](int u) -> bool { return (u - 3) * 32 >= 32 + Q0; };
     // band block u (32 band rows x this wave's 32 queries) -> fp32 scratch half (u & 1), stored [query][band column]
     auto band_mm = [&](int u) __attribute__((always_inline)) -> f32x16 {
-        const unsigned char* slot = Pr + (u % 6) * TB;
+        const unsigned char* slot = Pr + (u % 5) * TB;
         f32x16 acc = zero16();
         if (use_upper(u)) {
 #pragma unroll
@@ -1076,6 +1084,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         m2 = mx;                                          // finite: tile s0 holds a valid key
     }
+    __syncthreads();                                      // every wave is through with ring tile s0
+    issue_p(s0 + 5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
 #ifdef A3T_ATTN_TIMING
     unsigned long long tacc[32] = {}, tprev = __builtin_readcyclecounter();
@@ -1086,7 +1098,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     const int ttb = (int)((unsigned)T * (unsigned)T * 2u);
     const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(SAVE ? (void*)(p.probs + (int64_t)bh * T * T) : (void*)p.ctx, 0, ttb, 0x00020000);
     const __amdgpu_buffer_rsrc_t rSD = __builtin_amdgcn_make_buffer_rsrc((SAVE && DROP) ? (void*)(p.pdrop + (int64_t)bh * T * T) : (void*)p.ctx, 0, ttb, 0x00020000);
-    const unsigned svoff = i < T ? ((unsigned)i * (unsigned)T + 8u * lh) * 2u : 0x80000000u;
     f32x16 O[NDB];
 #pragma unroll
     for (int d = 0; d < NDB; ++d) O[d] = zero16();
@@ -1118,7 +1129,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         const unsigned char* Kt = Kb + ((s + 1) & 1) * TB;
         const int Vt = 2 * TB + (s & 1) * TB;
         const int un = s + 1 - w + 4;                     // the one new band block of step s+1
-        const unsigned char* slot = Pr + (un % 6) * TB;
+        const unsigned char* slot = Pr + (un % 5) * TB;
         const unsigned int vm = kmw[s] >> (4 * lh);       // bit (r & 3) + 8 (r >> 2) = this lane's key of register r
         Sn = zero16(), Bn = zero16();
         float pv[16];
@@ -1128,23 +1139,29 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             pv[r] = ((vm >> ((r & 3) + 8 * (r >> 2))) & 1u) ? e : 0.f;
             psum += pv[r];
         };
-        // saved probabilities go out as buffer stores: always exactly one instruction per PAIR of quads (rows / columns outside
-        // the tensor are dropped by the range check), so the end-of-iteration wait can be COUNTED -- vmcnt(number of stores)
-        // waits for the tile DMAs issued before them and not for the write acknowledgements.  A lane holds keys 4 lh .. +3 of
-        // quads 2 h, 2 h + 1; v_permlane32_swap trades one quad with lane +-32 so that it stores 8 consecutive keys (16 B) and
-        // a row gets a full 32-byte sector per instruction (8-byte pieces: 290 us instead of 235 for the two saved tensors).
-        auto save8 = [&](const __amdgpu_buffer_rsrc_t& r, const int hq) __attribute__((always_inline)) {
+        // Saved probabilities.  A lane holds 4 keys of 4 quads of ONE row: stored from there, an instruction touches 32 rows x
+        // 32 B and the store path takes ~150 cycles per instruction (+65 us per launch, whatever the width of the pieces).  The
+        // tile therefore goes through a per-wave LDS image ([32 rows][64 B], chunk-swizzled) and leaves as 16 rows x 64 B per
+        // instruction.  Always exactly two store instructions per tensor and step (rows / columns outside the tensor are
+        // dropped by the range check), so the end-of-iteration wait can be COUNTED: vmcnt(NSV) waits for the tile DMAs issued
+        // before the stores and not for the write acknowledgements.
+        auto stage4 = [&](const int ten, const int g) __attribute__((always_inline)) {     // this lane's quad g -> LDS image
+            unsigned char* im = stg + (w * 2 + ten) * 2048;
+            uint2 v2;
+            v2.x = io_pack2(pv[4 * g], pv[4 * g + 1]), v2.y = io_pack2(pv[4 * g + 2], pv[4 * g + 3]);
+            *(uint2*)(im + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = v2;
+        };
+        auto flush = [&](const __amdgpu_buffer_rsrc_t& r, const int ten) __attribute__((always_inline)) {
             typedef int v4i_ __attribute__((ext_vector_type(4)));
-            const int g0 = 2 * hq, g1 = g0 + 1;
-            const unsigned a0 = io_pack2(pv[4 * g0], pv[4 * g0 + 1]), a1 = io_pack2(pv[4 * g0 + 2], pv[4 * g0 + 3]);
-            const unsigned b0 = io_pack2(pv[4 * g1], pv[4 * g1 + 1]), b1 = io_pack2(pv[4 * g1 + 2], pv[4 * g1 + 3]);
-            const auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-            const auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            // lanes < 32: own quad g0 (keys 16 hq + 0..3) + the partner's g0 (keys + 4..7); lanes >= 32: partner's g1 + own g1 (keys 16 hq + 8..15)
-            v4i_ dta;
-            dta[0] = (int)x0[0], dta[1] = (int)x1[0], dta[2] = (int)x0[1], dta[3] = (int)x1[1];
-            const unsigned vo = (32 * s + 16 * hq + 8 * lh < T) ? svoff + (unsigned)(64 * s + 32 * hq) : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(dta, r, vo, 0, A3T_SAVE_AUX);
+            const unsigned char* im = stg + (w * 2 + ten) * 2048;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int row = 16 * q + (lane >> 2), gl = (lane & 3) ^ ((row >> 2) & 3);      // image chunk lane & 3 holds keys 8 gl .. + 7
+                const v4i_ dta = *(const v4i_*)(im + row * 64 + ((lane & 3) << 4));
+                const int gi = q0 + row, col = 32 * s + 8 * gl;
+                const unsigned vo = (gi < T && col < T) ? ((unsigned)gi * (unsigned)T + (unsigned)col) * 2u : 0x80000000u;
+                A3T_SAVE_STORE(dta, r, vo);
+            }
         };
         auto drop4 = [&](const int g) __attribute__((always_inline)) {
             if (DROP) {
@@ -1155,7 +1172,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             }
         };
         auto dsave = [&](const int g) __attribute__((always_inline)) {
-            if (SAVE && DROP && (g & 1)) save8(rSD, g >> 1);
+            if (SAVE && DROP) stage4(1, g);
         };
         // softmax slices over the KS product stages: exponentials first, then the dropout quads, then the packing
         constexpr int EXS = KS >= 8 ? KS - 4 : (KS > 1 ? KS - 1 : 1);        // stages that carry exponentials
@@ -1164,10 +1181,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r)
                 if (r * EXS / 16 == t) expo(r);
             if (KS >= 8) {
-                if (t == KS - 5 && SAVE) save8(rSP, 0), save8(rSP, 1);           // (all sixteen exponentials are done after stage EXS - 1 = KS - 5)
+                if (t == KS - 5 && SAVE) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3);   // (all sixteen exponentials are done after stage EXS - 1 = KS - 5)
+                if (t == KS - 3 && SAVE) flush(rSP, 0);
                 if (t >= KS - 4) drop4(t - (KS - 4)), dsave(t - (KS - 4));
             } else if (t == KS - 1) {
-                if (SAVE) save8(rSP, 0), save8(rSP, 1);
+                if (SAVE) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3), flush(rSP, 0);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) drop4(g), dsave(g);
             }
@@ -1199,6 +1217,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         }
         l_run += psum;
     };
+    auto flush_d = [&](const int s) __attribute__((always_inline)) {    // the dropped tile of step s (staged by the product stages)
+        typedef int v4i_ __attribute__((ext_vector_type(4)));
+        const unsigned char* im = stg + (w * 2 + 1) * 2048;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = 16 * q + (lane >> 2), gl = (lane & 3) ^ ((row >> 2) & 3);
+            const v4i_ dta = *(const v4i_*)(im + row * 64 + ((lane & 3) << 4));
+            const int gi = q0 + row, col = 32 * s + 8 * gl;
+            const unsigned vo = (gi < T && col < T) ? ((unsigned)gi * (unsigned)T + (unsigned)col) * 2u : 0x80000000u;
+            A3T_SAVE_STORE(dta, rSD, vo);
+        }
+    };
     auto pv_stages = [&](const int s) __attribute__((always_inline)) {
         const int Vt = 2 * TB + (s & 1) * TB;
         const int un = s + 1 - w + 4;
@@ -1210,6 +1240,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             O[d] = mfma32(st[t % 3][0], pf0, O[d]);
             O[d] = mfma32(st[t % 3][1], pf1, O[d]);
             if (d == 0) band_store(un, Bn);
+            if (SAVE && DROP && d == (NDB > 2 ? 2 : NDB - 1)) flush_d(s);
             if (d == 1 || NDB == 1) band_read(un - 1, bd);
             PHASE_FENCE();
         }
@@ -1765,7 +1796,7 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     if (a.probs && !(mode == 2 && grid <= (1u << 16))) return A3T_EINVAL;   // only the fixed-reference kernel can save probabilities
     if (mode == 2 && grid <= (1u << 16)) {
         constexpr int TB32 = DT32<NDB>::BYTES;
-        constexpr int lds32 = 10 * TB32 + 4 * 32 * SC_LD * 4 + 136 * 4;
+        constexpr int lds32 = 9 * TB32 + 4 * 32 * SC_LD * 4 + 136 * 4 + 4 * 2 * 2048;
 #define A3T_L32(DR, SV)                                                                                                              \
     do {                                                                                                                             \
         (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);   \

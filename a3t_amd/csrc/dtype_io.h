@@ -32,7 +32,9 @@ __device__ __forceinline__ unsigned int rng_fmix32(unsigned int h) {
 // epilogue of a 256x256 GEMM tile is 64 hashes per lane with nothing to hide them behind).  The key is itself a mixed
 // 32-bit hash of (step seed, site) computed on the host.
 __device__ __forceinline__ unsigned int rng_pair(unsigned int key, unsigned int pair) {
-    const unsigned int state = (pair + key) * 747796405u + 2891336453u;
+    // the key enters by XOR and again as the (odd) increment: with `pair + key` two sites' masks were index-shifted copies of
+    // each other; same instruction count
+    const unsigned int state = (pair ^ key) * 747796405u + (key | 1u);
     const unsigned int word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
     return (word >> 22u) ^ word;
 }

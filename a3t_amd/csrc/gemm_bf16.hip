@@ -469,11 +469,8 @@ int a3t_gemm_bf16_pn(const GP& p, int batch, int ly, hipStream_t stream);   // g
 template <int LY, int ST, int WM, int CV, int WN = 2>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
     constexpr int lds = ST * (64 * WM + 64 * WN) * 64 * 2;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<LY, ST, WM, CV, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = true;
-    }
+    // per device and cheap: a process that drives a second GPU must not launch there without the raised limit
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_glds_kernel<LY, ST, WM, CV, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((gemm_bf16_glds_kernel<LY, ST, WM, CV, WN>), grid, dim3(128 * WM), lds, stream, pv);
 }
 

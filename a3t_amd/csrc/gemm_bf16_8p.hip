@@ -698,15 +698,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
 #endif
 }
 
-static int g8_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+static int g8_cus() {          // per device (a process may drive several GPUs)
+    static int n[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
         hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
-        n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        n[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }
-    return n;
+    return n[dev];
 }
 
 template <bool CV>

@@ -333,15 +333,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
     if (pend) epi(e_tile, e_chunk);
 }
 
-static int pn_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+static int pn_cus() {          // per device (a process may drive several GPUs)
+    static int n[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
         hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
-        n = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        n[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
     }
-    return n;
+    return n[dev];
 }
 
 // mode: 0 never, 1 whenever legal, 2 cost model (default), 3 cost model for N = 384 only; A3T_GEMM_PN or a3t_gemm_pn_mode()

@@ -621,3 +621,73 @@ extern "C" int a3t_dropout_bwd_cast(const float* g, void* gm, int gm_dtype, floa
 }
 
 extern "C" const char* a3t_version(void) { return "a3t_hip 0.1 (gfx950)"; }
+
+
+// out[b][c] += sum_t x[b*T + t][c] (fp32): the gradient of a per-utterance vector that was added to every token of the
+// utterance (x-vector conditioning, configs[3]) -- one launch for all utterances instead of one column-sum pass each
+__global__ __launch_bounds__(256) void segment_colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int T, int C) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
+    float s = 0.f;
+    if (c < C)
+        for (int t = rl; t < T; t += 4) s += x[((int64_t)b * T + t) * C + c];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) out[(int64_t)b * C + c] += part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+extern "C" int a3t_segment_colsum(const float* x, float* out, int B, int T, int C, void* stream) {
+    if (B <= 0 || T <= 0 || C <= 0 || B > 65535) return A3T_EINVAL;
+    hipLaunchKernelGGL(segment_colsum_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, out, T, C);
+    return (int)hipGetLastError();
+}
+
+
+// On-device half of MLMCollateFn (collate_fn.py:330-385): paints masked_position, the segment ids and the padding masks
+// from the integer span lists.  The numpy-RNG draws that pick the phones stay on the host (the global-RNG contract);
+// what they produce -- sel[b][j] = phone j of utterance b is masked -- comes in with the frame indices of the phones.
+//   masked[b][t]  = (any selected phone j < L_b with fs <= t < fe  OR any explicit span of utterance b covers t) AND t < flen_b
+//   sp[b][t]      = (last j < L_b with fs <= t < fe) + 1, or 0        ("later phones overwrite earlier ones", :335-341)
+//   tp[b][j]      = j + 1 for j < L_b, else 0;   speech_mask = t < flen_b;   text_mask = j < tlen_b
+__global__ __launch_bounds__(256) void collate_paint_kernel(const int* __restrict__ fs, const int* __restrict__ fe,
+                                                            const int* __restrict__ alen, const unsigned char* __restrict__ sel,
+                                                            const int* __restrict__ mspan, const int* __restrict__ nms,
+                                                            const int* __restrict__ flen, const int* __restrict__ tlen,
+                                                            unsigned char* __restrict__ masked, unsigned char* __restrict__ smask,
+                                                            unsigned char* __restrict__ tmask, int64_t* __restrict__ sp,
+                                                            int64_t* __restrict__ tp, int Tm, int Tp, int P, int S, int sega) {
+    const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+    const int L = alen[b] < P ? alen[b] : P;
+    if (t < Tm) {
+        int seg = 0;
+        bool m = false;
+        for (int j = 0; j < L; ++j) {
+            const int s0 = fs[b * P + j], e0 = fe[b * P + j];
+            if (t >= s0 && t < e0) {
+                seg = j + 1;
+                m = m || (sel[b * P + j] != 0);
+            }
+        }
+        const int ns = nms[b];
+        for (int q = 0; q < ns; ++q) m = m || (t >= mspan[(b * S + q) * 2] && t < mspan[(b * S + q) * 2 + 1]);
+        const bool valid = t < flen[b];
+        masked[(int64_t)b * Tm + t] = (m && valid) ? 1 : 0;
+        smask[(int64_t)b * Tm + t] = valid ? 1 : 0;
+        sp[(int64_t)b * Tm + t] = sega ? seg : 0;
+    }
+    if (t < Tp) {
+        tmask[(int64_t)b * Tp + t] = t < tlen[b] ? 1 : 0;
+        tp[(int64_t)b * Tp + t] = (sega && t < L) ? t + 1 : 0;
+    }
+}
+
+extern "C" int a3t_collate_paint(const int* fs, const int* fe, const int* alen, const uint8_t* sel, const int* mspan,
+                                 const int* nms, const int* flen, const int* tlen, uint8_t* masked, uint8_t* speech_mask,
+                                 uint8_t* text_mask, int64_t* sp, int64_t* tp, int B, int Tm, int Tp, int P, int S,
+                                 int sega_emb, void* stream) {
+    if (B <= 0 || B > 65535 || Tm <= 0 || Tp < 0 || P < 0 || S < 0) return A3T_EINVAL;
+    const int n = Tm > Tp ? Tm : Tp;
+    hipLaunchKernelGGL(collate_paint_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                       fs, fe, alen, sel, mspan, nms, flen, tlen, masked, speech_mask, text_mask, sp, tp, Tm, Tp, P, S, sega_emb);
+    return (int)hipGetLastError();
+}

@@ -126,6 +126,8 @@ class MLMEngine:
         self.fused_attn_train = self.bf16 and fa == "auto" and os.environ.get("A3T_FUSED_ATTN_TRAIN", "1") != "0"
         self._fused_now = self.fused_attn
         self._fused_train_now = False
+        self._need_grad = training
+        self._mode_tag = None
         if self.bf16:
             for n, v in (("adim", cfg.adim), ("ff", cfg.ff), ("idim", cfg.idim), ("odim", cfg.odim),
                          ("dk", cfg.dk), ("postnet_chans", cfg.postnet_chans or 8)):
@@ -167,8 +169,9 @@ class MLMEngine:
     def refresh_weights(self):
         if self.bf16:
             ops.cast_bf16(self.store.flat, self.flat16)
-            for suf, (src_off, dst_off, _, flat, shp) in self._wt.items():
-                ops.cast_bf16_conv_t(self.store.flat, flat, src_off, dst_off, *shp)
+            if self._need_grad:       # transposed shadows feed data gradients only
+                for suf, (src_off, dst_off, _, flat, shp) in self._wt.items():
+                    ops.cast_bf16_conv_t(self.store.flat, flat, src_off, dst_off, *shp)
 
     def _setup_wt(self, suf, shape):
         """Transposed, tap-reversed bf16 shadows of every weight `*.suf` of `shape` = [n][k][c] -> [c][k'][n] (Linear: k = 1, stored
@@ -192,10 +195,13 @@ class MLMEngine:
         a3t_gemm_8p_supported / a3t_gemm_pn_supported): (keep, dgrad1, dgrad2) = the keep-bit protocol (forward conv 1 writes one bit per hidden activation,
         the data gradient of conv 2 reads it through the transposed w_2), and the data gradient of conv 1 through the
         transposed w_1.  A3T_FFN_8P=0 turns both off."""
-        if M not in self._ffn_plans:
+        # keyed by what the probes depend on: the kernels' modes may change at run time (a3t_gemm_8p_mode / _pn_mode), and a
+        # forward-only pass needs neither keep bits nor transposed weight shadows (ADVICE r3)
+        key = (M, self._need_grad, self._mode_tag)
+        if key not in self._ffn_plans:
             c = self.c
             keep = d1 = d2 = False
-            if self.bf16 and self.dev.type == "cuda" and os.environ.get("A3T_FFN_8P", "1") != "0":
+            if self._need_grad and self.bf16 and self.dev.type == "cuda" and os.environ.get("A3T_FFN_8P", "1") != "0":
                 k = c.ff_kernel
                 drop = ops.G8_DROP if (self.dropping and c.dropout_rate > 0) else 0
                 keep = ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_BIAS_ACT | drop | ops.G8_KEEP_OUT) and \
@@ -210,15 +216,15 @@ class MLMEngine:
                 if d1 and "w1" not in self._wt:
                     self._setup_wt("w1", (c.ff, k, c.adim))
                 keep, d1, d2 = keep and "w2" in self._wt, d1 and "w1" in self._wt, d2 and "w2" in self._wt
-            self._ffn_plans[M] = (keep, d1, d2)
-        return self._ffn_plans[M]
+            self._ffn_plans[key] = (keep, d1, d2)
+        return self._ffn_plans[key]
 
     def _lin_dgrad(self, dy, name, dx):
         """dx = dy W for the Linear weight `name` ([out][in]).  When the 384-column panel GEMM would take the k-contiguous form
         (in = 384 columns, A3T_LIN_DGRAD_T=0 turns it off) it runs as dx = dy (W^T)^T on the transposed bf16 shadow of W."""
         suf = name.rsplit(".", 1)[1]
         M = dy.shape[0]
-        key = (suf, M, dx.dtype)
+        key = (suf, M, dx.dtype, self._mode_tag)
         if key not in self._lin_plans:
             use = False
             if self.bf16 and self.dev.type == "cuda" and os.environ.get("A3T_LIN_DGRAD_T", "1") != "0":
@@ -707,6 +713,8 @@ class MLMEngine:
             (self.fused_attn_auto and not need_grad and B * c.heads * ((T + 127) // 128) >= 64)
         nblk = B * c.heads * ((T + 127) // 128)
         self._fused_train_now = self.fused_attn_train and need_grad and not self._fused_now and 64 <= nblk <= 65536 and T <= 2048
+        self._need_grad = bool(need_grad)
+        self._mode_tag = ops.gemm_mode_tag()
         self.step_seed += 1
         self.refresh_weights()
         self._arena_clear("fwd64")
@@ -894,8 +902,7 @@ class MLMEngine:
         if "spk" in self.sv:     # d Linear(spembs): per-utterance column sums of the gradient of the token stream
             se = self.sv["spk"]
             dspk = ws.get("tmp.dspk", (B, d), zero=True)
-            for b in range(B):
-                ops.bias_grad(g[b * T:(b + 1) * T], dspk[b], self.scratch64)
+            ops.segment_colsum(g, dspk, B, T)
             ops.linear_bwd_weight(dspk, se, gr["spk.w"], compute=F32)
             self._bias_grad(dspk, gr["spk.b"])
         xm, e, text, spos, tpos, masked, speech2 = self.sv["embed"]

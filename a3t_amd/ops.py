@@ -130,6 +130,28 @@ def gemm_pn_supported(M, N, K, taps=1, flags=0):
     return bool(L.load().a3t_gemm_pn_supported(int(M), int(N), int(K), int(taps), int(flags)))
 
 
+def gemm_mode_tag():
+    """(8-phase mode, panel mode) the dispatcher's cost models currently run under -- part of every cached GEMM plan key."""
+    lib = L.load()
+    m8 = lib.a3t_gemm_8p_mode(2)
+    lib.a3t_gemm_8p_mode(m8)
+    mp = lib.a3t_gemm_pn_mode(2)
+    lib.a3t_gemm_pn_mode(mp)
+    return (m8, mp)
+
+
+def collate_paint(fs, fe, alen, sel, mspan, nms, flen, tlen, masked, speech_mask, text_mask, sp, tp, sega_emb):
+    B, P = fs.shape
+    Tm, Tp, S = masked.shape[1], text_mask.shape[1], mspan.shape[1]
+    L.check(L.load().a3t_collate_paint(_ptr(fs), _ptr(fe), _ptr(alen), _ptr(sel), _ptr(mspan), _ptr(nms), _ptr(flen), _ptr(tlen),
+                                       _ptr(masked), _ptr(speech_mask), _ptr(text_mask), _ptr(sp), _ptr(tp), B, Tm, Tp, P, S,
+                                       int(bool(sega_emb)), _stream()), "collate_paint")
+
+
+def segment_colsum(x, out, B, T):
+    L.check(L.load().a3t_segment_colsum(_ptr(x), _ptr(out), B, T, x.shape[1], _stream()), "segment_colsum")
+
+
 def gemm_keep_bytes(M, N):
     return int(L.load().a3t_gemm_keep_bytes(int(M), int(N)))
 

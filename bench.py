@@ -217,7 +217,7 @@ def collate_leg(dev, B=32, Tm=1000, Tp=120, reps=3):
                                    text=rs.randint(2, 70, size=Tp).astype(np.int64), align_start=st.astype(np.float32),
                                    align_end=en.astype(np.float32))))
     fe = LogMelFbank(fs=fs, n_fft=2048, win_length=1200, hop_length=hop, n_mels=80, fmin=80, fmax=7600, device=dev)
-    coll = MLMCollateFn(fe, mlm_prob=0.8, mean_phn_span=8, sega_emb=True)
+    coll = MLMCollateFn(fe, mlm_prob=0.8, mean_phn_span=8, sega_emb=True, device_out=True)   # the whole batch dict is built on the device
     np.random.seed(1)
     coll(data)
     torch.cuda.synchronize()
@@ -227,7 +227,7 @@ def collate_leg(dev, B=32, Tm=1000, Tp=120, reps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     frames = int(out["speech"].shape[0] * out["speech"].shape[1])
-    res = dict(metric="collate mel-frames/s (host waveforms in, batch dict out)", frames_per_s=frames / dt, ms=dt * 1e3,
+    res = dict(metric="collate mel-frames/s (host waveforms in, device batch dict out)", frames_per_s=frames / dt, ms=dt * 1e3,
                workload=f"B={B} utterances x {Tm} frames (12.5 s at 24 kHz), {Tp} phones each")
     try:
         from oracle import a3t_oracle as O
@@ -382,6 +382,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but the RCCL group has {dist.get_world_size()} ranks")
 
     from a3t_amd import ops
     from a3t_amd.collate import synthetic_batch
@@ -444,6 +446,24 @@ def main():
                     buckets=len(rngs), dtype=a.comm_dtype, allreduce_ms_alone=tc * 1e3,
                     algbw_GBps=nbytes / tc / 1e9, busbw_GBps=2.0 * (world - 1) / world * nbytes / tc / 1e9)
         del gbuf
+        # how much of the exchange the backward pass hides: the same step with the collectives switched off (every rank on
+        # its own; the replicas diverge from here on, nothing is timed after this) against the timed step
+        saved = (tr.reducer, tr.world)
+        tr.reducer, tr.world = None, 1
+        for _ in range(2):
+            tr.step(batch)
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(5):
+            tr.step(batch)
+        sync()
+        t_nc = torch.tensor([(time.perf_counter() - t2) / 5], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_nc, op=dist.ReduceOp.MAX)
+        tr.reducer, tr.world = saved
+        ms_nc = float(t_nc) * 1e3
+        exposed = max(0.0, ms - ms_nc)
+        comm.update(step_ms_without_allreduce=ms_nc, allreduce_ms_exposed=exposed,
+                    allreduce_ms_hidden=max(0.0, tc * 1e3 - exposed))
     roofline = None
     prof_rows = []
     if not a.no_kernel_profile:      # every rank runs the two extra steps (they contain collectives when world > 1)

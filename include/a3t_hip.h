@@ -332,6 +332,19 @@ int a3t_dropout_bwd_cast(const float* g, void* gm, int gm_dtype, float* colsum, 
 int a3t_pwg_block(float* x, const float* cu, const float* wt0, const float* b0, const float* wt1, const float* b1,
                   float* g, float* skips, int B, int Tw, int dil, void* stream);
 
+/* On-device half of MLMCollateFn (espnet2/train/collate_fn.py:330-385): masked_position, speech / text segment ids and the
+ * two padding masks painted from integer span lists.  fs / fe [B][P] int32: frame span of phone j (floor(fs * t / hop) taken
+ * on the host in the alignment's dtype, collate_fn.py:236-237); alen [B] phones per utterance; sel [B][P] uint8: phone j is
+ * masked (decided by the host's numpy-RNG draws, random_spans_noise_mask :387-446); mspan [B][S][2] int32 + nms [B]: explicit
+ * frame spans to mask besides (span_boundary, the mean_phn_span == 0 and mlm_prob == 1 cases); flen / tlen [B] int32: valid
+ * frames / phones.  Outputs: masked, speech_mask [B][Tm] uint8 (0 / 1), text_mask [B][Tp] uint8, sp [B][Tm] and tp [B][Tp]
+ * int64 (all 0 when sega_emb == 0).  Later phones overwrite earlier ones where spans overlap (:335-341). */
+int a3t_collate_paint(const int* fs, const int* fe, const int* alen, const uint8_t* sel, const int* mspan, const int* nms,
+                      const int* flen, const int* tlen, uint8_t* masked, uint8_t* speech_mask, uint8_t* text_mask,
+                      int64_t* sp, int64_t* tp, int B, int Tm, int Tp, int P, int S, int sega_emb, void* stream);
+/* out[b][c] += sum_t x[b*T + t][c], fp32: gradient of a per-utterance vector added to every token of its utterance. */
+int a3t_segment_colsum(const float* x, float* out, int B, int T, int C, void* stream);
+
 const char* a3t_version(void);
 /* Name (as rocprofv3 prints it, without "void " / "(GP)") of the kernel variant a3t_gemm's dispatcher launched last on
  * the calling thread -- lets a profiler harness attribute event-bracketed launches to kernel-trace rows. */

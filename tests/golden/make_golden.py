@@ -640,6 +640,52 @@ def gen_extra(out):
     print("align_dtype.npz: segment ids differ at", int((e["f64.speech_segment_pos"] != e["f32.speech_segment_pos"]).sum()), "frames")
 
 
+def gen_bf16ref(out):
+    """e2e_bf16ref.npz: what the REFERENCE ITSELF does to its mel outputs when its matrix products run in bf16
+    (torch.autocast("cpu", dtype=torch.bfloat16): Linear / Conv1d / matmul operands and results in bf16, LayerNorm / softmax
+    / BatchNorm statistics in fp32) -- the yardstick the bf16 tolerances of tests/test_gpu_parity_r2.py are pinned to, instead
+    of a self-granted waiver.  Same configurations, procedural weights and batches as e2e_extra.npz; the batch is padded
+    to the 16-byte DMA granule exactly as the product's plugin model pads it (so both see the same tensors).  Stored: the
+    reference's bf16 outputs and their max / RMS error against its own fp32 outputs, relative to max(1, max|fp32|)."""
+    import torch
+    from oracle.a3t_oracle import A3TConfig, synthetic_batch
+    from a3t_amd.espnet_model import ESPnetMLMEncAsDecoderModel
+    # The reference cannot take bf16 scores as it stands: attention.py:81 asks numpy for finfo of the score dtype and numpy has
+    # no bfloat16 ("Got unsupported ScalarType BFloat16").  The one change made here (monkeypatch, nothing is copied): the
+    # scores enter forward_attention promoted to fp32 -- bf16 logits, fp32 softmax, the split a3t_amd's bf16 mode uses too.
+    from espnet.nets.pytorch_backend.transformer import attention as ref_attention
+    _orig_fa = ref_attention.MultiHeadedAttention.forward_attention
+    ref_attention.MultiHeadedAttention.forward_attention = lambda self, value, scores, mask: _orig_fa(self, value, scores.float(), mask)
+    d = {}
+    cases = dict(c1=(A3TConfig(adim=128, heads=2, ff=512, enc_blocks=1, dec_blocks=1), 4,
+                     dict(B=2, T_mel=200, T_phn=30, seed=13, lengths=[200, 171], text_lengths=[30, 22])),
+                 c4s=(A3TConfig(adim=512, heads=4, ff=2048, enc_blocks=1, dec_blocks=1), 5,
+                      dict(B=2, T_mel=96, T_phn=16, seed=14, lengths=[96, 70], text_lengths=[16, 11])),
+                 refyaml=(A3TConfig(), 3, dict(B=2, T_mel=200, T_phn=30, seed=12, lengths=[200, 163], text_lengths=[30, 24])))
+    for tag, (c, seed, bk) in cases.items():
+        batch = ESPnetMLMEncAsDecoderModel._pad_to_dma_granule(dict(synthetic_batch(c, **bk)))
+        model, _ = build_ref_model(c, c.vocab)
+        load_procedural(model, c, seed=seed)
+        model.train()
+        with torch.no_grad():
+            b32, a32, _, _ = _fwd_parts(model, batch)
+        load_procedural(model, c, seed=seed)          # (train-mode BatchNorm moved the running statistics)
+        model.train()
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            b16, a16, _, _ = _fwd_parts(model, batch)
+        for name, x32, x16 in (("before", b32, b16), ("after", a32, a16)):
+            x32, x16 = x32.double().numpy(), x16.float().double().numpy()
+            scale = max(1.0, float(np.abs(x32).max()))
+            d[f"{tag}.{name}.bf16"] = x16.astype(np.float32)
+            d[f"{tag}.{name}.err_max"] = np.float64(np.abs(x16 - x32).max() / scale)
+            d[f"{tag}.{name}.err_rms"] = np.float64(np.sqrt(np.mean((x16 - x32) ** 2)) / scale)
+            print(f"{tag} {name}: reference under bf16 autocast vs its own fp32: max {d[f'{tag}.{name}.err_max']:.3e}"
+                  f" rms {d[f'{tag}.{name}.err_rms']:.3e} of scale {scale:.2f}")
+    ref_attention.MultiHeadedAttention.forward_attention = _orig_fa
+    np.savez_compressed(os.path.join(out, "e2e_bf16ref.npz"), **d)
+    print("e2e_bf16ref.npz", len(d), "arrays")
+
+
 def sweep(out, n_masks, n_models):
     """Randomised pinning of the ORACLE to the REFERENCE (container only; the fixed goldens above are what travels).
 
@@ -771,7 +817,7 @@ if __name__ == "__main__":
         sweep(HERE, *a.sweep)
         sys.exit(0)
     todo = dict(masks=gen_masks, logmel=gen_logmel, e2e=gen_e2e, pwg=gen_pwg, sedit=gen_sedit, average=gen_average,
-                extra=gen_extra)
+                extra=gen_extra, bf16ref=gen_bf16ref)
     for k, f in todo.items():
         if a.only and k not in a.only.split(","):
             continue

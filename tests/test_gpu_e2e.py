@@ -190,6 +190,60 @@ def test_logmel_and_collate_on_device():
     np.testing.assert_allclose(b["speech"].numpy(), c["out.speech"], atol=2e-4)
 
 
+def test_collate_on_device_matches_host_collate_bit_for_bit():
+    """device_out=True (round 4): features stay on the device, masks / segment ids / padding masks are painted
+    by a3t_collate_paint from the integer span lists; only the numpy-RNG draws run on the host.  Against the reference's own
+    MLMCollateFn output (collate.npz) and against the host path on ragged random batches, all four masking branches."""
+    from a3t_amd.collate import MLMCollateFn
+    from a3t_amd.features import LogMelFbank
+    fe = LogMelFbank(fs=24000, n_fft=2048, win_length=1200, hop_length=300, n_mels=80, fmin=80, fmax=7600, device=DEV)
+    c = np.load(os.path.join(G, "collate.npz"))
+    data = [(f"utt{i}", {k: c[f"in{i}.{k}"] for k in ("speech", "text", "align_start", "align_end")}) for i in range(2)]
+    coll = MLMCollateFn(fe, float_pad_value=0.0, int_pad_value=0, mlm_prob=0.8, mean_phn_span=8, sega_emb=True, device_out=True)
+    np.random.seed(77)
+    uids, b = coll(data)
+    assert uids == ["utt0", "utt1"] and all(v.is_cuda for v in b.values())
+    for k in ("text", "masked_position", "speech_mask", "text_mask", "speech_segment_pos", "text_segment_pos",
+              "speech_lengths", "text_lengths"):
+        assert b[k].dtype == torch.from_numpy(c["out." + k]).dtype, k
+        assert np.array_equal(b[k].cpu().numpy(), c["out." + k]), k
+    np.testing.assert_allclose(b["speech"].cpu().numpy(), c["out.speech"], atol=2e-4)
+    rs = np.random.RandomState(8)
+    hop, fs = 300, 24000
+    for case in range(8):
+        B = int(rs.randint(1, 6))
+        data = []
+        for i in range(B):
+            F_ = int(rs.randint(30, 120))
+            n = hop * (F_ - 1) + int(rs.randint(0, hop))
+            P = int(rs.randint(1, 14))
+            cuts = np.sort(rs.choice(np.arange(1, F_ - 1), P - 1, replace=False)) if P > 1 else np.zeros(0, np.int64)
+            st = np.concatenate([[0], cuts]).astype(np.float64) * hop / fs + 1e-4
+            en = np.concatenate([cuts, [F_ - 1]]).astype(np.float64) * hop / fs + 1e-4
+            d = dict(speech=(0.1 * rs.standard_normal(n)).astype(np.float32), text=rs.randint(2, 70, size=P).astype(np.int64),
+                     align_start=st.astype(np.float32), align_end=en.astype(np.float32))
+            if case % 4 == 1:
+                d["span_boundary"] = np.sort(rs.randint(0, F_, size=2)).astype(np.int64)
+            data.append((f"u{i}", d))
+        if case % 4 == 1 and len({len(d) for _, d in data}) != 1:
+            continue
+        kw = dict(mlm_prob=1.0) if case % 4 == 3 else dict(mlm_prob=0.3, mean_phn_span=0) if case % 4 == 2 else dict(mlm_prob=0.8, mean_phn_span=8)
+        host = MLMCollateFn(fe, sega_emb=(case % 2 == 0), **kw)
+        devc = MLMCollateFn(fe, sega_emb=(case % 2 == 0), device_out=True, **kw)
+        np.random.seed(100 + case)
+        _, bh = host(data)
+        st_h = np.random.get_state()[1].copy()
+        np.random.seed(100 + case)
+        _, bd = devc(data)
+        assert np.array_equal(np.random.get_state()[1], st_h)
+        for k in bh:
+            assert bd[k].dtype == bh[k].dtype and tuple(bd[k].shape) == tuple(bh[k].shape), (case, k)
+            if k == "speech":
+                np.testing.assert_allclose(bd[k].cpu().numpy(), bh[k].numpy(), atol=1e-6)
+            else:
+                assert np.array_equal(bd[k].cpu().numpy(), bh[k].numpy()), (case, k)
+
+
 def test_dropout_backward_matches_finite_differences():
     """With dropout on (counter RNG, fixed step seed) the loss is a deterministic function of the
     parameters: the hand-written backward must agree with a central finite difference along the

@@ -745,3 +745,50 @@ def test_row_kernels_randomised_sweep():
     (K in 3..31, any C, bf16 vector path and generic path), forward and backward against torch math."""
     import fuzz_rowkernels as mod
     assert mod.run(seed=5, n=25, verbose=False) == 0
+
+
+def test_dropout_masks_of_two_keys_are_not_shifted_copies_of_each_other():
+    """Counter RNG (csrc/dtype_io.h rng_pair).  With the key entering ADDITIVELY (round 3) the masks of two dropout sites were
+    the same sequence read at an offset: keys k and k + 7 gave masks that agree 100 % at an index shift of 14.  Round 4: the key
+    enters by XOR and again as the increment.  Checked here: (a) for adjacent raw keys no index shift reproduces the other mask
+    (agreement stays far from 1), (b) for keys as the engine derives them (murmur-mixed hash of step seed and site, engine._drop)
+    the agreement at every small shift sits at the chance level p^2 + (1-p)^2, and the keep rate at 1 - p."""
+    import zlib
+    from a3t_amd import ops
+    n, p = 1 << 20, 0.2
+    x = torch.ones(n, device=DEV)
+
+    def mask(key):
+        y = torch.empty_like(x)
+        ops.dropout(x, y, p, key)
+        m = (y != 0)
+        assert abs(float(m.float().mean()) - (1 - p)) < 3e-3
+        return m
+
+    def engine_key(step, tag):
+        h = (zlib.crc32(tag.encode()) ^ ((step * 0x9E3779B1) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        h = ((h ^ (h >> 16)) * 0x85EBCA6B) & 0xFFFFFFFF
+        h = ((h ^ (h >> 13)) * 0xC2B2AE35) & 0xFFFFFFFF
+        return (h ^ (h >> 16)) & 0xFFFFFFFF
+
+    chance = p * p + (1 - p) * (1 - p)
+    shifts = list(range(0, 65)) + [1 << 10]
+
+    def worst_dev(ma, mb):
+        w, top = 0.0, 0.0
+        for sh in shifts:
+            m = n - sh
+            for u, v in ((ma, mb), (mb, ma)):
+                agree = float((u[:m] == v[sh:sh + m]).float().mean())
+                w, top = max(w, abs(agree - chance)), max(top, agree)
+        return w, top
+
+    a, b = mask(1000), mask(1007)                       # (a) raw adjacent keys: no shifted copy
+    w, top = worst_dev(a, b)
+    print(f"raw keys 1000 / 1007: largest agreement at any shift {top:.4f} (chance {chance:.4f})")
+    assert top < chance + 0.05
+    ks = [engine_key(3, "enc.0.mha.att"), engine_key(3, "enc.1.mha.att"), engine_key(4, "enc.0.mha.att")]
+    ms = [mask(k) for k in ks]                          # (b) production keys: chance level
+    worst = max(worst_dev(ms[i], ms[j])[0] for i, j in ((0, 1), (0, 2), (1, 2)))
+    print(f"engine keys: largest deviation of mask agreement from chance: {worst:.4f}")
+    assert worst < 5e-3

@@ -236,3 +236,38 @@ def test_checkpoint_average_nbest_matches_reference(tmp_path):
     m2, r3 = M(), ck.EpochReport()
     ck.resume(out / "checkpoint.pth", m2, r3)
     assert torch.equal(m2.s["w"], m.s["w"]) and r3.get_epoch() == 3 and r3.stats == r2.stats
+
+
+def test_masking_plan_is_phones_masking_in_integers():
+    """a3t_amd.collate.masking_plan (host half of the on-device collate) consumes the numpy RNG exactly like phones_masking
+    and its integer plan, painted the way a3t_collate_paint paints it, gives the same mask -- all four branches of
+    collate_fn.py:346-385 (phone spans, span_boundary, mean_phn_span == 0, mlm_prob == 1)."""
+    import numpy as np
+    from a3t_amd.collate import masking_plan, phones_masking
+    rs = np.random.RandomState(3)
+    for case in range(40):
+        B, T, P = int(rs.randint(1, 5)), int(rs.randint(20, 90)), int(rs.randint(1, 12))
+        alen = rs.randint(0, P + 1, size=B)
+        fs = np.sort(rs.randint(0, T, size=(B, P)), axis=1).astype(np.int32)
+        fe = np.minimum(fs + rs.randint(0, 9, size=(B, P)), T + 3).astype(np.int32)
+        flen = rs.randint(T // 2, T + 1, size=B)
+        flen[rs.randint(B)] = T
+        nonpad = np.arange(T)[None, :] < flen[:, None]
+        mode = case % 4
+        prob, span, sb = (0.8, 8, None) if mode == 0 else (0.8, 8, np.sort(rs.randint(0, T, size=(B, 4)), axis=1)) if mode == 1 \
+            else (0.3, 0, None) if mode == 2 else (1.0, 8, None)
+        np.random.seed(case)
+        want = phones_masking(T, nonpad, fs, fe, alen, prob, span, sb)
+        st_want = np.random.get_state()[1].copy()
+        np.random.seed(case)
+        sel, mspan, nms = masking_plan(T, alen, prob, span, P, sb)
+        assert np.array_equal(np.random.get_state()[1], st_want)          # same draws, same RNG state afterwards
+        got = np.zeros((B, T), dtype=bool)
+        for b in range(B):
+            for j in range(min(int(alen[b]), P)):
+                if sel[b, j]:
+                    got[b, max(int(fs[b, j]), 0):max(int(fe[b, j]), 0)] = True
+            for q in range(int(nms[b])):
+                got[b, mspan[b, q, 0]:mspan[b, q, 1]] = True
+        got &= nonpad
+        assert np.array_equal(got, want), (case, mode)

@@ -353,3 +353,26 @@ def test_alignment_dtype_follows_the_reference_collate(tag, cast):
     sp, tp = C.get_segment_pos(T_mel, len(g["text"]), fs_, fe_, np.array([len(st)]), True)
     assert np.array_equal(sp, g[f"{tag}.speech_segment_pos"]) and np.array_equal(tp, g[f"{tag}.text_segment_pos"])
     assert not np.array_equal(g["f64.speech_segment_pos"], g["f32.speech_segment_pos"])
+
+
+def test_reference_bf16_yardstick_fixture():
+    """e2e_bf16ref.npz (make_golden.py --only bf16ref): the imported reference under torch.autocast(cpu, bfloat16).  Its stored
+    error figures must be what its stored bf16 outputs give against the ORACLE's fp32 outputs on the same padded batch (the
+    oracle is pinned to the reference's fp32 outputs elsewhere), i.e. the yardstick of the GPU bf16 test is self-consistent."""
+    from a3t_amd.espnet_model import ESPnetMLMEncAsDecoderModel
+    g = _load("e2e_bf16ref.npz")
+    for tag in ("c1", "c4s", "refyaml"):
+        oc, seed, batch = _extra_case(tag)
+        pb = ESPnetMLMEncAsDecoderModel._pad_to_dma_granule(dict(batch))
+        p = O.to_torch_state(O.procedural_state(O.param_shapes(oc), seed))
+        with torch.no_grad():
+            _, rb, ra = O.forward_loss(p, pb, oc, True)
+        for name, ref in (("before", rb), ("after", ra)):
+            ref = ref.double().numpy()
+            x16 = np.asarray(g[f"{tag}.{name}.bf16"], np.float64).reshape(ref.shape)
+            scale = max(1.0, float(np.abs(ref).max()))
+            mx = float(np.abs(x16 - ref).max()) / scale
+            rms = float(np.sqrt(np.mean((x16 - ref) ** 2))) / scale
+            assert abs(mx - float(g[f"{tag}.{name}.err_max"])) < 2e-4 + 0.02 * mx, (tag, name, mx, float(g[f"{tag}.{name}.err_max"]))
+            assert abs(rms - float(g[f"{tag}.{name}.err_rms"])) < 1e-4 + 0.02 * rms
+            assert 1e-3 < mx < 0.1          # bf16 products cost the reference itself between 0.1 % and 10 % of the mel scale
