@@ -1124,19 +1124,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     };
     // product stages of step s+1 + the softmax of step s; two copies (the new band block takes (q+v)[i] or (q+v)[i+1]).  The PV
     // stages below exist ONCE: with two copies of them the accumulators O get two register homes and 96 moves per iteration.
-    auto products = [&](auto UP, const int s) __attribute__((always_inline)) {
-        constexpr bool up = decltype(UP)::value;
+    auto products = [&](auto UP, auto MASKED, const int s) __attribute__((always_inline)) {
+        constexpr bool up = decltype(UP)::value, msk = decltype(MASKED)::value;   // msk: the key tile holds masked keys (utterance ends only)
         const unsigned char* Kt = Kb + ((s + 1) & 1) * TB;
         const int Vt = 2 * TB + (s & 1) * TB;
         const int un = s + 1 - w + 4;                     // the one new band block of step s+1
         const unsigned char* slot = Pr + (un % 5) * TB;
-        const unsigned int vm = kmw[s] >> (4 * lh);       // bit (r & 3) + 8 (r >> 2) = this lane's key of register r
+        const unsigned int vm = msk ? kmw[s] >> (4 * lh) : 0u;   // bit (r & 3) + 8 (r >> 2) = this lane's key of register r
         Sn = zero16(), Bn = zero16();
         float pv[16];
         float psum = 0.f;
         auto expo = [&](const int r) __attribute__((always_inline)) {
             const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[r] + bd[r], sl2, -m2));
-            pv[r] = ((vm >> ((r & 3) + 8 * (r >> 2))) & 1u) ? e : 0.f;
+            pv[r] = (!msk || ((vm >> ((r & 3) + 8 * (r >> 2))) & 1u)) ? e : 0.f;
             psum += pv[r];
         };
         // Saved probabilities.  A lane holds 4 keys of 4 quads of ONE row: stored from there, an instruction touches 32 rows x
@@ -1255,8 +1255,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         // resident: K(s+1), V(s), ring tiles s+1 .. s+5; registers: Sc = S(s), bd = band values of step s
         TSTAMP(0);
         TSTAMP(1);
-        if (use_upper(s + 1 - w + 4)) products(TrueT(), s);
-        else products(FalseT(), s);
+        const bool full = __builtin_amdgcn_readfirstlane(kmw[s]) == 0xffffffffu;
+        if (use_upper(s + 1 - w + 4)) {
+            if (full) products(TrueT(), FalseT(), s);
+            else products(TrueT(), TrueT(), s);
+        } else {
+            if (full) products(FalseT(), FalseT(), s);
+            else products(FalseT(), TrueT(), s);
+        }
         pv_stages(s);
         // the DMA of this iteration has landed (it is older than the NSV probability stores), everyone is done reading
         PHASE_FENCE();
