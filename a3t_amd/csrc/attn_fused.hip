@@ -101,8 +101,12 @@ static __device__ int attn_redo[1 << 16];
 // write is in flight" and, because every tile pointer is an offset into the one dynamic LDS array, puts a vmcnt wait for ALL
 // outstanding DMA in front of the next LDS read that might alias -- i.e. in the middle of the iteration that issued it
 // (measured: +80 us per launch).  The kernels below wait for their DMA themselves (counted vmcnt + s_barrier).
-__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, const void* lds_ptr, unsigned voff) {
-    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_AS(lds_ptr));
+// (lds_addr: 32-bit LDS byte address, wave-uniform.  Callers form it as lds_base(smem) + offset: casting every tile pointer
+//  from the generic address space makes the compiler emit a null check against src_shared_base that some instantiations
+//  fail to select -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base".)
+__device__ __forceinline__ unsigned lds_base(const void* smem0) { return (unsigned)(uintptr_t)LDS_AS(smem0); }
+__device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff) {
+    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(r) : "memory");
 }
 __device__ __forceinline__ bf16x8 ld_frag_g(const u16* p, bool ok) {
@@ -881,7 +885,7 @@ __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NDB, bool DROP, bool SAVE>
+template <int NDB, bool DROP, bool SAVE, bool TWOPASS = false>
 __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     using D = DT32<NDB>;
     constexpr int DK = D::DK, KS = DK / 16, TB = D::BYTES, CPR = D::CPR, RB = D::RB, NPW = D::NP / 4;
@@ -893,6 +897,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     unsigned int* kmw = (unsigned int*)(sc + 4 * 32 * SC_LD);   // [136] key-mask words
     unsigned char* stg = (unsigned char*)(kmw + 136);    // SAVE: [4 waves][2 tensors][32 rows][64 B] probability tiles on their way out
 
+    const unsigned smem0 = lds_base(smem);
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, NQB = (T + 127) / 128, NS = (T + 31) / 32;
@@ -901,6 +906,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
         wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
+    if (TWOPASS && attn_redo[wi & 0xffff] == 0) return;     // fixup launch: only the blocks whose row sums overflowed
     const int bh = wi / NQB, qb = wi - bh * NQB;
     const int b = bh / p.H, h = bh - b * p.H;
     const int Q0 = qb * 128, q0 = Q0 + 32 * w, i = q0 + lr;
@@ -965,13 +971,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     }
     auto issue_kv1 = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s, const int q) __attribute__((always_inline)) {
         if (q < NPW || (q * 4 + w) * 1024 < TB)
-            dma16(r, tile + (q * 4 + w) * 1024, voffK[q] + (unsigned)(32 * s) * ldkv2);
+            dma16(r, smem0 + (unsigned)(tile - smem) + (q * 4 + w) * 1024, voffK[q] + (unsigned)(32 * s) * ldkv2);
     };
     auto issue_p1 = [&](int u, const int q) __attribute__((always_inline)) {
         if (q < NPW || (q * 4 + w) * 1024 < TB) {
             const int x = X0 + 32 * (u - 3) + drow[q];
             const int xr = x < T ? x : x - T - 1;
-            dma16(rP, Pr + (u % 5) * TB + (q * 4 + w) * 1024, (unsigned)xr * ldp2 + dcol[q]);
+            dma16(rP, smem0 + (unsigned)(4 * TB + (u % 5) * TB + (q * 4 + w) * 1024), (unsigned)xr * ldp2 + dcol[q]);
         }
     };
     auto issue_kv = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s) __attribute__((always_inline)) {
@@ -1073,16 +1079,48 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         band_read(u, bd);
     }
     float m2;
-    {
-        const unsigned int vm = kmw[s0];
+    auto tile_max = [&](const int s, const f32x16& S_, const float* bd_) __attribute__((always_inline)) -> float {
+        const unsigned int vm = kmw[s];
         float mx = -__builtin_inff();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kk = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if ((vm >> kk) & 1u) mx = fmaxf(mx, (Sc[r] + bd[r]) * sl2);
+            if ((vm >> kk) & 1u) mx = fmaxf(mx, (S_[r] + bd_[r]) * sl2);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        m2 = mx;                                          // finite: tile s0 holds a valid key
+        return fmaxf(mx, __shfl_xor(mx, 32, 64));
+    };
+    m2 = tile_max(s0, Sc, bd);                            // finite: tile s0 holds a valid key
+    if (TWOPASS) {
+        // Fixup of a block whose scores outgrew the first tile's maximum by more than ~88 (l overflowed): one plain sweep over
+        // all key tiles for the TRUE row maximum (no pipelining -- this path is rare), then the normal pipeline with it.
+        for (int s = s0 + 1; s < NS; ++s) {
+            if (__builtin_amdgcn_readfirstlane(kmw[s]) == 0u) continue;
+            __syncthreads();
+            issue_kv(rK, Kb + (s & 1) * TB, s);
+#pragma unroll
+            for (int u = 0; u < 5; ++u) issue_p(s + u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const f32x16 S2 = s_mm(Kb + (s & 1) * TB);
+            float bd2[16];
+            const int u = s - w + 3;
+            band_store(u, band_mm(u));
+            band_store(u + 1, band_mm(u + 1));
+            band_read(u, bd2);
+            m2 = fmaxf(m2, tile_max(s, S2, bd2));
+        }
+        __syncthreads();
+        issue_kv(rK, Kb + (s0 & 1) * TB, s0);
+        issue_kv(rK, Kb + ((s0 + 1) & 1) * TB, s0 + 1);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) issue_p(s0 + u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        Sc = s_mm(Kb + (s0 & 1) * TB);
+        const int u = s0 - w + 3;
+        band_store(u, band_mm(u));
+        band_store(u + 1, band_mm(u + 1));
+        band_read(u, bd);
     }
     __syncthreads();                                      // every wave is through with ring tile s0
     issue_p(s0 + 5);
@@ -1295,7 +1333,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         if (SAVE && lh == 0) p.rowscale[(int64_t)bh * T + i] = invl;
     }
     const int anybad = __syncthreads_or(bad && i < T);
-    if (tid == 0) attn_redo[wi & 0xffff] = anybad ? 1 : 0;
+    if (tid == 0 && !TWOPASS) attn_redo[wi & 0xffff] = anybad ? 1 : 0;
 }
 
 // =====================================================================================================================
@@ -1809,8 +1847,18 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV>), dim3(grid), dim3(256), lds32, s, a);                                    \
     } while (0)
         if (a.probs) {
-            if (a.drop_thr) A3T_L32(true, true);
-            else A3T_L32(false, true);
+            // training: the fixup of an overflowed block has to re-write its saved probabilities too -> the same kernel with
+            // a first sweep for the true row maximum (every block but the flagged ones exits at once)
+            if (a.drop_thr) {
+                A3T_L32(true, true);
+                (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
+                hipLaunchKernelGGL((attn_fwd32_kernel<NDB, true, true, true>), dim3(grid), dim3(256), lds32, s, a);
+            } else {
+                A3T_L32(false, true);
+                (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
+                hipLaunchKernelGGL((attn_fwd32_kernel<NDB, false, true, true>), dim3(grid), dim3(256), lds32, s, a);
+            }
+            return (int)hipGetLastError();
         } else {
             if (a.drop_thr) A3T_L32(true, false);
             else A3T_L32(false, false);

@@ -405,3 +405,38 @@ def test_engine_training_step_with_the_fused_forward_matches_the_materialised_st
         if cos < 0.985 or not (0.93 < ratio < 1.07):
             bad.append((k, round(cos, 4), round(ratio, 4)))
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_fixed_reference_maximum_overflow_falls_back_and_stays_exact(train):
+    """The 32-query forward fixes a row's reference maximum at the first key tile.  Keys whose scores exceed it by more than
+    ~88 overflow the row sum; the block then raises its redo flag and is recomputed -- by the rescaling 16-query kernel for
+    forward-only passes, by the same kernel with a first sweep for the true maximum for the training forward (it has to
+    re-write the saved probabilities).  Forced here: the keys of the second half of one utterance are scaled by 40."""
+    from a3t_amd import ops
+    B, H, T, dk = 2, 2, 328, 64
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=99)
+    d = H * dk
+    qkv = qkv.clone()
+    kview = qkv.view(B, T, 3 * d)
+    kview[1, 200:, d:2 * d] = (kview[1, 200:, d:2 * d].float() * 40.0).bfloat16()
+    ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=DEV)
+    if train:
+        probs = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+        rs = torch.zeros(B, H, T, device=DEV)
+        ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, None, rs, B, H, T, 1.0 / math.sqrt(dk))
+    else:
+        ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk))
+    torch.cuda.synchronize()
+    ref, pr, rlse = _exact(qkv, qu, qv, P, keymask, B, H, T, dk)
+    assert float(rlse.max()) > 100.0                       # the scenario really has scores far beyond the first tile's
+    got = ctx.float().cpu().double()
+    assert bool(torch.isfinite(got).all())
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max()) / scale
+    assert err < 2e-2, err
+    assert float((lse.cpu().double() - rlse).abs().max()) < 2e-2
+    if train:
+        pn = probs.float().cpu().double() * rs.cpu().double()[..., None]
+        assert bool(torch.isfinite(pn).all()) and float((pn - pr).abs().max()) < 8e-3
