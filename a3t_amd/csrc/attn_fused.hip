@@ -427,424 +427,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
     }
 }
 
-// =====================================================================================================================
-// Forward, software-pipelined and group-staggered (round 4).  Same tiles, fragments and LDS images as attn_fwd16_kernel;
-// what changes is WHEN things run.  The 16-query kernel above is a dependency chain per key block (S -> LDS skew ->
-// softmax -> PV -> barrier) that all eight waves walk in lockstep: MFMA idle during the softmax, VALU idle during the
-// products, ~5500 cycles per 32-key step against 576 cycles of MFMA issue per wave.  Here a step is split in two halves,
-//     M(s): S(s) = K (q+u)^T, the two new band blocks of step s, PV(s-1)       (36 MFMAs, 36 KiB of LDS fragments)
-//     V(s): skewed band read, online softmax of step s, dropout, P(s) -> bf16   (VALU only)
-// and waves 4-7 run ONE s_barrier behind waves 0-3 (every SIMD holds one wave of each group), so that while one group
-// multiplies the other exponentiates: the matrix pipe and the VALU of a SIMD are both busy all the time.  P(s) is
-// carried to the next M half in 4 registers; the O rescale of the deferred-max rule is decided in V(s), when PV(s-1) is
-// complete and PV(s) not begun (the safe order).  DMA for step s+1 (K(s+1), V(s), Pext ring tile s+5) is issued at the
-// start of the even global half 2s by all eight waves and waited for (vmcnt(0)) at the end of the odd half 2s+1 -- a
-// full step of flight time; every buffer it overwrites was last read in half 2s-1.
-// =====================================================================================================================
-#define ATT_BAR()                               \
-    do {                                        \
-        __builtin_amdgcn_sched_barrier(0);      \
-        asm volatile("s_barrier" ::: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);      \
-    } while (0)
-#define ATT_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-// S / band MFMA with the query fragment pinned to the accumulator half of the register file (B may be an AGPR): the
-// allocator otherwise keeps 48 fragment registers in the 128 arch VGPRs and spills.  asm => no latency tracking: callers
-// pad with mfma_settle() before a VALU / DS instruction reads the accumulator.
-__device__ __forceinline__ void mfma16_qa(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma16_qv(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-#ifndef A3T_QU
-#define A3T_QU mfma16_qa
-#endif
-#ifndef A3T_QV
-#define A3T_QV mfma16_qa
-#endif
-__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 3"); }
-// O *= alpha IN PLACE in the accumulator registers, through a 16-byte LDS slot of this lane, executed only when `need`
-// (wave-uniform) is set -- the branch is INSIDE the asm on purpose.  Every formulation that lets the compiler see two
-// definitions of the accumulators (a C++ multiply on the cold path, per-element asm operands, an `if` around this asm)
-// gives O a second set of registers and moves all of it between the two sets on every step of the hot path (48
-// v_accvgpr_mov per step and 48 registers at d_k = 192).
-__device__ __forceinline__ void acc_scale4_if(f32x4& acc, float alpha, unsigned lds_addr, int need) {
-    float t0, t1, t2, t3;
-    asm volatile(
-        "s_cmp_eq_u32 %[nd], 0\n\t"
-        "s_cbranch_scc1 1f\n\t"
-        "ds_write_b128 %[ad], %[acc]\n\t"
-        "ds_read_b32 %[t0], %[ad]\n\tds_read_b32 %[t1], %[ad] offset:4\n\tds_read_b32 %[t2], %[ad] offset:8\n\tds_read_b32 %[t3], %[ad] offset:12\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_mul_f32 %[t0], %[t0], %[al]\n\tv_mul_f32 %[t1], %[t1], %[al]\n\tv_mul_f32 %[t2], %[t2], %[al]\n\tv_mul_f32 %[t3], %[t3], %[al]\n\t"
-        "ds_write_b32 %[ad], %[t0]\n\tds_write_b32 %[ad], %[t1] offset:4\n\tds_write_b32 %[ad], %[t2] offset:8\n\tds_write_b32 %[ad], %[t3] offset:12\n\t"
-        "ds_read_b128 %[acc], %[ad]\n\t"
-        "s_waitcnt lgkmcnt(0)\n"
-        "1:"
-        : [acc] "+v"(acc), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-        : [ad] "v"(lds_addr), [al] "v"(alpha), [nd] "s"(__builtin_amdgcn_readfirstlane(need))
-        : "memory", "scc");
-}
-__device__ __forceinline__ int opaque_v(int x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-
-#ifdef A3T_PP_ASM_MFMA
-#define PPM(acc, a, b) mfma16_qa(acc, a, b)
-#define PP_DRAIN() mfma_drain()
-#define PP_SETTLE() mfma_settle()
-#else   // builtins: the compiler tracks MFMA latency itself and may keep fragments / accumulators in either half of the file
-#define PPM(acc, a, b) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0)
-#define PP_DRAIN() ((void)0)
-#define PP_SETTLE() ((void)0)
-#endif
-template <int NDB, int EXP = 0>
-__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnArgs p) {
-    using D = DT16<NDB>;
-    constexpr int DK = D::DK, KS = NDB, NDT = 2 * NDB, TB = D::BYTES, CPR = D::CPR, RB = D::RB;
-    constexpr int NP = TB / 1024, NPW = (NP + 7) / 8;      // 1-KiB DMA pieces per tile / per wave
-    constexpr int NPV = (NDT + 3) / 4, NST = KS + NPV;      // M half = KS stages of S + band, NPV stages of 4 PV tiles
-    constexpr bool LOWSW = (CPR % 8) != 0;                  // swizzle < 4: chunk 4 kk + PI sits at a fixed 64 kk bytes
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Kb = smem;                            // [2]
-    unsigned char* Vb = smem + 2 * TB;                   // [2]
-    unsigned char* Pr = smem + 4 * TB;                   // 6 ring slots of 32-row Pext tiles
-    float* sc = (float*)(smem + 10 * TB);                // [8 waves][16][SC16_LD]: ring of four 16-column band blocks
-    unsigned int* kmw = (unsigned int*)(sc + 8 * 16 * SC16_LD);   // [128] key-mask words
-    unsigned char* xrow = (unsigned char*)(kmw + 128);   // [8 waves][DK] bf16: row q0 + 16 of (q+v), lane 15 of the upper half
-
-    const int tid = threadIdx.x, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
-    const int PI = ((lg & 1) << 1) | (lg >> 1);
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = (EXP & 16) ? 0 : (w >> 2);           // 0: leading group, 1: one barrier behind
-    const int T = p.T, NQB = (T + 127) / 128, NS = (T + 31) / 32;
-    int wi = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
-        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
-    }
-    const int bh = wi / NQB, qb = wi - bh * NQB;
-    const int b = bh / p.H, h = bh - b * p.H;
-    const int Q0 = qb * 128, q0 = Q0 + 16 * w, i = q0 + lq;
-    const int XB = T - Q0 - 128;
-    const u16* quB = p.qu + (int64_t)b * T * p.ldq + h * DK;
-    const u16* qvB = p.qv + (int64_t)b * T * p.ldq + h * DK;
-    const u16* kB = p.k + (int64_t)b * T * p.ldkv + h * DK;
-    const u16* vB = p.v + (int64_t)b * T * p.ldkv + h * DK;
-    const u16* pB = p.pos + h * DK;
-    const uint8_t* mkB = p.keymask + (int64_t)b * T;
-    float* scw = sc + w * 16 * SC16_LD;
-
-    // ---- DMA geometry.  Tiles arrive through buffer descriptors whose range check supplies every zero: rows past the end
-    // of the utterance, band rows x < 0, x == T (xr = -1) and x - T - 1 >= T all land beyond num_records (the row offset
-    // sits in voffset: the check ignores soffset).  Piece q of this wave = 1 KiB = 64 lanes x 16 B.
-    const unsigned ldkv2 = (unsigned)p.ldkv * 2u, ldp2 = (unsigned)p.ldp * 2u;
-    const int kvbytes = (int)((unsigned)(T - 1) * ldkv2 + DK * 2u), pbytes = (int)((unsigned)(T - 1) * ldp2 + DK * 2u);
-    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kB, 0, kvbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)vB, 0, kvbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)pB, 0, pbytes, 0x00020000);
-    unsigned voffK[2], dcol[2];      // (NPW <= 2; a template-sized array captured by the lambdas below loses the host stub for NDB = 1)
-    int drow[2];
-#pragma unroll
-    for (int q = 0; q < NPW; ++q) {
-        const int ci = (q * 8 + w) * 64 + lane;
-        const int row = ci / CPR, pos = ci - row * CPR;
-        drow[q] = row;
-        dcol[q] = (unsigned)((pos ^ D::sw(row)) * 16);
-        voffK[q] = (unsigned)row * ldkv2 + dcol[q];
-    }
-    auto issue_kv = [&](const __amdgpu_buffer_rsrc_t& r, unsigned char* tile, int s) __attribute__((always_inline)) {
-        const unsigned step = (unsigned)(32 * s) * ldkv2;
-#pragma unroll
-        for (int q = 0; q < NPW; ++q)
-            if (q * 8 + w < NP)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_AS(tile + (q * 8 + w) * 1024), 16, voffK[q] + step, 0, 0, 0);
-    };
-    auto issue_p = [&](int u) __attribute__((always_inline)) {
-        unsigned char* tile = Pr + (u % 6) * TB;
-#pragma unroll
-        for (int q = 0; q < NPW; ++q)
-            if (q * 8 + w < NP) {
-                const int x = XB + 32 * u + drow[q];
-                const int xr = x < T ? x : x - T - 1;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rP, LDS_AS(tile + (q * 8 + w) * 1024), 16, (unsigned)xr * ldp2 + dcol[q], 0, 0, 0);
-            }
-    };
-    // everything step idx+1 needs that is not resident yet: K(idx+1), V(idx) (PV(idx) runs in M(idx+1)), ring tile idx+5
-    auto issue_step = [&](int idx) __attribute__((always_inline)) {
-        if (EXP & 1) return;
-        issue_kv(rK, Kb + ((idx + 1) & 1) * TB, idx + 1);
-        issue_kv(rV, Vb + (idx & 1) * TB, idx);
-        issue_p(idx + 5);
-    };
-
-    issue_kv(rK, Kb, 0);
-#pragma unroll
-    for (int u = 0; u < 5; ++u) issue_p(u);
-    issue_kv(rV, Vb + TB, 1 << 20);                      // "V(-1)" = zeros: step 0 multiplies it by P(-1) = 0
-    if (EXP & 1) issue_kv(rV, Vb, 0), issue_kv(rK, Kb + TB, 1), issue_p(5);
-    bf16x8 fqu[KS], fqv[KS];                             // (q+u)[i]; (q+v)[i], turned into (q+v)[i+1] when the band crosses x = T
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        const int off = 32 * kk + 8 * PI;
-        fqu[kk] = ld_frag_g(quB + (int64_t)i * p.ldq + off, i < T);
-        fqv[kk] = ld_frag_g(qvB + (int64_t)i * p.ldq + off, i < T);
-    }
-    if (lane < CPR) {
-        const int r16 = q0 + 16;
-        *(uint4*)(xrow + w * DK * 2 + lane * 16) = *(const uint4*)(r16 < T ? qvB + (int64_t)r16 * p.ldq + lane * 8 : (const u16*)attn_zero_page);
-    }
-    for (int sb = w; sb < NS; sb += 8) {
-        const int jl = 32 * sb + (lane & 31);
-        const bool kvalid = (jl < T) && (mkB[jl < T ? jl : 0] != 0);
-        const unsigned int vmw = (unsigned int)__ballot(kvalid);
-        if (lane == 0) kmw[sb] = vmw;
-    }
-    __syncthreads();
-
-    // (q+v)[i] -> (q+v)[i+1], in place: lane lq takes the fragment of lane lq + 1 (same k-chunk group), lane 15 the row
-    // q0 + 16 parked in LDS.  Happens once per wave, when its band blocks cross x = T.
-    bool upper = false;
-    auto to_upper = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const uint4 x = *(const uint4*)(xrow + w * DK * 2 + (4 * kk + PI) * 16);
-            uint4 f = __builtin_bit_cast(uint4, fqv[kk]);
-            f.x = (unsigned)__builtin_amdgcn_update_dpp((int)x.x, (int)f.x, 0x101, 0xf, 0xf, false);
-            f.y = (unsigned)__builtin_amdgcn_update_dpp((int)x.y, (int)f.y, 0x101, 0xf, 0xf, false);
-            f.z = (unsigned)__builtin_amdgcn_update_dpp((int)x.z, (int)f.z, 0x101, 0xf, 0xf, false);
-            f.w = (unsigned)__builtin_amdgcn_update_dpp((int)x.w, (int)f.w, 0x101, 0xf, 0xf, false);
-            fqv[kk] = __builtin_bit_cast(bf16x8, f);
-        }
-        upper = true;
-    };
-    // per-lane LDS byte offsets of this lane's fragments inside a tile image (rows lq and 16 + lq share the swizzle)
-    int koff[LOWSW ? 1 : KS], voff[LOWSW ? 2 : NDT];
-    {
-        const int sw = D::sw(lq);
-        if (LOWSW) koff[0] = lq * RB + ((PI ^ sw) << 4);
-        else
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) koff[LOWSW ? 0 : kk] = lq * RB + (((4 * kk + PI) ^ sw) << 4);
-        const int r0 = 4 * lg + (lq >> 2), e = (lq & 3) >> 1, in = 8 * (lq & 1), swv = D::sw(r0);
-        if (LOWSW) voff[0] = r0 * RB + ((e ^ swv) << 4) + in, voff[1] = r0 * RB + (((2 + e) ^ swv) << 4) + in;
-        else
-#pragma unroll
-            for (int d = 0; d < NDT; ++d) voff[LOWSW ? 0 : d] = r0 * RB + (((2 * d + e) ^ swv) << 4) + in;
-    }
-    // base = byte offset of (tile + row block) in smem, already combined with koff[0] / made opaque by the caller when LOWSW
-    auto frag_k = [&](const int base, const int kk) __attribute__((always_inline)) -> bf16x8 {
-        if (LOWSW) return *(const bf16x8*)(smem + base + 64 * kk);
-        return *(const bf16x8*)(smem + base + koff[LOWSW ? 0 : kk]);
-    };
-    auto kbase = [&](const int tile_off) __attribute__((always_inline)) -> int { return LOWSW ? opaque_v(tile_off + koff[0]) : tile_off; };
-    // vb0 / vb1: opaque per-step bases (LOWSW: even / odd output tile)
-    auto frag_v = [&](const int vb0, const int vb1, const int d) __attribute__((always_inline)) -> bf16x8 {
-        const unsigned char* a0 = LOWSW ? smem + ((d & 1) ? vb1 : vb0) + 64 * (d >> 1) : smem + vb0 + voff[LOWSW ? 0 : d];
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0 + 16 * RB));
-        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
-    };
-
-    // block n of the band (16 x-rows, base x = XB + 16 n) lies in the (q+v)[i+1] half iff x >= T  <=>  16 n >= Q0 + 128
-    {
-        const int n = 7 - w;
-        if (16 * n >= Q0 + 128) to_upper();
-        const int slot = kbase(4 * TB + ((n >> 1) % 6) * TB + 16 * (n & 1) * RB);
-        f32x4 acc = zero4();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_k(slot, kk), fqv[kk], acc, 0, 0, 0);
-        *(float4*)(scw + lq * SC16_LD + 16 * (n & 3) + 4 * lg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    if (grp == 0) issue_step(0);                         // global half 0 (group 1 issues its share before its extra barrier)
-
-    f32x4 O[NDT];
-#pragma unroll
-    for (int d = 0; d < NDT; ++d) O[d] = zero4();
-    float m_run = -1e30f, l_run = 0.f;
-    const float NEG_INF = -__builtin_inff();
-    const unsigned int ibase = (unsigned int)(((int64_t)bh * T + i) * T);
-    bf16x8 pf = zero_frag();
-    f32x4 sa0, sa1;
-    float sv[8];
-
-    // One M half.  Fragments are read from LDS PD stages ahead of the MFMAs that use them (PD + 1 staging sets of four
-    // fragments); sched_barriers pin the order, the compiler's own counted lgkmcnt waits then come out right.
-    // MIXED: the one step of a wave whose first new band block still belongs to (q+v)[i] and whose second one to (q+v)[i+1].
-    constexpr int PD = 2;
-    auto mhalf = [&](auto MIXED, const int s) __attribute__((always_inline)) {
-        constexpr bool mixed = decltype(MIXED)::value;
-        const int n0 = 7 - w + 2 * s;
-        const int Kt = kbase((s & 1) * TB), Kt16 = LOWSW ? Kt : Kt + 16 * RB;
-        const int vt = 2 * TB + ((s + 1) & 1) * TB;                       // V(s-1)
-        const int vb0 = LOWSW ? opaque_v(vt + voff[0]) : vt, vb1 = LOWSW ? opaque_v(vt + voff[1]) : vt;
-        const int blk1 = kbase(4 * TB + (((n0 + 1) >> 1) % 6) * TB + 16 * ((n0 + 1) & 1) * RB);
-        const int blk2 = kbase(4 * TB + (((n0 + 2) >> 1) % 6) * TB + 16 * ((n0 + 2) & 1) * RB);
-        bf16x8 st[PD + 1][4];
-        f32x4 b1 = zero4(), b2 = zero4();
-        sa0 = zero4(), sa1 = zero4();
-        auto rd = [&](const int t) __attribute__((always_inline)) {
-            const int sl = t % (PD + 1);
-            if (t < KS) {
-                if (EXP & 8) return;
-                st[sl][0] = frag_k(Kt, t);
-                st[sl][1] = frag_k(Kt16, LOWSW ? t + (16 * RB) / 64 : t);
-                st[sl][2] = frag_k(blk1, t);
-                if (!mixed) st[sl][3] = frag_k(blk2, t);
-            } else if (t < NST) {
-                if (EXP & 4) return;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * (t - KS) + e < NDT) st[sl][e] = frag_v(vb0, vb1, 4 * (t - KS) + e);
-            }
-        };
-#pragma unroll
-        for (int t = 0; t < PD; ++t) {
-            rd(t);
-            PHASE_FENCE();
-        }
-#pragma unroll
-        for (int t = 0; t < NST; ++t) {
-            if (!(mixed && t + PD >= KS)) rd(t + PD);     // (mixed: the PV fragments are fetched after the second band chain)
-            PHASE_FENCE();
-            const int sl = t % (PD + 1);
-            if (t < KS) {
-                if (!(EXP & 8)) {
-                    PPM(sa0, st[sl][0], fqu[t]);
-                    PPM(sa1, st[sl][1], fqu[t]);
-                    PPM(b1, st[sl][2], fqv[t]);
-                    if (!mixed) PPM(b2, st[sl][3], fqv[t]);
-                }
-                if (t == KS - 1) {
-                    PHASE_FENCE();
-                    if (mixed) {
-                        PP_SETTLE();
-                        to_upper();
-#pragma unroll
-                        for (int kk = 0; kk < KS; ++kk) PPM(b2, frag_k(blk2, kk), fqv[kk]);
-#pragma unroll
-                        for (int u = KS; u < KS + PD && u < NST; ++u) rd(u);
-                    }
-                    PP_SETTLE();
-                    *(float4*)(scw + lq * SC16_LD + 16 * ((n0 + 1) & 3) + 4 * lg) = make_float4(b1[0], b1[1], b1[2], b1[3]);
-                    *(float4*)(scw + lq * SC16_LD + 16 * ((n0 + 2) & 3) + 4 * lg) = make_float4(b2[0], b2[1], b2[2], b2[3]);
-                    // skewed band read: (query ii, key kk) <- band column 15 - ii + kk of blocks n0 .. n0+2; issued here so that
-                    // its latency runs under PV(s-1) and the barrier
-                    const int c0 = 16 * (n0 & 3) + 15 - lq + 4 * lg;
-                    const float* srow = scw + lq * SC16_LD;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) sv[r] = srow[(c0 + (r & 3) + 16 * (r >> 2)) & 63];
-                }
-            } else if (!(EXP & 4)) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * (t - KS) + e < NDT) PPM(O[4 * (t - KS) + e], st[sl][e], pf);
-            }
-            PHASE_FENCE();
-        }
-        PP_DRAIN();
-    };
-    typedef std::integral_constant<bool, false> FalseT;
-    typedef std::integral_constant<bool, true> TrueT;
-
-    if (grp == 1) {
-        issue_step(0);
-        ATT_BAR();
-    }
-    for (int s = 0; s < NS; ++s) {
-        // ================================ M half: S(s), band(s), PV(s-1) ==============================================
-        if (grp == 0 && s > 0) issue_step(s);
-        {
-            const int n0 = 7 - w + 2 * s;
-            const bool up1 = 16 * (n0 + 1) >= Q0 + 128, up2 = 16 * (n0 + 2) >= Q0 + 128;
-            if (up1 && !upper) to_upper();
-            if (up1 == up2) mhalf(FalseT(), s);
-            else mhalf(TrueT(), s);
-        }
-        if (grp == 1) ATT_WAIT_VM0();                     // end of global half 2s+1: what was issued in half 2s has landed
-        ATT_BAR();
-        // ================================ V half: softmax(s) ==========================================================
-        if (grp == 1 && s + 1 < NS) issue_step(s + 1);    // global half 2(s+1)
-        if (EXP & 2) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) sv[r] = (r < 4 ? sa0[r & 3] : sa1[r & 3]) + sv[r];
-            pf = pack_frag(sv);
-        } else {
-            const unsigned int vm = kmw[s];
-            float mloc = NEG_INF;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int kk = (r & 3) + 16 * (r >> 2) + 4 * lg;
-                const float x = ((r < 4 ? sa0[r & 3] : sa1[r & 3]) + sv[r]) * p.scale;
-                sv[r] = ((vm >> kk) & 1u) ? x : NEG_INF;
-                mloc = fmaxf(mloc, sv[r]);
-            }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            {   // deferred-max rescale, branch-free in C++ (alpha = 1 unless some row's maximum grew by more than 8)
-                const int need = __any(mloc > m_run + 8.f) ? 1 : 0;
-                const float mnew = need ? fmaxf(m_run, mloc) : m_run;
-                const float alpha = __expf(m_run - mnew);
-                l_run *= alpha;
-                m_run = mnew;
-                // (PV(s-1) drained before the barrier; the LDS slot is this lane's float4 of band block n0, dead since the skew read)
-                const unsigned slot = (unsigned)(uintptr_t)LDS_AS(scw + lq * SC16_LD + 16 * ((7 - w + 2 * s) & 3) + 4 * lg);
-#pragma unroll
-                for (int d = 0; d < NDT; ++d) acc_scale4_if(O[d], alpha, slot, need);
-            }
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                sv[r] = __expf(sv[r] - m_run);
-                psum += sv[r];
-            }
-            l_run += psum;
-            if (p.drop_thr) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    bool kp[4];
-                    rng_keep4(p.drop_key, ibase + (unsigned int)(32 * s + 16 * g + 4 * lg), p.drop_thr, kp);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sv[4 * g + e] = kp[e] ? sv[4 * g + e] * p.drop_inv : 0.f;
-                }
-            }
-            pf = pack_frag(sv);
-        }
-        if (grp == 0) ATT_WAIT_VM0();                     // end of global half 2s+1
-        ATT_BAR();
-    }
-    // ---- tail: PV(NS-1).  Group 1 runs it one half later; group 0 keeps the barrier count equal.
-    if (!(EXP & 4)) {
-        const int vt = 2 * TB + ((NS - 1) & 1) * TB;
-        const int vb0 = LOWSW ? vt + voff[0] : vt, vb1 = LOWSW ? vt + voff[1] : vt;
-#pragma unroll
-        for (int d = 0; d < NDT; ++d) PPM(O[d], frag_v(vb0, vb1, d), pf);
-        PP_DRAIN();
-    }
-    if (!(EXP & 16)) ATT_BAR();
-
-    float l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float invl = l > 0.f ? 1.f / l : 0.f;
-    if (i < T) {
-        u16* o = p.ctx + ((int64_t)b * T + i) * p.ldo + h * DK + 4 * lg;
-#pragma unroll
-        for (int d = 0; d < NDT; ++d) {
-            uint2 v2;
-            v2.x = io_pack2(O[d][0] * invl, O[d][1] * invl);
-            v2.y = io_pack2(O[d][2] * invl, O[d][3] * invl);
-            *(uint2*)(o + 16 * d) = v2;
-        }
-        if (lg == 0) p.lse[(int64_t)bh * T + i] = l > 0.f ? m_run + __logf(l) : __builtin_inff();
-    }
-}
-
 __device__ __forceinline__ void st4_bf16(u16* dst, float a, float b, float c, float d);
+
 // =====================================================================================================================
 // Forward, round 4: 4 waves x 32 queries, ONE wave per SIMD with the whole 512-entry register file, 32x32x16 MFMAs.
 // Why not more waves: at d_k = 192 a wave's resident set is O (16 q x 192 -> 48 registers per 16 queries), (q+u) and
@@ -1811,13 +1395,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
 
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
-// A3T_ATTN_FWD=16: the rescaling 16-query kernel alone (round 2); =pp: the staggered 16-query experiment; default: the
-// 32-query one-wave-per-SIMD kernel + the 16-query kernel as its overflow fixup
+// A3T_ATTN_FWD=16: the rescaling 16-query kernel alone (round 2); default: the 32-query one-wave-per-SIMD kernel + the
+// 16-query kernel as its overflow fixup
 static int attn_fwd_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("A3T_ATTN_FWD");
-        mode = (e && !strcmp(e, "16")) ? 0 : (e && !strcmp(e, "pp")) ? 1 : 2;
+        mode = (e && !strcmp(e, "16")) ? 0 : 2;
     }
     return mode;
 }
@@ -1825,17 +1409,12 @@ static int attn_fwd_mode() {
 template <int NDB>
 static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     constexpr int TB = DT16<NDB>::BYTES;
-    constexpr int lds = 10 * TB + 8 * 16 * SC16_LD * 4 + 4 * 128 + 8 * 64 * NDB;
+    constexpr int lds = 10 * TB + 8 * 16 * SC16_LD * 4 + 4 * 128;
     // (the attribute is per device: set it on every launch -- a process that drives several GPUs would otherwise launch on
     //  its second device without the raised LDS limit)
     const int nqb = (a.T + 127) / 128;
     const unsigned grid = (unsigned)(a.B * a.H * nqb);
     const int mode = attn_fwd_mode();
-    if (mode == 1) {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(attn_fwd_pp_kernel<NDB>, dim3(grid), dim3(512), lds, s, a);
-        return (int)hipGetLastError();
-    }
     AttnArgs a16 = a;
     if (a.probs && !(mode == 2 && grid <= (1u << 16))) return A3T_EINVAL;   // only the fixed-reference kernel can save probabilities
     if (mode == 2 && grid <= (1u << 16)) {

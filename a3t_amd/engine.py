@@ -61,6 +61,11 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
+# measurement only (tools/step_ab.sh): what the FFN weight gradients cost inside the two-stream step -- the step WITHOUT them
+# (wrong gradients, never set in production) bounds what any faster weight-gradient kernel can buy
+_SKIP_FFN_WGRAD = os.environ.get("A3T_EXPERIMENT_SKIP_FFN_WGRAD", "0") == "1"
+
+
 class MLMEngine:
     def __init__(self, cfg: A3TConfig, store: ParamStore, compute: str = "f32", training: bool = True,
                  dropout: bool = False):
@@ -386,7 +391,8 @@ class MLMEngine:
         self._sub_begin()
         g16 = self._g16(g)
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".b2"], 0.5)
-        self._side(lambda: ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp))
+        if not _SKIP_FFN_WGRAD:
+            self._side(lambda: ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp))
         dh = self._act(self._t("tmp.dh"), (M, c.ff))
         # (without dropout b2's gradient = 0.5*colsum(g) was accumulated by the LayerNorm backward that
         #  produced g; the dropout on h folds into the relu mask S=h>0 and the 1/(1-p) factor)
@@ -401,7 +407,8 @@ class MLMEngine:
         else:
             ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=a_dh,
                               compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
-        self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp))
+        if not _SKIP_FFN_WGRAD:
+            self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp))
         dy = self._act("tmp.dy", (M, c.adim))
         if self._ffn_plan(M)[1]:
             ops.conv_fwd(dh, self._wt["w1"][2][pre + ".w1"], dy, T, c.ff_kernel - 1 - pad, compute=self.cmp)

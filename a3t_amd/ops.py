@@ -1,6 +1,7 @@
 """Thin host wrappers over the C ABI (include/a3t_hip.h): torch tensors supply device memory and
 the current HIP stream, every computation happens in liba3t_hip.so.  No torch math here."""
 import ctypes
+import os
 
 import torch
 
@@ -72,12 +73,15 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
 
 
+_SPLITK_TARGET = int(os.environ.get("A3T_SPLITK_TARGET", "1000"))   # A/B knob (tools/step_ab.sh)
+
+
 def _splitk_for(n_tiles, K, ktile=64):
     """Token-reduction GEMMs (weight gradients) have few output tiles: split K over workgroups so the
     grid is ONE resident wave of the kernel variant a3t_gemm will pick -- ~1000 workgroups for the
     single-buffer variant (4/CU, chosen when tiles*splitk >= 768), ~440 for the double-buffered one
     (2/CU); more splits only add fp32 atomics (measured on MI355X, tools/tn_bench*.py)."""
-    target = 1000 if n_tiles >= 64 else 440
+    target = _SPLITK_TARGET if n_tiles >= 64 else 440
     s = max(1, target // max(n_tiles, 1))
     s = min(s, max(1, K // (ktile * 8)))
     return int(s)

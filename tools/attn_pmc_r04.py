@@ -1,0 +1,24 @@
+"""The attention kernels alone for rocprofv3 counter passes (tools/r04_profiles.sh): a few launches of the fused forward
+(inference and training variants) and of the materialised backward's kernels at the benchmark shape."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+from a3t_amd import ops
+from test_gpu_attn_fused import _inputs
+
+B, H, T, dk = 32, 2, 1120, 192
+d, M = H * dk, B * T
+qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=1)
+ctx = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
+lse = torch.zeros(B, H, T, device="cuda")
+probs = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+pdrop = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+rs = torch.zeros(B, H, T, device="cuda")
+for _ in range(3):
+    ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
+    ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
+torch.cuda.synchronize()
