@@ -797,15 +797,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             if (SAVE && DROP) stage4(1, g);
         };
         // softmax slices over the KS product stages: exponentials first, then the dropout quads, then the packing
-        constexpr int EXS = KS >= 8 ? KS - 4 : (KS > 1 ? KS - 1 : 1);        // stages that carry exponentials
+#ifndef A3T_EXS_N
+#define A3T_EXS_N (KS - 4)
+#endif
+#ifndef A3T_FENCE_EVERY
+#define A3T_FENCE_EVERY 1
+#endif
+        constexpr int EXS = KS >= 8 ? (A3T_EXS_N) : (KS > 1 ? KS - 1 : 1);   // stages that carry exponentials (the dropout quads follow)
         auto slice = [&](const int t) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (r * EXS / 16 == t) expo(r);
             if (KS >= 8) {
-                if (t == KS - 5 && SAVE) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3);   // (all sixteen exponentials are done after stage EXS - 1 = KS - 5)
-                if (t == KS - 3 && SAVE) flush(rSP, 0);
-                if (t >= KS - 4) drop4(t - (KS - 4)), dsave(t - (KS - 4));
+                if (t == EXS - 1 && SAVE) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3);   // (all sixteen exponentials are done after stage EXS - 1)
+                if (t == EXS + 1 && SAVE) flush(rSP, 0);
+                if (t >= EXS && t < EXS + 4) drop4(t - EXS), dsave(t - EXS);
             } else if (t == KS - 1) {
                 if (SAVE) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3), flush(rSP, 0);
 #pragma unroll
@@ -835,7 +841,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
                 issue_p(s + 6);
             }
             slice(t);
-            PHASE_FENCE();
+            if ((t + 1) % (A3T_FENCE_EVERY) == 0 || t == KS - 1) PHASE_FENCE();
         }
         l_run += psum;
     };

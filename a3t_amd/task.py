@@ -67,8 +67,9 @@ class MLMTask:
         return LogMelFbank(device=device, **conf)
 
     @classmethod
-    def build_collate_fn(cls, args: argparse.Namespace, train: bool, epoch: int = -1, device="cuda") -> Callable:
-        """tasks/mlm.py:262-291."""
+    def build_collate_fn(cls, args: argparse.Namespace, train: bool, epoch: int = -1, device="cuda",
+                         device_out: bool = False) -> Callable:
+        """tasks/mlm.py:262-291.  device_out=True (extension): the batch dict comes back as device tensors, built on the GPU."""
         feats = cls._feats(args, device)
         sega = args.encoder_conf.get("input_layer") == "sega_mlm"
         if args.encoder_conf.get("selfattention_layer_type") == "longformer":
@@ -77,7 +78,7 @@ class MLMTask:
         dur = args.model_conf.get("duration_predictor_layers", 0) > 0
         return MLMCollateFn(feats, float_pad_value=0.0, int_pad_value=0, mlm_prob=args.model_conf["mlm_prob"] * factor,
                             mean_phn_span=args.model_conf["mean_phn_span"], attention_window=0, pad_speech=False,
-                            sega_emb=sega, duration_collect=dur)
+                            sega_emb=sega, duration_collect=dur, device_out=device_out)
 
     @classmethod
     def build_model(cls, args: argparse.Namespace, device="cpu", compute: str = "f32") -> ESPnetMLMEncAsDecoderModel:
