@@ -129,6 +129,8 @@ class MLMEngine:
         self.fused_attn_fwd_only = self.bf16 and fa == "fwd"
         self.fused_attn_auto = self.bf16 and fa == "auto"
         self.fused_attn_train = self.bf16 and fa == "auto" and os.environ.get("A3T_FUSED_ATTN_TRAIN", "1") != "0"
+        # (=2: also below the 64-workgroup threshold -- the small-batch parity fixtures go through the fused kernel that way)
+        self.fused_attn_train_min = 1 if os.environ.get("A3T_FUSED_ATTN_TRAIN", "1") == "2" else 64
         self._fused_now = self.fused_attn
         self._fused_train_now = False
         self._need_grad = training
@@ -719,7 +721,8 @@ class MLMEngine:
         self._fused_now = self.fused_attn or (self.fused_attn_fwd_only and not need_grad) or \
             (self.fused_attn_auto and not need_grad and B * c.heads * ((T + 127) // 128) >= 64)
         nblk = B * c.heads * ((T + 127) // 128)
-        self._fused_train_now = self.fused_attn_train and need_grad and not self._fused_now and 64 <= nblk <= 65536 and T <= 2048
+        self._fused_train_now = self.fused_attn_train and need_grad and not self._fused_now and \
+            self.fused_attn_train_min <= nblk <= 65536 and T <= 2048
         self._need_grad = bool(need_grad)
         self._mode_tag = ops.gemm_mode_tag()
         self.step_seed += 1
