@@ -64,6 +64,9 @@ class Workspace:
 # measurement only (tools/step_ab.sh): what the FFN weight gradients cost inside the two-stream step -- the step WITHOUT them
 # (wrong gradients, never set in production) bounds what any faster weight-gradient kernel can buy
 _SKIP_FFN_WGRAD = os.environ.get("A3T_EXPERIMENT_SKIP_FFN_WGRAD", "0") == "1"
+# the same kind of bound for a fused attention backward: 1 = the step without dprobs GEMM, softmax backward and the dQu GEMM
+# (what a query-pass kernel reading the saved probabilities would replace), 2 = without the first two only
+_SKIP_ATTN_BWD_MAIN = int(os.environ.get("A3T_EXPERIMENT_SKIP_ATTN_BWD", "0"))
 
 
 class MLMEngine:
@@ -548,8 +551,9 @@ class MLMEngine:
         dpr = self.ws.get("tmp.ac", (B, H, T, T), sdt)      # reuse the score buffers
         zb = (H * T * T, T * T)
         # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
-        ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
-                 b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
+        if not _SKIP_ATTN_BWD_MAIN:
+            ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
+                     b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
         fz = self.bf16   # bias / pos-bias gradients ride on the GEMM epilogues as column sums
         gbq = gr[pre + ".bqkv"]
@@ -577,8 +581,9 @@ class MLMEngine:
         # bf16 path: the attention-dropout mask comes back from the counter RNG (same key and index as the forward) instead
         # of being read off the dropped probabilities: one T x T read less in the most HBM-bound kernel of the step
         regen = self.bf16 and self.attn_regen and adr is not None and T % 8 == 0 and T <= 2048
-        ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
-                               drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0, rowscale=rs)
+        if not _SKIP_ATTN_BWD_MAIN:
+            ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
+                                   drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0, rowscale=rs)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
             dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
             if hm:
@@ -597,8 +602,9 @@ class MLMEngine:
         dqu = self._act("tmp.dqu", (M, d))
         dqv = self._act("tmp.dqv", (M, d))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
-        ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=sl if fz else None, **csk)
+        if _SKIP_ATTN_BWD_MAIN != 1:
+            ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
+                     b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=sl if fz else None, **csk)
         dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
                                               a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
                                               colsum=sl[2 * d:] if fz else None, **csk), want_event=True)

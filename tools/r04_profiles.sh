@@ -72,6 +72,6 @@ python tools/attn_fwd_time.py 16 4 1800 128 >> gpurun_out/r04_attn_bench.txt 2>&
 TRAIN=1 python tools/attn_fwd_time.py 16 4 1800 128 >> gpurun_out/r04_attn_bench.txt 2>&1
 A3T_ATTN_FWD=16 python tools/attn_fwd_time.py 16 4 1800 128 >> gpurun_out/r04_attn_bench.txt 2>&1
 python tools/collate_time.py > gpurun_out/r04_collate_time.txt 2>&1
-bash tools/step_ab.sh "default:A3T_X=0" "materialised_attention_forward:A3T_FUSED_ATTN_TRAIN=0" "one_stream:A3T_SIDE_STREAM=0" "without_ffn_weight_gradients(bound,wrong_gradients):A3T_EXPERIMENT_SKIP_FFN_WGRAD=1" "default_again:A3T_X=0" > gpurun_out/r04_step_ab.txt 2>&1
+bash tools/step_ab.sh "default:A3T_X=0" "materialised_attention_forward:A3T_FUSED_ATTN_TRAIN=0" "one_stream:A3T_SIDE_STREAM=0" "without_ffn_weight_gradients(bound,wrong_gradients):A3T_EXPERIMENT_SKIP_FFN_WGRAD=1" "without_dprobs_softmaxbwd_dqu(bound,wrong_gradients):A3T_EXPERIMENT_SKIP_ATTN_BWD=1" "without_dprobs_softmaxbwd(bound,wrong_gradients):A3T_EXPERIMENT_SKIP_ATTN_BWD=2" "default_again:A3T_X=0" > gpurun_out/r04_step_ab.txt 2>&1
 bash tools/c4_ab.sh "default:A3T_X=0" "materialised_attention_forward:A3T_FUSED_ATTN_TRAIN=0" > gpurun_out/r04_c4_ab.txt 2>&1
 tail -c 600 gpurun_out/r04_bench_n1.json; cat gpurun_out/r04_attn_pmc.log | tail -4; cat gpurun_out/r04_step_ab.txt
