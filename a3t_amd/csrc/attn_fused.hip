@@ -69,6 +69,10 @@ struct AttnArgs {
     u16* probs;           // [B][H][T][T]
     u16* pdrop;           // the same after attention dropout (NULL without dropout)
     float* rowscale;      // [B][H][T]: 1 / row sum, the factor that normalises a row of probs / pdrop
+    // forward, key-split launch of the tail blocks (launch_fwd16): blocks item0 .. of the (b, h, query block) order, nparts
+    // key ranges each; partial sums go to part_ws and attn_split_finish_kernel folds them
+    int item0, nparts;
+    float* part_ws;       // [items][nparts][128][dk] O, then [items][nparts][128] l, then [items][128] m2
 };
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -469,7 +473,7 @@ __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NDB, bool DROP, bool SAVE, bool TWOPASS = false>
+template <int NDB, bool DROP, bool SAVE, bool TWOPASS = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     using D = DT32<NDB>;
     constexpr int DK = D::DK, KS = DK / 16, TB = D::BYTES, CPR = D::CPR, RB = D::RB, NPW = D::NP / 4;
@@ -485,13 +489,42 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, NQB = (T + 127) / 128, NS = (T + 31) / 32;
-    int wi = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+    // SPLIT launch: workgroups item0 .. are the tail blocks, one workgroup per (block, key range); they are dispatched last
+    int wi = blockIdx.x, part = 0, titem = 0;
+    const bool split = SPLIT && wi >= p.item0;
+    if (split) {
+        const int t = wi - p.item0;
+        titem = t / p.nparts, part = t - titem * p.nparts;
+        wi = p.item0 + titem;
+    } else {
+        const int nwg = SPLIT ? p.item0 : (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
         wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
     if (TWOPASS && attn_redo[wi & 0xffff] == 0) return;     // fixup launch: only the blocks whose row sums overflowed
     const int bh = wi / NQB, qb = wi - bh * NQB;
+    const int sa_ = split ? (part * NS) / p.nparts : 0, sb = split ? ((part + 1) * NS) / p.nparts : NS;
+    float* wsO = nullptr;
+    float* wsL = nullptr;
+    float* wsM = nullptr;
+    if (split) {
+        const int64_t pairs = (int64_t)gridDim.x - p.item0, nrow = pairs * 128, pr = (int64_t)(blockIdx.x - p.item0) * 128 + 32 * w + lr;
+        wsO = p.part_ws + pr * DK;                        // [pair][128][DK] | [pair][128] | [block][128]
+        wsL = p.part_ws + nrow * DK + pr;
+        wsM = p.part_ws + nrow * (DK + 1) + (int64_t)titem * 128 + 32 * w + lr;
+    }
+    // a part's partial sums: un-normalised O and l relative to the block's reference maximum m2 (part 0 files m2)
+    auto part_out = [&](const f32x16* O_, const float l_, const float m2_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(wsO + 32 * d + 8 * g + 4 * lh) = make_float4(O_[d][4 * g], O_[d][4 * g + 1], O_[d][4 * g + 2], O_[d][4 * g + 3]);
+        if (lh == 0) {
+            *wsL = l_;
+            if (part == 0) *wsM = m2_;
+        }
+        if (tid == 0 && part == 0) attn_redo[wi & 0xffff] = 0;      // attn_split_finish_kernel raises it
+    };
     const int b = bh / p.H, h = bh - b * p.H;
     const int Q0 = qb * 128, q0 = Q0 + 32 * w, i = q0 + lr;
     const int X0 = T - 32 - Q0;                          // band block u covers x in [X0 + 32 (u - 3), +32)
@@ -514,6 +547,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     int s0 = 0;
     while (s0 < NS && kmw[s0] == 0) ++s0;
     s0 = __builtin_amdgcn_readfirstlane(s0);
+    if (split && s0 >= NS) {                              // (no valid key: part 0 files m2 = +inf, the fold writes ctx = 0, lse = +inf)
+        if (SAVE && i < T)
+            for (int c = 32 * sa_ + lh * 4; c < 32 * sb && c < T; c += 8) {
+                *(uint2*)(p.probs + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+                if (DROP) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+            }
+        f32x16 Oz[NDB];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) Oz[d] = zero16();
+        part_out(Oz, 0.f, __builtin_inff());
+        return;
+    }
     if (s0 >= NS) {                                       // no valid key at all: zero context, lse = +inf
         if (i < T) {
             u16* o = p.ctx + ((int64_t)b * T + i) * p.ldo + h * DK;
@@ -530,8 +575,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         if (tid == 0) attn_redo[wi & 0xffff] = 0;
         return;
     }
+    const int sa = split ? (sa_ > s0 ? sa_ : s0) : s0;    // this workgroup's key tiles: [sa, sb)
     if (SAVE && i < T)                                    // key tiles in front of the first valid one are skipped: their probabilities are 0
-        for (int c = lh * 4; c < 32 * s0; c += 8) {
+        for (int c = 32 * sa_ + lh * 4; c < 32 * s0 && c < 32 * sb; c += 8) {
             *(uint2*)(p.probs + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
             if (DROP) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
         }
@@ -693,21 +739,31 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             band_read(u, bd2);
             m2 = fmaxf(m2, tile_max(s, S2, bd2));
         }
-        __syncthreads();
-        issue_kv(rK, Kb + (s0 & 1) * TB, s0);
-        issue_kv(rK, Kb + ((s0 + 1) & 1) * TB, s0 + 1);
+    }
+    if (split && sa >= sb) {                              // a key range in front of the first valid key: nothing to add
+        f32x16 Oz[NDB];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) issue_p(s0 + u);
+        for (int d = 0; d < NDB; ++d) Oz[d] = zero16();
+        part_out(Oz, 0.f, m2);
+        return;
+    }
+    if (TWOPASS || (split && sa != s0)) {                 // (re)start the pipeline at key tile sa
+        __syncthreads();
+        issue_kv(rK, Kb + (sa & 1) * TB, sa);
+        issue_kv(rK, Kb + ((sa + 1) & 1) * TB, sa + 1);
+        issue_kv(rV, Vb + (sa & 1) * TB, sa);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) issue_p(sa + u);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        Sc = s_mm(Kb + (s0 & 1) * TB);
-        const int u = s0 - w + 3;
+        Sc = s_mm(Kb + (sa & 1) * TB);
+        const int u = sa - w + 3;
         band_store(u, band_mm(u));
         band_store(u + 1, band_mm(u + 1));
         band_read(u, bd);
     }
-    __syncthreads();                                      // every wave is through with ring tile s0
-    issue_p(s0 + 5);
+    __syncthreads();                                      // every wave is through with ring tile sa
+    issue_p(sa + 5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -874,7 +930,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     typedef std::integral_constant<bool, true> TrueT;
     constexpr int NSV = SAVE ? (DROP ? 4 : 2) : 0;      // probability stores per iteration
 
-    for (int s = s0; s < NS; ++s) {
+    for (int s = sa; s < sb; ++s) {
         // resident: K(s+1), V(s), ring tiles s+1 .. s+5; registers: Sc = S(s), bd = band values of step s
         TSTAMP(0);
         TSTAMP(1);
@@ -905,6 +961,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 #endif
 
     float l = l_run + __shfl_xor(l_run, 32, 64);
+    if (split) {
+        part_out(O, l, m2);
+        return;
+    }
     const bool bad = !(l < 3.0e38f);                      // +inf / NaN: some score exceeded the reference maximum by > ~88
     const float invl = l > 0.f ? 1.f / l : 0.f;
     if (i < T) {
@@ -1394,7 +1454,87 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
     }
 }
 
+// Fold of the key-split tail blocks (launch_fwd16): O = sum of the parts' un-normalised sums, l likewise, both relative to
+// the block's one reference maximum -> ctx, lse, rowscale and the overflow flag exactly as the unsplit epilogue writes them.
+// grid = items x 8, 4 waves x 4 rows each, lane = 4 columns.
+__global__ __launch_bounds__(256) void attn_split_finish_kernel(AttnArgs p, int nitems, int DK) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int titem = blockIdx.x >> 3, P = p.nparts, T = p.T, NQB = (T + 127) / 128;
+    const int wi = p.item0 + titem, bh = wi / NQB, qb = wi - bh * NQB, b = bh / p.H, h = bh - b * p.H;
+    const int64_t nrow = (int64_t)nitems * P * 128;
+    bool bad = false;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = (blockIdx.x & 7) * 16 + w * 4 + rr, i = qb * 128 + row;
+        if (i >= T) continue;
+        float l = 0.f;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < P; ++q) {
+            const int64_t pr = ((int64_t)titem * P + q) * 128 + row;
+            l += p.part_ws[nrow * DK + pr];
+            if (lane * 4 < DK) {
+                const float4 v = *(const float4*)(p.part_ws + pr * DK + lane * 4);
+                o.x += v.x, o.y += v.y, o.z += v.z, o.w += v.w;
+            }
+        }
+        const float m2 = p.part_ws[nrow * (DK + 1) + (int64_t)titem * 128 + row];
+        bad = bad || !(l < 3.0e38f);
+        const float invl = l > 0.f ? 1.f / l : 0.f;
+        if (lane * 4 < DK) {
+            uint2 pk;
+            pk.x = io_pack2(o.x * invl, o.y * invl), pk.y = io_pack2(o.z * invl, o.w * invl);
+            *(uint2*)(p.ctx + ((int64_t)b * T + i) * p.ldo + h * DK + lane * 4) = pk;
+        }
+        if (lane == 0) {
+            p.lse[(int64_t)bh * T + i] = m2 == __builtin_inff() ? m2 : (m2 + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+            if (p.rowscale) p.rowscale[(int64_t)bh * T + i] = invl;
+        }
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&attn_redo[wi & 0xffff], 1);
+}
+
 static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
+
+// workspace of the key-split launch, one per device, allocated at the first use (<= 256 (block, part) pairs of 128 rows):
+// like the overflow flags it serves ONE attention launch at a time per device (the engine issues them on one stream)
+static float* attn_split_ws(size_t floats) {
+    static float* ws[64];
+    static size_t cap[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (cap[dev] < floats) {
+        if (ws[dev]) (void)hipFree(ws[dev]);
+        ws[dev] = nullptr, cap[dev] = 0;
+        if (hipMalloc((void**)&ws[dev], floats * sizeof(float)) != hipSuccess) return nullptr;
+        cap[dev] = floats;
+    }
+    return ws[dev];
+}
+static int attn_cus() {
+    static int n[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        n[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return n[dev];
+}
+// A3T_ATTN_SPLIT=0 / a3t_attn_split_mode(0): no key-split of the tail blocks
+static int g_attn_split = -1;
+static int attn_split_on() {
+    if (g_attn_split < 0) {
+        const char* e = getenv("A3T_ATTN_SPLIT");
+        g_attn_split = (e && !strcmp(e, "0")) ? 0 : 1;
+    }
+    return g_attn_split;
+}
+extern "C" int a3t_attn_split_mode(int mode) {
+    const int old = attn_split_on();
+    g_attn_split = mode < 0 ? -1 : (mode ? 1 : 0);
+    return old;
+}
 
 // A3T_ATTN_FWD=16: the rescaling 16-query kernel alone (round 2); default: the 32-query one-wave-per-SIMD kernel + the
 // 16-query kernel as its overflow fixup
@@ -1423,10 +1563,33 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     if ((mode == 2 || a.probs) && grid <= (1u << 16)) {
         constexpr int TB32 = DT32<NDB>::BYTES;
         constexpr int lds32 = 9 * TB32 + 4 * 32 * SC_LD * 4 + 136 * 4 + 4 * 2 * 2048;
+        // One workgroup per CU and equal workgroups: the launch runs in ceil(grid / CUs) rounds and the last one may be mostly
+        // empty (configs[1]: 576 blocks = 2.25 rounds on 256 CUs -> the time of 3).  The blocks of a last round that fills at most
+        // half the chip go to the END of the grid, each split into 2..4 key ranges (one short round instead of a full one); the parts
+        // share the block's reference maximum (every part evaluates the first valid key tile), so their un-normalised sums add.
+        const int cus = attn_cus();
+        const unsigned nfull = (grid / (unsigned)cus) * (unsigned)cus, ntail = grid - nfull;
+        int nparts = ntail ? (int)((unsigned)cus / ntail) : 1;
+        if (nparts > 4) nparts = 4;
+        const int ns = (a.T + 31) / 32;
+        AttnArgs at = a;
+        if (attn_split_on() && nfull && ntail && nparts >= 2 && ns >= 4 * nparts) {
+            const size_t rows = (size_t)ntail * nparts * 128;
+            at.part_ws = attn_split_ws(rows * (DT32<NDB>::DK + 1) + (size_t)ntail * 128);
+            at.item0 = (int)nfull, at.nparts = nparts;
+        }
+        const bool split = at.part_ws != nullptr;
 #define A3T_L32(DR, SV)                                                                                                              \
     do {                                                                                                                             \
         (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);   \
-        hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV>), dim3(grid), dim3(256), lds32, s, a);                                    \
+        if (split) {                                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV, false, true>,                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds32);                                            \
+            hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV, false, true>), dim3(nfull + ntail * nparts), dim3(256), lds32, s, at); \
+            hipLaunchKernelGGL(attn_split_finish_kernel, dim3(ntail * 8), dim3(256), 0, s, at, (int)ntail, DT32<NDB>::DK);            \
+        } else {                                                                                                                     \
+            hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV>), dim3(grid), dim3(256), lds32, s, a);                                 \
+        }                                                                                                                            \
     } while (0)
         if (a.probs) {
             // training: the fixup of an overflowed block has to re-write its saved probabilities too -> the same kernel with

@@ -93,11 +93,16 @@ class MLMEngine:
         # Weight-gradient GEMMs feed nothing until the optimizer, so the backward schedule launches them on a second HIP
         # stream: they fill the partially empty last round of the data-gradient GEMMs' grids and overlap the HBM-bound
         # row kernels (LayerNorm / softmax backward).  Scratch tensors they read are double-buffered by sub-layer parity.
-        self.side = None
+        self.side = self.side2 = None
         if self.dev.type == "cuda" and os.environ.get("A3T_SIDE_STREAM", "1") != "0":
             self.side = torch.cuda.Stream(device=self.dev)
+            # results the main stream waits for inside the sub-layer (dV, dK of the attention backward) get a stream of their own:
+            # queued behind the weight gradients they would hand the main stream the whole backlog to wait for
+            self.side2 = (torch.cuda.Stream(device=self.dev, priority=torch.cuda.Stream.priority_range()[1])
+                          if os.environ.get("A3T_SIDE2", "1") != "0" else self.side)
         self._par = 0
-        self._side_ev = [None, None]
+        self._depth = max(2, int(os.environ.get("A3T_SIDE_DEPTH", "4")))   # scratch sets the main stream may run ahead by
+        self._side_ev = [None] * self._depth
         self._gm_ready = None
         self._arena = {k: dict(buf=None, used=0, slots={}, dtype=dt) for k, dt in
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
@@ -274,11 +279,12 @@ class MLMEngine:
         dropping = self.dropping and self.c.dropout_rate > 0
         if dropping and self.bf16 and self.fuse_ln_dropout and nb is not None and nxt is not None and x.shape[1] % 128 == 0:
             dr = self._drop(self.c.dropout_rate, nxt)
-            gm = self.ws.get(f"tmp.gm.{self._par ^ 1}", tuple(dx.shape), self.adt)
-            ev = self._side_ev[self._par ^ 1]          # side-stream readers of that scratch set must have drained
+            nx = (self._par + 1) % self._depth
+            gm = self.ws.get(f"tmp.gm.{nx}", tuple(dx.shape), self.adt)
+            ev = self._side_ev[nx]                     # side-stream readers of that scratch set must have drained
             if ev is not None:
                 torch.cuda.current_stream().wait_event(ev)
-                self._side_ev[self._par ^ 1] = None
+                self._side_ev[nx] = None
             ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=gm,
                               dxsum=nb[0], dxsum_scale=nb[1], drop=dr)
             self._gm_ready = nxt
@@ -328,7 +334,7 @@ class MLMEngine:
     def _sub_begin(self):
         """Start of a sub-layer backward: flip the parity; its scratch set was last read by the side-stream work
         issued two sub-layers ago, which must have drained before the main stream overwrites it."""
-        self._par ^= 1
+        self._par = (self._par + 1) % self._depth
         ev = self._side_ev[self._par]
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -340,16 +346,18 @@ class MLMEngine:
             ev.record(self.side)
             self._side_ev[self._par] = ev
 
-    def _side(self, fn, want_event=False):
+    def _side(self, fn, want_event=False, urgent=False):
         """Run fn (work whose inputs are complete on the main stream NOW) on the side stream; with want_event the
-        returned event marks its completion (for results the main stream consumes later)."""
+        returned event marks its completion (for results the main stream consumes later).  urgent: the main stream joins
+        this work before the sub-layer ends -- it goes to the second side stream, in front of no backlog."""
         if self.side is None:
             fn()
             return None
         ev = torch.cuda.Event()
         ev.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ev)
+        st = self.side2 if urgent else self.side
+        with torch.cuda.stream(st):
+            st.wait_event(ev)
             fn()
             if want_event:
                 done = torch.cuda.Event()
@@ -360,7 +368,9 @@ class MLMEngine:
     def _side_join(self):
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
-            self._side_ev = [None, None]
+            if self.side2 is not self.side:
+                torch.cuda.current_stream().wait_stream(self.side2)
+            self._side_ev = [None] * self._depth
 
     def _pre_ln(self, ga, g, g16):
         """The sub-layer's closing LayerNorm backward rewrites g / g16 in place: if the side-stream GEMMs read the
@@ -566,7 +576,7 @@ class MLMEngine:
         # (independent of the dprobs -> softmax-backward chain: runs beside it on the side stream)
         self._side(lambda: ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                                     batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
-                                    compute=cmp, colsum=sl[3 * d:] if fz else None, **csk))
+                                    compute=cmp, colsum=sl[3 * d:] if fz else None, **csk), urgent=True)
         # dBD is laid out head-major [H][B][T][T] (bf16 mode): the gradient of linear_pos, sum_b dbd[b,h]^T (q+v)[b,h], is then ONE
         # token-reduction GEMM per head with K = B*T (split-K) instead of B*H products of K = T accumulated by atomics
         hm = self.bf16 and self.attn_hm
@@ -607,7 +617,7 @@ class MLMEngine:
                      b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=sl if fz else None, **csk)
         dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
                                               a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
-                                              colsum=sl[2 * d:] if fz else None, **csk), want_event=True)
+                                              colsum=sl[2 * d:] if fz else None, **csk), want_event=True, urgent=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
                  c_bs=(T * d, dk), compute=cmp, colsum=sl[d:] if fz else None, **csk)

@@ -354,6 +354,11 @@ const char* a3t_gemm_last_kernel(void);
 int a3t_gemm_8p_mode(int mode);
 /* The same switch for the 384-column panel GEMM (A3T_GEMM_PN). */
 int a3t_gemm_pn_mode(int mode);
+/* Fused attention forward (a3t_attn_fwd, a3t_attn_fwd_train): 1 (default) = when the last round of 128-query blocks would fill at
+ * most half of the chip, those blocks run as a launch of their own, split into 2..4 key ranges whose partial sums a small kernel
+ * folds (attention.py:64-96 is associative in the keys once every range uses the block's one reference maximum); 0 = one
+ * workgroup per block always; -1 = re-read A3T_ATTN_SPLIT.  Returns the previous mode. */
+int a3t_attn_split_mode(int mode);
 
 #ifdef __cplusplus
 }

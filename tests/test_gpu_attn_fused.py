@@ -443,3 +443,99 @@ def test_fixed_reference_maximum_overflow_falls_back_and_stays_exact(train):
     if train:
         pn = probs.float().cpu().double() * rs.cpu().double()[..., None]
         assert bool(torch.isfinite(pn).all()) and float((pn - pr).abs().max()) < 8e-3
+
+
+def _split_off():
+    from a3t_amd import _lib
+    return _lib.load().a3t_attn_split_mode(0)
+
+
+def _split_restore(old):
+    from a3t_amd import _lib
+    _lib.load().a3t_attn_split_mode(old)
+
+
+@pytest.mark.parametrize("train,drop_p", [(False, 0.0), (True, 0.0), (True, 0.2)])
+@pytest.mark.parametrize("B,H,T,dk,lengths", [
+    (16, 2, 1120, 64, None),                                   # 288 blocks = 256 + 32 -> the tail runs as 4 key ranges
+    (12, 3, 1000, 32, [1000, 640, 0, 977] + [1000] * 8),        # 288 blocks; an empty utterance, ragged lengths in and out of the tail
+    (43, 1, 896, 96, [896] * 40 + [100, 896, 30]),              # 301 blocks = 256 + 45 -> 4 ranges; keys end inside the first range
+])
+def test_key_split_tail_blocks_equal_the_unsplit_launch(B, H, T, dk, lengths, train, drop_p):
+    """A launch whose last round of 128-query blocks fills at most half the chip runs those blocks split into key ranges
+    (launch_fwd16 in attn_fused.hip).  Every range uses the block's reference maximum, so the saved probabilities are
+    bit-identical to the unsplit launch and ctx / lse / rowscale differ by the fp32 summation order only."""
+    from a3t_amd import ops
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("block counts chosen for 256 CUs")
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=7 + B, lengths=lengths)
+    d = H * dk
+    drop = (drop_p, 4242) if drop_p else (0.0, 0)
+
+    def run():
+        ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+        lse = torch.zeros(B, H, T, device=DEV)
+        if not train:
+            ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=drop)
+            torch.cuda.synchronize()
+            return ctx, lse
+        probs = torch.full((B, H, T, T), 7.0, device=DEV, dtype=torch.bfloat16)
+        pdrop = torch.full((B, H, T, T), 7.0, device=DEV, dtype=torch.bfloat16) if drop_p else None
+        rs = torch.zeros(B, H, T, device=DEV)
+        ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk), drop=drop)
+        torch.cuda.synchronize()
+        return ctx, lse, rs, probs, pdrop
+
+    got = run()
+    old = _split_off()
+    try:
+        ref = run()
+    finally:
+        _split_restore(old)
+    assert old == 1
+    assert bool(torch.isfinite(got[0].float()).all())
+    assert float((got[0].float() - ref[0].float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref[0].float().abs().max()))
+    fin = torch.isfinite(ref[1])
+    assert bool((torch.isfinite(got[1]) == fin).all())
+    assert float((got[1][fin] - ref[1][fin]).abs().max()) < 1e-5
+    assert bool((got[1][~fin] == ref[1][~fin]).all())
+    if train:
+        assert float(((got[2] - ref[2]).abs() / ref[2].abs().clamp_min(1e-30)).max()) < 1e-5
+        assert torch.equal(got[3], ref[3])
+        if drop_p:
+            assert torch.equal(got[4], ref[4])
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_key_split_tail_block_that_overflows_is_recomputed(train):
+    """The overflow flag of a split block is raised by the fold kernel from the summed row sums; the fixup launch then
+    recomputes the whole block unsplit.  Keys of the last utterance (its blocks are the tail of the launch) scaled by 40."""
+    from a3t_amd import ops
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("block counts chosen for 256 CUs")
+    B, H, T, dk = 29, 2, 640, 64                           # 290 blocks = 256 + 34
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=5)
+    d = H * dk
+    qkv = qkv.clone()
+    kview = qkv.view(B, T, 3 * d)
+    kview[B - 1, 300:, d:2 * d] = (kview[B - 1, 300:, d:2 * d].float() * 40.0).bfloat16()
+    ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=DEV)
+    if train:
+        probs = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+        rs = torch.zeros(B, H, T, device=DEV)
+        ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, None, rs, B, H, T, 1.0 / math.sqrt(dk))
+    else:
+        ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk))
+    torch.cuda.synchronize()
+    sl = slice(B - 2, B)                                   # check the last two utterances against the exact formula
+    M0 = (B - 2) * T
+    ref, pr, rlse = _exact(qkv[M0:], qu[M0:], qv[M0:], P, keymask[sl], 2, H, T, dk)
+    assert float(rlse.max()) > 100.0
+    got = ctx[M0:].float().cpu().double()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - ref).abs().max()) / max(1.0, float(ref.abs().max())) < 2e-2
+    assert float((lse[sl].cpu().double() - rlse).abs().max()) < 2e-2
+    if train:
+        pn = probs[sl].float().cpu().double() * rs[sl].cpu().double()[..., None]
+        assert bool(torch.isfinite(pn).all()) and float((pn - pr).abs().max()) < 8e-3
