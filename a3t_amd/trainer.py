@@ -249,6 +249,8 @@ class A3TTrainer:
 
         def after(name):          # called after the backward of the parameter group starting at `name`
             lo = offs[name][0]
+            if state["next"] < len(lows) and lows[state["next"]] >= lo and hasattr(eng, "join_side"):
+                eng.join_side()       # the weight gradients of the range come from the engine's side streams
             while state["next"] < len(lows) and lows[state["next"]] >= lo:
                 red.reduce_range(state["next"])
                 state["next"] += 1
