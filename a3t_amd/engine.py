@@ -39,6 +39,67 @@ def legacy_pe_table(c: A3TConfig) -> torch.Tensor:
     return pe
 
 
+class _FastEvent:
+    """Cross-stream hand-over event created with hipEventDisableTiming | hipEventDisableSystemFence: the marker packet of
+    a default-flag event costs the queue it is recorded on ~7.3 us between two kernels, this one ~5.2 (tools/event_cost.py,
+    rocprofv3 kernel trace); the engine records ~110 of them per step on the main stream.  Same interface as the two methods
+    of torch.cuda.Event the engine uses.  A3T_FAST_EVENTS=0: torch events."""
+    _hip = None
+    _pools = {}        # device -> [events, next]: an event belongs to the device that was current when it was created
+
+    @classmethod
+    def get(cls):
+        import ctypes
+        if cls._hip is None:
+            cls._hip = ctypes.CDLL("libamdhip64.so")
+        pool = cls._pools.setdefault(torch.cuda.current_device(), [[], 0])
+        if len(pool[0]) < 1024:            # ring of events: a wait captures the record that precedes it, so re-recording is safe
+            h = ctypes.c_void_p()
+            if cls._hip.hipEventCreateWithFlags(ctypes.byref(h), ctypes.c_uint(0x2 | 0x20000000)) != 0:
+                raise RuntimeError("hipEventCreateWithFlags failed")
+            e = cls.__new__(cls)
+            e.h = h
+            pool[0].append(e)
+            return e
+        pool[1] = (pool[1] + 1) % len(pool[0])
+        return pool[0][pool[1]]
+
+    def record(self, stream=None):
+        import ctypes
+        st = stream if stream is not None else torch.cuda.current_stream()
+        if self._hip.hipEventRecord(self.h, ctypes.c_void_p(st.cuda_stream)) != 0:
+            raise RuntimeError("hipEventRecord failed")
+
+    def wait_on(self, stream):
+        import ctypes
+        if self._hip.hipStreamWaitEvent(ctypes.c_void_p(stream.cuda_stream), self.h, 0) != 0:
+            raise RuntimeError("hipStreamWaitEvent failed")
+
+
+class _TorchEvent:
+    def __init__(self):
+        self.e = torch.cuda.Event()
+
+    def record(self, stream=None):
+        self.e.record(stream) if stream is not None else self.e.record()
+
+    def wait_on(self, stream):
+        stream.wait_event(self.e)
+
+
+def _new_event():
+    global _FAST_EVENTS
+    if _FAST_EVENTS:
+        try:
+            return _FastEvent.get()
+        except (OSError, RuntimeError):          # no libamdhip64 by that name: torch's events do the same job
+            _FAST_EVENTS = False
+    return _TorchEvent()
+
+
+_FAST_EVENTS = os.environ.get("A3T_FAST_EVENTS", "1") != "0"
+
+
 class Workspace:
     """Named device buffers, allocated on first use and reused every step (static shapes)."""
 
@@ -101,7 +162,7 @@ class MLMEngine:
             self.side2 = (torch.cuda.Stream(device=self.dev, priority=torch.cuda.Stream.priority_range()[1])
                           if os.environ.get("A3T_SIDE2", "1") != "0" else self.side)
         self._par = 0
-        self._depth = max(2, int(os.environ.get("A3T_SIDE_DEPTH", "4")))   # scratch sets the main stream may run ahead by
+        self._depth = max(2, int(os.environ.get("A3T_SIDE_DEPTH", "48")))   # scratch sets the main stream may run ahead by
         self._side_ev = [None] * self._depth
         # (A3T_SIDE_DEFER=1, experiment: hand a sub-layer's weight gradients over at its END with one event record instead of one
         #  per GEMM -- 47.1 ms per step against 45.4: the weight gradients have to start as early as they can)
@@ -287,7 +348,7 @@ class MLMEngine:
             gm = self.ws.get(f"tmp.gm.{nx}", tuple(dx.shape), self.adt)
             ev = self._side_ev[nx]                     # side-stream readers of that scratch set must have drained
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                ev.wait_on(torch.cuda.current_stream())
                 self._side_ev[nx] = None
             ops.layernorm_bwd(dy, x, p[pre + ".g"], mean, rstd, dres, dx, g[pre + ".g"], g[pre + ".b"], dx16=gm,
                               dxsum=nb[0], dxsum_scale=nb[1], drop=dr)
@@ -341,13 +402,13 @@ class MLMEngine:
         self._par = (self._par + 1) % self._depth
         ev = self._side_ev[self._par]
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            ev.wait_on(torch.cuda.current_stream())
             self._side_ev[self._par] = None
 
     def _sub_end(self):
         if self.side is not None:
             self._side_flush()
-            ev = torch.cuda.Event()
+            ev = _new_event()
             ev.record(self.side)
             self._side_ev[self._par] = ev
 
@@ -355,10 +416,10 @@ class MLMEngine:
         """A3T_SIDE_DEFER=1 only: hand the sub-layer's deferred side work over with one event record on the main stream."""
         if not self._side_pending:
             return
-        ev = torch.cuda.Event()
+        ev = _new_event()
         ev.record()
         with torch.cuda.stream(self.side):
-            self.side.wait_event(ev)
+            ev.wait_on(self.side)
             for fn in self._side_pending:
                 fn()
         self._side_pending = []
@@ -373,14 +434,14 @@ class MLMEngine:
         if self._side_defer and not urgent and not want_event:     # its inputs stay valid until the sub-layer ends (scratch sets)
             self._side_pending.append(fn)
             return None
-        ev = torch.cuda.Event()
+        ev = _new_event()
         ev.record()
         st = self.side2 if urgent else self.side
         with torch.cuda.stream(st):
-            st.wait_event(ev)
+            ev.wait_on(st)
             fn()
             if want_event:
-                done = torch.cuda.Event()
+                done = _new_event()
                 done.record()
                 return done
         return None
@@ -649,7 +710,7 @@ class MLMEngine:
                  c_bs=(T * d, dk), compute=cmp, colsum=sl[d:] if fz else None, **csk)
         ops.add_pos_bias_bwd(dqu, dqv, dqkv)      # (the dq slice only)
         if dk_done is not None:      # the dV / dK slices of dqkv and their column sums come from the side stream
-            torch.cuda.current_stream().wait_event(dk_done)
+            dk_done.wait_on(torch.cuda.current_stream())
         if fz:   # d u, d v, d b_q = d u + d v, d b_k, d b_v from the slot sums (all four GEMMs have drained here)
             ops.attn_bias_fold(sl, S, d, gr[pre + ".u"], gr[pre + ".v"], gbq)
         else:
