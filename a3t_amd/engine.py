@@ -168,6 +168,8 @@ class MLMEngine:
         #  per GEMM -- 47.1 ms per step against 45.4: the weight gradients have to start as early as they can)
         self._side_defer = os.environ.get("A3T_SIDE_DEFER", "0") == "1"
         self._side_pending = []
+        # (A3T_SIDE_LATE=1, experiment: 46.5 ms per step against 45.2 -- see _pre_ln)
+        self._side_late = os.environ.get("A3T_SIDE_LATE", "0") == "1"
         self._gm_ready = None
         self._arena = {k: dict(buf=None, used=0, slots={}, dtype=dt) for k, dt in
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
@@ -424,15 +426,15 @@ class MLMEngine:
                 fn()
         self._side_pending = []
 
-    def _side(self, fn, want_event=False, urgent=False):
+    def _side(self, fn, want_event=False, urgent=False, late=False):
         """Run fn (work whose inputs are complete on the main stream NOW) on the side stream; with want_event the
         returned event marks its completion (for results the main stream consumes later).  urgent: the main stream joins
         this work before the sub-layer ends -- it goes to the second side stream, in front of no backlog."""
         if self.side is None:
             fn()
             return None
-        if self._side_defer and not urgent and not want_event:     # its inputs stay valid until the sub-layer ends (scratch sets)
-            self._side_pending.append(fn)
+        if (self._side_defer or (late and self._side_late)) and not urgent and not want_event:
+            self._side_pending.append(fn)         # (its inputs stay valid until the sub-layer ends: scratch sets)
             return None
         ev = _new_event()
         ev.record()
@@ -461,6 +463,14 @@ class MLMEngine:
     def _pre_ln(self, ga, g, g16):
         """The sub-layer's closing LayerNorm backward rewrites g / g16 in place: if the side-stream GEMMs read the
         gradient from there (no dropout copy), they must finish first."""
+        if self.side is not None and self._side_late:
+            # `late` weight gradients (their operand is produced in front of the sub-layer's last data-gradient GEMM) are handed
+            # over HERE: forked earlier they become eligible while that GEMM runs, take every CU the moment it ends, and the
+            # LayerNorm backward -- not eligible before the GEMM has completed -- waits a whole weight gradient for its slots
+            # (170 us instead of 53: tools/trace_analyse.py).  Eligible together, the high-priority main stream is served first.
+            # Measured: the LayerNorm backwards drop from 6.6 to 5.1 ms per step, but the late weight gradients then collide with
+            # the next sub-layer's first GEMMs (+2.8 ms): off by default.
+            self._side_flush()
         if self.side is not None and (ga is g or ga is g16):
             self._side_flush()
             torch.cuda.current_stream().wait_stream(self.side)
@@ -510,7 +520,7 @@ class MLMEngine:
             ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=a_dh,
                               compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
         if not _SKIP_FFN_WGRAD:
-            self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp))
+            self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp), late=True)
         dy = self._act("tmp.dy", (M, c.adim))
         if self._ffn_plan(M)[1]:
             ops.conv_fwd(dh, self._wt["w1"][2][pre + ".w1"], dy, T, c.ff_kernel - 1 - pad, compute=self.cmp)
@@ -630,7 +640,7 @@ class MLMEngine:
                 ops.linear_bwd_weight(dP16, pos, gr[pre + ".wpos"], compute=cmp)
             self._side(pos_weight_grad_fused)
             ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gr[pre + ".u"], gr[pre + ".v"], gr[pre + ".bqkv"])
-            self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp))
+            self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp), late=True)
             dy = self._act("tmp.dy", (M, d))
             self._lin_dgrad(dqkv, pre + ".wqkv", dy)
             self._pre_ln(ga, g, g16)
@@ -717,7 +727,7 @@ class MLMEngine:
             self._bias_grad(dqu, gr[pre + ".u"])
             self._bias_grad(dqv, gr[pre + ".v"])
             self._bias_grad(dqkv, gbq)
-        self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp))
+        self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp), late=True)
         dy = self._act("tmp.dy", (M, d))
         self._lin_dgrad(dqkv, pre + ".wqkv", dy)
         self._pre_ln(ga, g, g16)
@@ -782,7 +792,7 @@ class MLMEngine:
         dg = self._act(self._t("tmp.dg"), (M, 2 * d))
         ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T,
                            dgsum=gr[pre + ".pb1"])
-        self._side(lambda: ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp))
+        self._side(lambda: ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp), late=True)
         dy = self._act("tmp.dy", (M, d))
         self._lin_dgrad(dg, pre + ".pw1", dy)
         self._pre_ln(ga, g, g16)
