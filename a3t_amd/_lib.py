@@ -60,6 +60,8 @@ _SIGS = {
     "a3t_attn_fwd_train": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                            c_int64, c_float, c_float, ctypes.c_uint32, _P],
     "a3t_attn_scale_rows": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "a3t_attn_bwd_ds": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_float,
+                        c_float, ctypes.c_uint32, _P],
     "a3t_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                      c_float, c_float, ctypes.c_uint32, _P],
     "a3t_attn_delta": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int64, _P],

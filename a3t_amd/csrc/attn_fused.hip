@@ -982,6 +982,249 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 }
 
 // =====================================================================================================================
+// Score gradients of the training path that keeps the forward's probabilities (a3t_attn_fwd_train):
+//   dP = dctx V^T on the matrix cores, dS = p (keep/(1-p_drop) dP - delta) scale with p = probs * rowscale and
+//   delta_i = dctx_i . ctx_i (a3t_attn_delta), written twice: row-major (operand of dK = dS^T (q+u) and d(q+u) = dS K) and
+//   through the inverse legacy skew (attention.py:145-165) into the compact dBD matrix (operand of d(q+v) and d linear_pos).
+// It replaces the dprobs GEMM (a T x T write) and a3t_relpos_softmax_bwd (a T x T read): 480 MB per launch at configs[1] instead
+// of 800.  No state is carried along the keys (delta is known up front), so the unit of work is a 32-query x (KT x 32)-key
+// strip and a wave walks strips independently: V fragments come straight from L2, the probability tile and the two outputs go
+// through a per-wave LDS image that turns the MFMA layout (lane = query, 4 x 4 keys) into 16 rows x 64 B per instruction.
+struct DsArgs {
+    const u16* dctx;      // [B*T][ldo]
+    const u16* v;         // [B*T][ldkv], head h at column h*dk
+    const u16* probs;     // [B][H][T][T] exp(s - m_ref)
+    const float* rowscale;   // [B][H][T]
+    const float* delta;      // [B][H][T]
+    u16* ds;              // [B][H][T][T]
+    u16* dbd;             // compact dBD, block (b, h) at b*dbd_bsb + h*dbd_bsh
+    int B, H, T;
+    int64_t ldo, ldkv, dbd_bsb, dbd_bsh;
+    float scale, drop_inv;
+    unsigned int drop_thr, drop_key;
+};
+
+// chunk ci (row-contiguous 16-byte pieces, chunk index fastest) of the wave's probability strip
+// (x / d for x * d < 2^20 as a multiply: the strip geometry is a runtime value and an integer division is ~40 instructions --
+//  forty of them per task were a third of the kernel's VALU work)
+__device__ __forceinline__ unsigned ds_magic(int d) { return (unsigned)(1048576.0f / (float)d) + 1u; }
+__device__ __forceinline__ int ds_div(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
+__device__ __forceinline__ uint4 ds_ld_chunk(const u16* prB, int T, int q0, int J0, int cpr, int npair, int ci) {
+    const int row = ds_div(ci, ds_magic(cpr)), ch = ci - row * cpr;
+    const int gi = q0 + row, col = J0 + 8 * ch;
+    const bool ok = ci < npair && gi < T && col < T;
+    const u16* src = ok ? prB + (int64_t)gi * T + col : (const u16*)attn_zero_page;
+    return *(const uint4*)src;
+}
+
+// One workgroup = 128 queries (4 waves x 32) x a strip of up to KT key tiles.  Everything global is touched in row-contiguous
+// 16-byte pieces (a vector-memory instruction costs with the number of cache lines it touches: the first version of this
+// kernel, tile by tile with 16 rows x 64 B per instruction and 2-byte dBD stores, ran 297 us against 184 for the two kernels it
+// replaces):  the wave's probability strip [32][nt*32] comes into a per-wave LDS image at the start, dS overwrites it in
+// place tile by tile, and at the end the image leaves twice -- as rows of dS, and as the dBD rows, which are the SAME flat
+// sequence shifted (dbd[r][c] = ds_flat[(r-1) T + c + r + 1]: two runs per query row, keys <= i into row i from column
+// T-1-i, keys >= i+2 into row i+1 from column 0) and are written in DESTINATION-aligned 16-byte chunks: five dwords of the
+// image funnel-shifted by the source's parity; the partial chunks at the ends of a run go out element by element.
+// V tiles are shared by the four waves: DMA into a double buffer, one barrier per tile.
+template <int NDB, bool DROP, int KT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
+    using D = DT32<NDB>;
+    constexpr int DK = D::DK, KS = DK / 16, TB = D::BYTES, CPR = D::CPR, RS = KT * 64 + 16, IMG = 32 * RS, NPMIN = D::NP / 4;
+    constexpr int NRING = 3;                             // V tiles in flight: DMA two tiles ahead, across task boundaries
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned smem0 = lds_base(smem);
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* img = smem + NRING * TB + w * IMG;
+    const int T = p.T, NS = (T + 31) / 32, NKC = (NS + KT - 1) / KT, NQB = (T + 127) / 128;
+    const int64_t ntasks = (int64_t)p.B * p.H * NQB * NKC;
+    const unsigned ldkv2 = (unsigned)p.ldkv * 2u;
+    const int vbytes = (int)((unsigned)(T - 1) * ldkv2 + DK * 2u);
+    unsigned voffV[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int ci = (q * 4 + w) * 64 + lane;
+        const int row = ci / CPR, pos = ci - row * CPR;
+        voffV[q] = (unsigned)row * ldkv2 + (unsigned)((pos ^ D::sw(row)) * 16);
+    }
+    const int swr = D::sw(lr);
+    // a task = (b, h, 128-query block, strip of key tiles) as plain scalars (a struct handed around by reference lands in scratch)
+#define A3T_DS_DECODE(P, task_)                                                        \
+    do {                                                                               \
+        const int kc_ = (int)((task_) % NKC);                                          \
+        const int64_t t2_ = (task_) / NKC;                                             \
+        const int qb_ = (int)(t2_ % NQB);                                              \
+        P##bh = (int)(t2_ / NQB), P##b = P##bh / p.H, P##h = P##bh - P##b * p.H;       \
+        P##q0 = 128 * qb_ + 32 * w;                                                    \
+        P##sa = kc_ * KT;                                                              \
+        const int sb_ = (P##sa + KT < NS) ? P##sa + KT : NS;                           \
+        P##nt = sb_ - P##sa, P##J0 = 32 * P##sa, P##J1 = (32 * sb_ < T) ? 32 * sb_ : T; \
+    } while (0)
+#define A3T_DS_ISSUE_V(P, k_, slot_)                                                                                     \
+    do {                                                                                                                 \
+        const u16* vB_ = p.v + ((int64_t)P##b * T) * p.ldkv + P##h * DK;                                                 \
+        const __amdgpu_buffer_rsrc_t rV_ = __builtin_amdgcn_make_buffer_rsrc((void*)vB_, 0, vbytes, 0x00020000);        \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                                    \
+            if ((q * 4 + w) * 1024 < TB)                                                                                 \
+                dma16(rV_, smem0 + (unsigned)((slot_) * TB + (q * 4 + w) * 1024), voffV[q] + (unsigned)(32 * (P##sa + (k_))) * ldkv2); \
+    } while (0)
+    // the wave's inputs of a task are held in registers until its image is free: probability strip (row-contiguous 16-byte
+    // chunks), dctx fragments, row factors.  (A macro, not a lambda: arrays handed to a lambda by reference end up in scratch.)
+    static_assert(KT == 5, "ten named strip registers below");
+    uint4 pr0, pr1, pr2, pr3, pr4, pr5, pr6, pr7, pr8, pr9;      // (named: an array that lives across the task loop stays in scratch)
+    bf16x8 in_fd[KS];
+    float in_rsc, in_dl;
+#define A3T_DS_FETCH(P)                                                                                             \
+    do {                                                                                                            \
+        const int i_ = P##q0 + lr, cpr_ = 4 * P##nt, np_ = 32 * cpr_;                                               \
+        const u16* prB_ = p.probs + (int64_t)P##bh * T * T;                                                         \
+        const u16* dcB_ = p.dctx + ((int64_t)P##b * T) * p.ldo + P##h * DK;                                         \
+        pr0 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, lane), pr1 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 64 + lane);         \
+        pr2 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 128 + lane), pr3 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 192 + lane);  \
+        pr4 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 256 + lane), pr5 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 320 + lane);  \
+        pr6 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 384 + lane), pr7 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 448 + lane);  \
+        pr8 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 512 + lane), pr9 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 576 + lane);  \
+        _Pragma("unroll") for (int kk = 0; kk < KS; ++kk)                                                           \
+            in_fd[kk] = ld_frag_g(dcB_ + (int64_t)i_ * p.ldo + 16 * kk + 8 * lh, i_ < T);                           \
+        in_rsc = i_ < T ? p.rowscale[(int64_t)P##bh * T + i_] * p.scale : 0.f;                                      \
+        in_dl = i_ < T ? p.delta[(int64_t)P##bh * T + i_] : 0.f;                                                    \
+    } while (0)
+#define A3T_DS_PUT(u_, v_)                                                          \
+    do {                                                                            \
+        const int ci = 64 * (u_) + lane, row = ds_div(ci, mg_cpr), ch = ci - row * cpr; \
+        if (ci < npair) *(uint4*)(img + row * RS + ch * 16) = (v_);                 \
+    } while (0)
+
+    int64_t task = blockIdx.x;
+    if (task >= ntasks) return;
+    int c_bh, c_b, c_h, c_q0, c_sa, c_nt, c_J0, c_J1, n_bh, n_b, n_h, n_q0, n_sa, n_nt, n_J0, n_J1;
+    A3T_DS_DECODE(c_, task);
+    int gt = 0;                                          // running tile count of this workgroup: ring slot = gt % NRING
+    A3T_DS_ISSUE_V(c_, 0, 0);
+    if (c_nt > 1) A3T_DS_ISSUE_V(c_, 1, 1);
+    A3T_DS_FETCH(c_);
+    while (true) {
+        const int64_t ntask = task + gridDim.x;
+        const bool more = ntask < ntasks;
+        A3T_DS_DECODE(n_, (more ? ntask : task));
+        const int cpr = 4 * c_nt, npair = 32 * cpr;
+        const unsigned mg_cpr = ds_magic(cpr), mg_slot = ds_magic(cpr + 1);
+        const int i = c_q0 + lr;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this task's inputs (and its first V tiles, and the last task's stores)
+        A3T_DS_PUT(0, pr0); A3T_DS_PUT(1, pr1); A3T_DS_PUT(2, pr2); A3T_DS_PUT(3, pr3); A3T_DS_PUT(4, pr4);
+        A3T_DS_PUT(5, pr5); A3T_DS_PUT(6, pr6); A3T_DS_PUT(7, pr7); A3T_DS_PUT(8, pr8); A3T_DS_PUT(9, pr9);
+        bf16x8 fd[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) fd[kk] = in_fd[kk];
+        const float rsc = in_rsc, dl = in_dl;
+        const unsigned int ibase = (unsigned int)(((int64_t)c_bh * T + i) * T);
+        u16* dsB = p.ds + (int64_t)c_bh * T * T;
+        u16* dbB = p.dbd + (int64_t)c_b * p.dbd_bsb + (int64_t)c_h * p.dbd_bsh;
+        if (c_q0 == 0 && c_sa == 0)          // BD[0][0 .. T-2] never reaches the scores (attention.py:157-165)
+            for (int c = lane; c < T - 1; c += 64) dbB[c] = 0;
+        // ---- tiles
+        for (int k = 0; k < c_nt; ++k, ++gt) {
+            // V(k) has landed: of the DMA issued after it only tile k+1 may still be in flight (tile k+2 is issued below)
+            if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (NPMIN >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (NPMIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (NPMIN == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // two tiles ahead, into the slot every wave left before this barrier; past the end of the task: the next task's
+            if (k + 2 < c_nt) A3T_DS_ISSUE_V(c_, k + 2, (gt + 2) % NRING);
+            else if (more && k + 2 - c_nt < n_nt) A3T_DS_ISSUE_V(n_, k + 2 - c_nt, (gt + 2) % NRING);
+            const unsigned char* Vt = smem + (gt % NRING) * TB;
+            f32x16 dP = zero16();
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+                dP = mfma32(*(const bf16x8*)(Vt + lr * D::RB + (((2 * kk + lh) ^ swr) << 4)), fd[kk], dP);
+            unsigned char* cell = img + lr * RS + k * 64 + 8 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 pk = *(const uint2*)(cell + 16 * g);
+                const float p0 = io_bf2f(pk.x & 0xffff), p1 = io_bf2f(pk.x >> 16), p2 = io_bf2f(pk.y & 0xffff), p3 = io_bf2f(pk.y >> 16);
+                float d0_ = dP[4 * g], d1_ = dP[4 * g + 1], d2_ = dP[4 * g + 2], d3_ = dP[4 * g + 3];
+                if (DROP) {
+                    const unsigned int i0 = ibase + (unsigned int)(32 * (c_sa + k) + 8 * g + 4 * lh);
+                    const unsigned int h0 = rng_pair(p.drop_key, i0 >> 1), h1 = rng_pair(p.drop_key, (i0 >> 1) + 1), t = p.drop_thr >> 16;
+                    d0_ = (h0 & 0xffffu) >= t ? d0_ * p.drop_inv : 0.f, d1_ = (h0 >> 16) >= t ? d1_ * p.drop_inv : 0.f;
+                    d2_ = (h1 & 0xffffu) >= t ? d2_ * p.drop_inv : 0.f, d3_ = (h1 >> 16) >= t ? d3_ * p.drop_inv : 0.f;
+                }
+                uint2 o;
+                o.x = io_pack2(p0 * rsc * (d0_ - dl), p1 * rsc * (d1_ - dl)), o.y = io_pack2(p2 * rsc * (d2_ - dl), p3 * rsc * (d3_ - dl));
+                *(uint2*)(cell + 16 * g) = o;
+            }
+        }
+        // (a one-tile task leaves the next task's second V tile to be issued here; a barrier first: slot gt+1 may still be read)
+        if (more && c_nt == 1 && n_nt > 1) {
+            __syncthreads();
+            A3T_DS_ISSUE_V(n_, 1, (gt + 1) % NRING);
+        }
+        // ---- the next task's inputs travel while this one's image leaves
+        if (more) A3T_DS_FETCH(n_);
+        // ---- dS rows
+        for (int c0 = 0; c0 < npair; c0 += 64) {
+            const int ci = c0 + lane, row = ds_div(ci, mg_cpr), ch = ci - row * cpr;
+            const int gi = c_q0 + row, col = c_J0 + 8 * ch;
+            if (ci < npair && gi < T && col < T) *(uint4*)(dsB + (int64_t)gi * T + col) = *(const uint4*)(img + row * RS + ch * 16);
+        }
+        // ---- dBD: per query row a lower run (keys <= i -> row i) and an upper run (keys >= i+2 -> row i+1)
+        const int nslot = cpr + 1, nps = 32 * nslot;
+#pragma unroll 1
+        for (int run = 0; run < 2; ++run) {
+            if (run == 0 ? (c_J0 > c_q0 + 31) : (c_J1 - 1 < c_q0 + 2)) continue;        // no row of this wave has that run
+            // whole 16-byte chunks of the destination
+            for (int c0 = 0; c0 < nps; c0 += 64) {
+                const int id = c0 + lane, row = ds_div(id, mg_slot), slot = id - row * nslot, gi = c_q0 + row;
+                if (id >= nps || gi >= T) continue;
+                int jlo, jhi, drow, dc0;
+                if (run == 0) jlo = c_J0, jhi = (c_J1 - 1 < gi) ? c_J1 - 1 : gi, drow = gi, dc0 = T - 1 - gi + jlo;
+                else jlo = (c_J0 > gi + 2) ? c_J0 : gi + 2, jhi = c_J1 - 1, drow = gi + 1, dc0 = jlo - gi - 2;
+                const int n = jhi - jlo + 1;
+                const int cc = (dc0 & ~7) + 8 * slot;
+                if (n <= 0 || cc < dc0 || cc + 8 > dc0 + n) continue;
+                const int so = jlo - c_J0 - dc0 + cc;              // source element (strip-local) of destination column cc
+                const unsigned int* dw = (const unsigned int*)(img + row * RS + (so >> 1) * 4);
+                const unsigned int a0 = dw[0], a1 = dw[1], a2 = dw[2], a3 = dw[3], a4 = dw[4];
+                const unsigned int sh = (unsigned int)(so & 1) * 16u;
+                uint4 o;
+                o.x = __builtin_amdgcn_alignbit(a1, a0, sh), o.y = __builtin_amdgcn_alignbit(a2, a1, sh);
+                o.z = __builtin_amdgcn_alignbit(a3, a2, sh), o.w = __builtin_amdgcn_alignbit(a4, a3, sh);
+                *(uint4*)(dbB + (int64_t)drow * T + cc) = o;
+            }
+            // the partial chunks at the two ends of each row's run: all 64 of them in ONE pass of element stores (a vector-memory
+            // instruction costs ~50 cycles of the CU's address path whatever its mask: spread over the loop above they were 88
+            // instructions per wave and task)
+            {
+                const int row = lane >> 1, tail = lane & 1, gi = c_q0 + row;
+                int jlo, jhi, drow, dc0;
+                if (run == 0) jlo = c_J0, jhi = (c_J1 - 1 < gi) ? c_J1 - 1 : gi, drow = gi, dc0 = T - 1 - gi + jlo;
+                else jlo = (c_J0 > gi + 2) ? c_J0 : gi + 2, jhi = c_J1 - 1, drow = gi + 1, dc0 = jlo - gi - 2;
+                const int n = jhi - jlo + 1;
+                const int chd = dc0 & ~7, ctl = (dc0 + n - 1) & ~7, cc = tail ? ctl : chd;
+                const bool mine = gi < T && n > 0 && !(cc >= dc0 && cc + 8 <= dc0 + n) && (!tail || ctl != chd);
+                u16* dst = dbB + (int64_t)drow * T;
+                const unsigned char* srow = img + row * RS;
+                const int so0 = jlo - c_J0 - dc0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int x = cc + e;
+                    if (mine && x >= dc0 && x < dc0 + n) dst[x] = *(const u16*)(srow + (so0 + x) * 2);
+                }
+            }
+        }
+        if (!more) break;
+        task = ntask;
+        c_bh = n_bh, c_b = n_b, c_h = n_h, c_q0 = n_q0, c_sa = n_sa, c_nt = n_nt, c_J0 = n_J0, c_J1 = n_J1;
+    }
+#undef A3T_DS_FETCH
+#undef A3T_DS_PUT
+#undef A3T_DS_DECODE
+#undef A3T_DS_ISSUE_V
+}
+
+// =====================================================================================================================
 // Backward.  Two passes that both recompute the probabilities from the saved log-sum-exp (two-pass flash backward):
 //   attn_bwd_q_kernel : query-block outer (lane = query).  dS^T per tile -> d(q+u) += dS K (registers), and through the
 //                       INVERSE skew (scatter dS into band coordinates in an LDS scratch) dBD band blocks ->
@@ -1673,6 +1916,51 @@ static int launch_bwd(const AttnArgs& a, int which, hipStream_t s) {
 }
 
 static bool attn_shape_ok(int dk, int T) { return dk % 32 == 0 && dk <= 192 && dk != 160 && T % 8 == 0 && T >= 8 && T <= 4096; }
+
+extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* probs, const float* rowscale, const float* delta,
+                               void* ds, void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb,
+                               int64_t dbd_bsh, float scale, float drop_p, uint32_t drop_key, void* stream) {
+    if (!attn_shape_ok(dk, T) || drop_p < 0.f || drop_p >= 1.f || !dctx || !v || !probs || !rowscale || !delta || !ds || !dbd)
+        return A3T_EINVAL;
+    if (!al16(dctx) || !al16(v) || !al16(probs) || !al16(ds) || !al16(dbd) || ldo % 8 || ldkv % 8 || dbd_bsb % 8 || dbd_bsh % 8)
+        return A3T_EINVAL;
+    if ((int64_t)B * H * T * T >= (1ll << 32)) return A3T_EINVAL;       // (the dropout counter is 32 bits, as in the forward)
+    if (dbd_bsb == 0 && dbd_bsh == 0) dbd_bsb = (int64_t)H * T * T, dbd_bsh = (int64_t)T * T;
+    DsArgs a = {};
+    a.dctx = (const u16*)dctx, a.v = (const u16*)v, a.probs = (const u16*)probs, a.rowscale = rowscale, a.delta = delta;
+    a.ds = (u16*)ds, a.dbd = (u16*)dbd, a.B = B, a.H = H, a.T = T, a.ldo = ldo, a.ldkv = ldkv, a.dbd_bsb = dbd_bsb, a.dbd_bsh = dbd_bsh;
+    a.scale = scale;
+    a.drop_thr = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u, a.drop_key = drop_key, a.drop_inv = 1.f / (1.f - drop_p);
+    // tasks = (128 queries) x (5 key tiles): several times more tasks than workgroup slots (2 per CU), so the last round is short
+    constexpr int KT = 5;
+    const int NS = (T + 31) / 32;
+    const int64_t ntasks = (int64_t)B * H * ((T + 127) / 128) * ((NS + KT - 1) / KT);
+    int64_t grid = (int64_t)attn_cus() * 2;
+    if (grid > ntasks) grid = ntasks;
+    hipStream_t s = (hipStream_t)stream;
+#define A3T_DS1(NDB, DR)                                                                                                         \
+    do {                                                                                                                         \
+        constexpr int lds = 3 * DT32<NDB>::BYTES + 4 * 32 * (KT * 64 + 16);                                                      \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<NDB, DR, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((attn_bwd_ds_kernel<NDB, DR, KT>), dim3((unsigned)grid), dim3(256), lds, s, a);                        \
+    } while (0)
+#define A3T_DS(NDB)                      \
+    do {                                 \
+        if (a.drop_thr) A3T_DS1(NDB, true); \
+        else A3T_DS1(NDB, false);        \
+    } while (0)
+    switch (dk / 32) {
+        case 1: A3T_DS(1); break;
+        case 2: A3T_DS(2); break;
+        case 3: A3T_DS(3); break;
+        case 4: A3T_DS(4); break;
+        case 6: A3T_DS(6); break;
+        default: return A3T_EINVAL;
+    }
+#undef A3T_DS1
+#undef A3T_DS
+    return (int)hipGetLastError();
+}
 
 extern "C" int a3t_attn_delta(const void* dctx, const void* ctx, float* delta, int B, int H, int T, int dk, int64_t ldo,
                               void* stream) {

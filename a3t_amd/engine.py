@@ -188,6 +188,10 @@ class MLMEngine:
         # on the side stream it costs the main stream more than the 64 small products did: opt-in (A3T_ATTN_DBD_HM=1).
         self.attn_hm = os.environ.get("A3T_ATTN_DBD_HM", "0") == "1"
         self.attn_regen = os.environ.get("A3T_ATTN_REGEN_MASK", "1") != "0"
+        # dS / dBD straight from the saved probabilities in one launch (a3t_attn_bwd_ds) instead of the dprobs GEMM + softmax
+        # backward: opt-in -- 208 us against 220 alone, but a persistent 79-KB-LDS kernel shares the chip with the weight-gradient
+        # stream worse than the pair it replaces (configs[1]: 46.6 ms per step against 45.6)
+        self.attn_bwd_ds = os.environ.get("A3T_ATTN_BWD_DS", "0") == "1"
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
         # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
         # at the benchmark shape; whole eval forward 4.32 vs 4.74 ms at B = 8, 10.5 vs 11.3 ms at B = 32, 4+4 blocks), except
@@ -655,12 +659,20 @@ class MLMEngine:
         if rs is not None:                 # dV = pdrop^T (rs * dctx): fold the row normalisation into the small operand
             dctx_v = self._act(self._t("tmp.dctxs"), (M, d))
             ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
-        dpr = self.ws.get("tmp.ac", (B, H, T, T), sdt)      # reuse the score buffers
+        adr = self._drop(c.attention_dropout_rate, tag + ".att") if pdrop is not None else None
+        # bf16 path: the attention-dropout mask comes back from the counter RNG (same key and index as the forward) instead
+        # of being read off the dropped probabilities: one T x T read less in the most HBM-bound kernel of the step
+        regen = self.bf16 and self.attn_regen and adr is not None and T % 8 == 0 and T <= 2048
+        # saved un-normalised probabilities + counter-RNG mask: dS / dBD in one launch, dprobs never stored (a3t_attn_bwd_ds)
+        ds_fused = (rs is not None and self.bf16 and self.attn_bwd_ds and (adr is None or regen) and dk % 32 == 0 and dk <= 192
+                    and dk != 160 and T % 8 == 0)
         zb = (H * T * T, T * T)
-        # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
-        if not _SKIP_ATTN_BWD_MAIN:
-            ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
-                     b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
+        if not ds_fused:
+            dpr = self.ws.get("tmp.ac", (B, H, T, T), sdt)      # reuse the score buffers
+            # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
+            if not _SKIP_ATTN_BWD_MAIN:
+                ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
+                         b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
         fz = self.bf16   # bias / pos-bias gradients ride on the GEMM epilogues as column sums
         gbq = gr[pre + ".bqkv"]
@@ -684,11 +696,12 @@ class MLMEngine:
         else:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
-        adr = self._drop(c.attention_dropout_rate, tag + ".att") if pdrop is not None else None
-        # bf16 path: the attention-dropout mask comes back from the counter RNG (same key and index as the forward) instead
-        # of being read off the dropped probabilities: one T x T read less in the most HBM-bound kernel of the step
-        regen = self.bf16 and self.attn_regen and adr is not None and T % 8 == 0 and T <= 2048
-        if not _SKIP_ATTN_BWD_MAIN:
+        if ds_fused:
+            if not _SKIP_ATTN_BWD_MAIN:
+                delta = self.ws.get("tmp.attn.delta", (B, H, T))
+                ops.attn_delta(dctx, ctx, delta, B, H, T)
+                ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0), dbd_head_major=hm)
+        elif not _SKIP_ATTN_BWD_MAIN:
             ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
                                    drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0, rowscale=rs)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*

@@ -328,6 +328,16 @@ def attn_scale_rows(x, rowscale, y, B, H, T):
     L.check(L.load().a3t_attn_scale_rows(_ptr(x), _ptr(rowscale), _ptr(y), B, H, T, d // H, _stream()), "attn_scale_rows")
 
 
+def attn_bwd_ds(dctx, qkv, probs, rowscale, delta, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=False):
+    """dS and the compact dBD from the saved un-normalised probabilities of attn_fwd_train (dP = dctx V^T is never stored):
+    replaces the dprobs GEMM + relpos_softmax_bwd.  qkv: [B*T, 3d], V in columns 2d..3d."""
+    d = dctx.shape[1]
+    v = qkv.view(-1)[2 * d:]
+    bsb, bsh = ((T * T, B * T * T) if dbd_head_major else (0, 0))
+    L.check(L.load().a3t_attn_bwd_ds(_ptr(dctx), _ptr(v), _ptr(probs), _ptr(rowscale), _ptr(delta), _ptr(ds), _ptr(dbd), B, H, T,
+                                     d // H, d, 3 * d, bsb, bsh, scale, drop[0], drop[1], _stream()), "attn_bwd_ds")
+
+
 def attn_delta(dctx, ctx, delta, B, H, T):
     d = ctx.shape[1]
     L.check(L.load().a3t_attn_delta(_ptr(dctx), _ptr(ctx), _ptr(delta), B, H, T, d // H, d, _stream()), "attn_delta")

@@ -217,6 +217,16 @@ int a3t_attn_fwd_train(const void* qu, const void* qv, const void* k, const void
 /* y[r][h*dk + c] = x[r][h*dk + c] * rowscale[(b*H + h)*T + i], r = b*T + i: folds the row normalisation of
  * a3t_attn_fwd_train's probabilities into the dctx operand of dV = probs_drop^T dctx (attention.py:96 backward). */
 int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y, int B, int H, int T, int dk, void* stream);
+/* Score gradients from a3t_attn_fwd_train's saved probabilities in ONE launch (the backward of attention.py:64-96, 145-209
+ * between dctx and the two T x T operands of the remaining GEMMs): dP = dctx V^T is formed tile by tile on the matrix cores and
+ * never stored;  ds[b][h][i][j] = probs * rowscale[i] * (keep_ij / (1 - drop_p) * dP_ij - delta[i]) * scale  (keep from the counter
+ * RNG with the forward's key and index; delta from a3t_attn_delta);  dbd = the same values in the compact dBD layout of
+ * a3t_relpos_softmax_bwd (block (b, h) at b*dbd_bsb + h*dbd_bsh elements, both 0 = [B][H][T][T]; every entry is written).
+ * Replaces the dprobs GEMM + a3t_relpos_softmax_bwd of the materialised backward.  dctx row stride ldo, v row stride ldkv
+ * (head h at column h*dk), dk % 32 == 0 (<= 192, not 160), T % 8 == 0. */
+int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* probs, const float* rowscale, const float* delta, void* ds,
+                    void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb, int64_t dbd_bsh,
+                    float scale, float drop_p, uint32_t drop_key, void* stream);
 /* Backward of a3t_attn_fwd (the autograd graph of attention.py:167-209 restated): probabilities are recomputed from
  * lse, nothing T x T is read.
  *   a3t_attn_delta: delta[b][h][i] = sum_d dctx * ctx (= sum_j dP_ij P_ij, with or without dropout).

@@ -365,14 +365,17 @@ def test_training_forward_saves_probabilities_the_materialised_backward_can_use(
         assert rel < 1e-2, rel                        # same mask; one more bf16 rounding
 
 
+@pytest.mark.parametrize("bwd_ds", ["0", "1"])
 @pytest.mark.parametrize("dropout", [False, True])
-def test_engine_training_step_with_the_fused_forward_matches_the_materialised_step(dropout, monkeypatch):
+def test_engine_training_step_with_the_fused_forward_matches_the_materialised_step(dropout, bwd_ds, monkeypatch):
     """Default training path of round 4 (fused forward that saves un-normalised probabilities + materialised backward) against
-    the fully materialised step: same dropout masks, loss and every parameter gradient to bf16 accuracy."""
+    the fully materialised step: same dropout masks, loss and every parameter gradient to bf16 accuracy.  bwd_ds = 1: the
+    opt-in score-gradient kernel (a3t_attn_bwd_ds) in place of the dprobs GEMM + softmax backward."""
     from a3t_amd.config import A3TConfig
     from a3t_amd.engine import MLMEngine
     from a3t_amd.params import ParamStore
     monkeypatch.delenv("A3T_FUSED_ATTN", raising=False)
+    monkeypatch.setenv("A3T_ATTN_BWD_DS", bwd_ds)
     oc = O.A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
     c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab,
                   dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
@@ -386,7 +389,7 @@ def test_engine_training_step_with_the_fused_forward_matches_the_materialised_st
         store = ParamStore(c, DEV)
         store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
         eng = MLMEngine(c, store, compute="bf16", training=True, dropout=dropout)
-        assert eng.fused_attn_train == (fused == "1")
+        assert eng.fused_attn_train == (fused == "1") and eng.attn_bwd_ds == (bwd_ds == "1")
         loss = float(eng.forward(batch)["loss"])
         assert sum(k.endswith(".rs") for k in eng.sv) == (3 if fused == "1" else 0)
         store.zero_grad()
@@ -539,3 +542,75 @@ def test_key_split_tail_block_that_overflows_is_recomputed(train):
     if train:
         pn = probs[sl].float().cpu().double() * rs[sl].cpu().double()[..., None]
         assert bool(torch.isfinite(pn).all()) and float((pn - pr).abs().max()) < 8e-3
+
+
+@pytest.mark.parametrize("hm", [False, True])
+@pytest.mark.parametrize("drop_p", [0.0, 0.2])
+@pytest.mark.parametrize("B,H,T,dk,lengths", CASES[:3] + [(2, 2, 328, 192, [328, 0]), (1, 2, 296, 64, [200]), (3, 2, 1120, 96, [1120, 900, 1000])])
+def test_score_gradients_from_saved_probabilities_in_one_launch(B, H, T, dk, lengths, drop_p, hm):
+    """a3t_attn_bwd_ds against the definition on the same operands (fp64): ds = p (keep/(1-p) dctx V^T - delta) scale with
+    p = probs * rowscale, keep read off probs_drop; dbd = ds through the inverse legacy skew (attention.py:145-165), every
+    entry written; and against the two kernels it replaces (dprobs GEMM + a3t_relpos_softmax_bwd)."""
+    from a3t_amd import ops
+    from a3t_amd._lib import BF16
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=3 * T + dk + 1, lengths=lengths)
+    if lengths is not None and len(lengths) == 1:
+        keymask[0, :40] = 0
+        keymask[0, 120:150] = 0
+    d = H * dk
+    scale = 1.0 / math.sqrt(dk)
+    drop = (drop_p, 0x5151) if drop_p else (0.0, 0)
+    ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=DEV)
+    probs = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    pdrop = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16) if drop_p else None
+    rs = torch.zeros(B, H, T, device=DEV)
+    ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, scale, drop=drop)
+    g = torch.Generator(device="cpu").manual_seed(T + dk)
+    dctx = torch.randn(B * T, d, generator=g).to(DEV).bfloat16()
+    delta = torch.zeros(B, H, T, device=DEV)
+    ops.attn_delta(dctx, ctx, delta, B, H, T)
+    ds = torch.full((B, H, T, T), 3.0, device=DEV, dtype=torch.bfloat16)
+    dshape = (H, B, T, T) if hm else (B, H, T, T)
+    dbd = torch.full(dshape, 3.0, device=DEV, dtype=torch.bfloat16)
+    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=hm)
+    torch.cuda.synchronize()
+    # definition in fp64
+    v = qkv[:, 2 * d:].double().view(B, T, H, dk).transpose(1, 2)
+    dc = dctx.double().view(B, T, H, dk).transpose(1, 2)
+    dP = dc @ v.transpose(-1, -2)
+    if drop_p:
+        keep = ((pdrop.float() != 0) | (probs.float() == 0)).double()
+        dP = dP * keep / (1.0 - drop_p)
+    pn = probs.double() * rs.double()[..., None]
+    want = pn * (dP - delta.double()[..., None]) * scale
+    got = ds.double()
+    sc = max(1e-6, float(want.abs().max()))
+    err = float((got - want).abs().max()) / sc
+    print(f"[B{B} H{H} T{T} dk{dk} p{drop_p}] ds max err / max |ds| = {err:.2e}")
+    assert err < 6e-3                                  # bf16 outputs
+    # dbd = the inverse skew of the ds the kernel wrote, bit for bit; row 0, columns 0..T-2 zero
+    dsb = ds if not hm else ds
+    dbv = dbd.transpose(0, 1) if hm else dbd
+    ref = torch.zeros(B, H, T + 1, T, device=DEV, dtype=torch.bfloat16)
+    ii = torch.arange(T, device=DEV)[:, None].expand(T, T)
+    jj = torch.arange(T, device=DEV)[None, :].expand(T, T)
+    lo = jj <= ii
+    up = jj >= ii + 2
+    ref[:, :, ii[lo], (T - 1 - ii + jj)[lo]] = dsb[:, :, ii[lo], jj[lo]]
+    ref[:, :, (ii + 1)[up], (jj - ii - 2)[up]] = dsb[:, :, ii[up], jj[up]]
+    assert torch.equal(dbv.contiguous(), ref[:, :, :T].contiguous())
+    # the kernels it replaces
+    dpr = torch.empty(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    vv = qkv.view(-1)[2 * d:]
+    zb = (H * T * T, T * T)
+    ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(T * 3 * d, dk),
+             c_bs=zb, compute=BF16)
+    ds2 = torch.empty_like(ds)
+    dbd2 = torch.zeros_like(dbd)
+    ops.relpos_softmax_bwd(probs, dpr, ds2, dbd2, B, H, T, scale, probs_drop=None, drop_p=drop[0], dbd_head_major=hm,
+                           drop_key=drop[1], rowscale=rs)
+    torch.cuda.synchronize()
+    err2 = float((ds2.double() - want).abs().max()) / sc
+    assert err <= err2 + 2e-3, (err, err2)              # no worse than the path through a bf16 dprobs
+    assert float((ds2.float() - ds.float()).abs().max()) / sc < 2e-2
