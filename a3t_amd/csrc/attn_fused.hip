@@ -1699,29 +1699,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
 
 // Fold of the key-split tail blocks (launch_fwd16): O = sum of the parts' un-normalised sums, l likewise, both relative to
 // the block's one reference maximum -> ctx, lse, rowscale and the overflow flag exactly as the unsplit epilogue writes them.
-// grid = items x 8, 4 waves x 4 rows each, lane = 4 columns.
+// grid = items x 32, one row per wave, lane = 4 columns; the (<= 4) parts of a row are requested together.
 __global__ __launch_bounds__(256) void attn_split_finish_kernel(AttnArgs p, int nitems, int DK) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int titem = blockIdx.x >> 3, P = p.nparts, T = p.T, NQB = (T + 127) / 128;
+    const int titem = blockIdx.x >> 5, P = p.nparts, T = p.T, NQB = (T + 127) / 128;
     const int wi = p.item0 + titem, bh = wi / NQB, qb = wi - bh * NQB, b = bh / p.H, h = bh - b * p.H;
     const int64_t nrow = (int64_t)nitems * P * 128;
+    const int row = (blockIdx.x & 31) * 4 + w, i = qb * 128 + row;
     bool bad = false;
+    if (i < T) {
+        float lp[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 op[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int row = (blockIdx.x & 7) * 16 + w * 4 + rr, i = qb * 128 + row;
-        if (i >= T) continue;
-        float l = 0.f;
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = 0; q < P; ++q) {
-            const int64_t pr = ((int64_t)titem * P + q) * 128 + row;
-            l += p.part_ws[nrow * DK + pr];
-            if (lane * 4 < DK) {
-                const float4 v = *(const float4*)(p.part_ws + pr * DK + lane * 4);
-                o.x += v.x, o.y += v.y, o.z += v.z, o.w += v.w;
+        for (int q = 0; q < 4; ++q) {
+            op[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < P) {
+                const int64_t pr = ((int64_t)titem * P + q) * 128 + row;
+                lp[q] = p.part_ws[nrow * DK + pr];
+                if (lane * 4 < DK) op[q] = *(const float4*)(p.part_ws + pr * DK + lane * 4);
             }
         }
         const float m2 = p.part_ws[nrow * (DK + 1) + (int64_t)titem * 128 + row];
-        bad = bad || !(l < 3.0e38f);
+        const float l = (lp[0] + lp[1]) + (lp[2] + lp[3]);
+        const float4 o = make_float4((op[0].x + op[1].x) + (op[2].x + op[3].x), (op[0].y + op[1].y) + (op[2].y + op[3].y),
+                                     (op[0].z + op[1].z) + (op[2].z + op[3].z), (op[0].w + op[1].w) + (op[2].w + op[3].w));
+        bad = !(l < 3.0e38f);
         const float invl = l > 0.f ? 1.f / l : 0.f;
         if (lane * 4 < DK) {
             uint2 pk;
@@ -1829,7 +1831,7 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV, false, true>,                                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds32);                                            \
             hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV, false, true>), dim3(nfull + ntail * nparts), dim3(256), lds32, s, at); \
-            hipLaunchKernelGGL(attn_split_finish_kernel, dim3(ntail * 8), dim3(256), 0, s, at, (int)ntail, DT32<NDB>::DK);            \
+            hipLaunchKernelGGL(attn_split_finish_kernel, dim3(ntail * 32), dim3(256), 0, s, at, (int)ntail, DT32<NDB>::DK);            \
         } else {                                                                                                                     \
             hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV>), dim3(grid), dim3(256), lds32, s, a);                                 \
         }                                                                                                                            \
