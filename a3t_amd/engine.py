@@ -39,6 +39,21 @@ def legacy_pe_table(c: A3TConfig) -> torch.Tensor:
     return pe
 
 
+_STREAMS = {}
+
+
+def shared_stream(dev, kind, high=False):
+    """One HIP stream per (device, role) for the whole process.  HIP maps streams onto a small pool of hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) round-robin: a process that builds a second engine / trainer with streams of its own
+    gets a main and a side stream on the SAME hardware queue sooner or later and the two-stream schedule silently runs as
+    one (bench.py's configs[3] leg, the third trainer of its process: 84 ms per step instead of 66)."""
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), kind)
+    if key not in _STREAMS:
+        pr = torch.cuda.Stream.priority_range()[1] if high else 0
+        _STREAMS[key] = torch.cuda.Stream(device=dev, priority=pr)
+    return _STREAMS[key]
+
+
 class _FastEvent:
     """Cross-stream hand-over event created with hipEventDisableTiming | hipEventDisableSystemFence: the marker packet of
     a default-flag event costs the queue it is recorded on ~7.3 us between two kernels, this one ~5.2 (tools/event_cost.py,
@@ -156,10 +171,10 @@ class MLMEngine:
         # row kernels (LayerNorm / softmax backward).  Scratch tensors they read are double-buffered by sub-layer parity.
         self.side = self.side2 = None
         if self.dev.type == "cuda" and os.environ.get("A3T_SIDE_STREAM", "1") != "0":
-            self.side = torch.cuda.Stream(device=self.dev)
+            self.side = shared_stream(self.dev, "side")
             # results the main stream waits for inside the sub-layer (dV, dK of the attention backward) get a stream of their own:
             # queued behind the weight gradients they would hand the main stream the whole backlog to wait for
-            self.side2 = (torch.cuda.Stream(device=self.dev, priority=torch.cuda.Stream.priority_range()[1])
+            self.side2 = (shared_stream(self.dev, "side2", high=True)
                           if os.environ.get("A3T_SIDE2", "1") != "0" else self.side)
         self._par = 0
         self._depth = max(2, int(os.environ.get("A3T_SIDE_DEPTH", "48")))   # scratch sets the main stream may run ahead by

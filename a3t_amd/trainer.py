@@ -87,7 +87,11 @@ class FlatAllReduce:
         self.g = flat_grad
         self.ranges = ranges
         self.cuda = flat_grad.is_cuda
-        self.stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        if self.cuda:
+            from .engine import shared_stream
+            self.stream = shared_stream(flat_grad.device, "allreduce")
+        else:
+            self.stream = None
         self.works = []
         self.comm_dtype = comm_dtype
         self.stage = None
@@ -162,7 +166,8 @@ class A3TTrainer:
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self._main = None
         if dev.type == "cuda" and os.environ.get("A3T_MAIN_PRIORITY", "1") != "0":
-            self._main = torch.cuda.Stream(device=dev, priority=torch.cuda.Stream.priority_range()[1])
+            from .engine import shared_stream
+            self._main = shared_stream(dev, "main", high=True)
         self.reducer = None
         if self.world > 1 or (force_reducer and dist.is_available() and dist.is_initialized()):
             # (force_reducer: run the bucketed, overlapped reduction on a 1-rank group -- test hook for the stream /
