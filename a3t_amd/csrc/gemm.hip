@@ -466,6 +466,11 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 0.f;
     p.keep_out = (unsigned char*)d->keep_out, p.keep_in = (const unsigned char*)d->keep_in;
     p.a_bytes = p.b_bytes = 0;
+    p.ln_g = d->ln_gamma, p.ln_b = d->ln_beta, p.ln_y = d->ln_y, p.ln_mean = d->ln_mean, p.ln_rstd = d->ln_rstd;
+    p.ln_eps = d->ln_eps, p.ln_y_dtype = d->ln_y_dtype;
+    if (p.ln_y && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16 || !p.ln_g || !p.ln_b || !p.ln_mean ||
+                   !p.ln_rstd || (p.ln_y_dtype != A3T_BF16 && p.ln_y_dtype != A3T_F32)))
+        return A3T_EINVAL;
     const bool keep = p.keep_out || p.keep_in;
     if (keep && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16)) return A3T_EINVAL;
     if (p.c_dtype == A3T_BF16 && p.accumulate != A3T_ACC_STORE) return A3T_EINVAL;
@@ -517,6 +522,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         if (rc >= 0) return rc;                                   // -1: alignment contract not met
     }
     if (keep) return A3T_EINVAL;        // keep-bit images only exist in the 8-phase kernel
+    if (p.ln_y) return A3T_EINVAL;      // the fused LayerNorm only exists in the panel kernel
     if (d->colsum) return A3T_EINVAL;   // fused column sums live in the direct-to-LDS kernel's epilogue
     {
         const int ea = d->a_dtype == A3T_BF16 ? 2 : 4, eb = d->b_dtype == A3T_BF16 ? 2 : 4;

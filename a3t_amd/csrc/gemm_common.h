@@ -35,6 +35,14 @@ struct GP {
     unsigned char* keep_out;        // optional: one keep bit per output (value > 0), tile-major image
     const unsigned char* keep_in;   // optional: keep bits applied as a mask (written by the GEMM with the same M x N tiling)
     unsigned int a_bytes, b_bytes;  // operand extents for the buffer descriptors
+    // panel kernel (gemm_bf16_pn.hip), N == 384: LayerNorm of the finished output rows in the epilogue
+    const float* ln_g;
+    const float* ln_b;
+    void* ln_y;                     // [M][N] bf16 | fp32 (ln_y_dtype)
+    float* ln_mean;
+    float* ln_rstd;
+    float ln_eps;
+    int ln_y_dtype;
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return io_f2bf(f); }   // hardware RNE conversion
