@@ -43,4 +43,29 @@ def test_gemm_desc_layout_matches_header():
     assert GemmDesc.batch.offset == 112 and GemmDesc.a_bs0.offset == 120
     assert GemmDesc.taps.offset == 168 and GemmDesc.alpha.offset == 188
     assert GemmDesc.s_dtype.offset == 220 and GemmDesc.colsum.offset == 232 and GemmDesc.drop_p.offset == 256
-    assert GemmDesc.keep_out.offset == 264 and GemmDesc.keep_in.offset == 272 and ctypes.sizeof(GemmDesc) == 280
+    assert GemmDesc.keep_out.offset == 264 and GemmDesc.keep_in.offset == 272
+    # round 4: the fused-LayerNorm block appended at the end (older callers that zero the struct keep working)
+    assert GemmDesc.ln_gamma.offset == 280 and GemmDesc.ln_y.offset == 296 and GemmDesc.ln_rstd.offset == 312
+    assert GemmDesc.ln_eps.offset == 320 and GemmDesc.ln_y_dtype.offset == 324 and ctypes.sizeof(GemmDesc) == 328
+
+
+def test_gemm_desc_layout_as_the_c_compiler_sees_the_header(tmp_path):
+    """offsetof / sizeof of a3t_gemm_desc from include/a3t_hip.h compiled by gcc against the ctypes mirror, field by field."""
+    import ctypes
+    import shutil
+    import subprocess
+    from a3t_amd._lib import GemmDesc
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    names = [f[0] for f in GemmDesc._fields_]
+    src = tmp_path / "off.c"
+    body = "\n".join(f'    printf("{n} %zu\\n", offsetof(a3t_gemm_desc, {n}));' for n in names)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "a3t_hip.h"\nint main(void) {\n' + body +
+                   '\n    printf("sizeof %zu\\n", sizeof(a3t_gemm_desc));\n    return 0;\n}\n')
+    exe = tmp_path / "off"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n in names:
+        assert int(out[n]) == getattr(GemmDesc, n).offset, n
+    assert int(out["sizeof"]) == ctypes.sizeof(GemmDesc)
