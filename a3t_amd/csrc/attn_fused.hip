@@ -100,6 +100,7 @@ static __device__ __attribute__((aligned(16))) unsigned int attn_zero_page[8];
 #define A3T_SAVE_STORE(d, r, vo) __builtin_amdgcn_raw_buffer_store_b128(d, r, vo, 0, A3T_SAVE_AUX)
 #endif
 static __device__ int attn_redo[1 << 16];
+static void* g_attn_timing_buf = nullptr;      // a3t_attn_timing_buf(): where timing builds (-DA3T_ATTN_TIMING / -DA3T_DS_TIMING) file their stamps
 
 // LDS-DMA piece (64 lanes x 16 B -> 1 KiB at lds_addr) as inline asm ON PURPOSE: for the builtin the compiler tracks "an LDS
 // write is in flight" and, because every tile pointer is an offset into the one dynamic LDS array, puts a vmcnt wait for ALL
@@ -1002,6 +1003,7 @@ struct DsArgs {
     int64_t ldo, ldkv, dbd_bsb, dbd_bsh;
     float scale, drop_inv;
     unsigned int drop_thr, drop_key;
+    unsigned long long* timing;   // A3T_DS_TIMING builds: per-wave cycle totals of the eight phases
 };
 
 // chunk ci (row-contiguous 16-byte pieces, chunk index fastest) of the wave's probability strip
@@ -1097,6 +1099,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
 
     int64_t task = blockIdx.x;
     if (task >= ntasks) return;
+#ifdef A3T_DS_TIMING
+    unsigned long long tacc[8] = {}, tprev = __builtin_readcyclecounter();
+#define DSTAMP(k) do { PHASE_FENCE(); const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; PHASE_FENCE(); } while (0)
+#else
+#define DSTAMP(k) ((void)0)
+#endif
     int c_bh, c_b, c_h, c_q0, c_sa, c_nt, c_J0, c_J1, n_bh, n_b, n_h, n_q0, n_sa, n_nt, n_J0, n_J1;
     A3T_DS_DECODE(c_, task);
     int gt = 0;                                          // running tile count of this workgroup: ring slot = gt % NRING
@@ -1110,7 +1118,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         const int cpr = 4 * c_nt, npair = 32 * cpr;
         const unsigned mg_cpr = ds_magic(cpr), mg_slot = ds_magic(cpr + 1);
         const int i = c_q0 + lr;
+        DSTAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this task's inputs (and its first V tiles, and the last task's stores)
+        DSTAMP(1);
         A3T_DS_PUT(0, pr0); A3T_DS_PUT(1, pr1); A3T_DS_PUT(2, pr2); A3T_DS_PUT(3, pr3); A3T_DS_PUT(4, pr4);
         A3T_DS_PUT(5, pr5); A3T_DS_PUT(6, pr6); A3T_DS_PUT(7, pr7); A3T_DS_PUT(8, pr8); A3T_DS_PUT(9, pr9);
         bf16x8 fd[KS];
@@ -1122,6 +1132,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         u16* dbB = p.dbd + (int64_t)c_b * p.dbd_bsb + (int64_t)c_h * p.dbd_bsh;
         if (c_q0 == 0 && c_sa == 0)          // BD[0][0 .. T-2] never reaches the scores (attention.py:157-165)
             for (int c = lane; c < T - 1; c += 64) dbB[c] = 0;
+        DSTAMP(2);
         // ---- tiles
         for (int k = 0; k < c_nt; ++k, ++gt) {
             // V(k) has landed: of the DMA issued after it only tile k+1 may still be in flight (tile k+2 is issued below)
@@ -1131,6 +1142,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
             else if (NPMIN == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            DSTAMP(3);
             // two tiles ahead, into the slot every wave left before this barrier; past the end of the task: the next task's
             if (k + 2 < c_nt) A3T_DS_ISSUE_V(c_, k + 2, (gt + 2) % NRING);
             else if (more && k + 2 - c_nt < n_nt) A3T_DS_ISSUE_V(n_, k + 2 - c_nt, (gt + 2) % NRING);
@@ -1155,6 +1167,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
                 o.x = io_pack2(p0 * rsc * (d0_ - dl), p1 * rsc * (d1_ - dl)), o.y = io_pack2(p2 * rsc * (d2_ - dl), p3 * rsc * (d3_ - dl));
                 *(uint2*)(cell + 16 * g) = o;
             }
+            DSTAMP(4);
         }
         // (a one-tile task leaves the next task's second V tile to be issued here; a barrier first: slot gt+1 may still be read)
         if (more && c_nt == 1 && n_nt > 1) {
@@ -1163,12 +1176,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         }
         // ---- the next task's inputs travel while this one's image leaves
         if (more) A3T_DS_FETCH(n_);
+        DSTAMP(5);
         // ---- dS rows
         for (int c0 = 0; c0 < npair; c0 += 64) {
             const int ci = c0 + lane, row = ds_div(ci, mg_cpr), ch = ci - row * cpr;
             const int gi = c_q0 + row, col = c_J0 + 8 * ch;
             if (ci < npair && gi < T && col < T) *(uint4*)(dsB + (int64_t)gi * T + col) = *(const uint4*)(img + row * RS + ch * 16);
         }
+        DSTAMP(6);
         // ---- dBD: per query row a lower run (keys <= i -> row i) and an upper run (keys >= i+2 -> row i+1)
         const int nslot = cpr + 1, nps = 32 * nslot;
 #pragma unroll 1
@@ -1214,10 +1229,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
                 }
             }
         }
+        DSTAMP(7);
         if (!more) break;
         task = ntask;
         c_bh = n_bh, c_b = n_b, c_h = n_h, c_q0 = n_q0, c_sa = n_sa, c_nt = n_nt, c_J0 = n_J0, c_J1 = n_J1;
     }
+#ifdef A3T_DS_TIMING
+    if (lane == 0 && p.timing) {
+        unsigned long long* o = p.timing + ((int64_t)blockIdx.x * 4 + w) * 8;
+        for (int e = 0; e < 8; ++e) o[e] = tacc[e];
+    }
+#endif
+#undef DSTAMP
 #undef A3T_DS_FETCH
 #undef A3T_DS_PUT
 #undef A3T_DS_DECODE
@@ -1933,6 +1956,7 @@ extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* prob
     a.ds = (u16*)ds, a.dbd = (u16*)dbd, a.B = B, a.H = H, a.T = T, a.ldo = ldo, a.ldkv = ldkv, a.dbd_bsb = dbd_bsb, a.dbd_bsh = dbd_bsh;
     a.scale = scale;
     a.drop_thr = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u, a.drop_key = drop_key, a.drop_inv = 1.f / (1.f - drop_p);
+    a.timing = (unsigned long long*)g_attn_timing_buf;
     // tasks = (128 queries) x (5 key tiles): several times more tasks than workgroup slots (2 per CU), so the last round is short
     constexpr int KT = 5;
     const int NS = (T + 31) / 32;
@@ -2009,8 +2033,7 @@ extern "C" int a3t_attn_bwd_finish(const void* dqu, const void* dqvl, const void
     return (int)hipGetLastError();
 }
 
-#ifdef A3T_ATTN_TIMING
-static void* g_attn_timing_buf = nullptr;
+#if defined(A3T_ATTN_TIMING) || defined(A3T_DS_TIMING)
 extern "C" void a3t_attn_timing_buf(void* ptr) { g_attn_timing_buf = ptr; }
 #endif
 __global__ __launch_bounds__(256) void attn_scale_rows_kernel(const u16* __restrict__ x, const float* __restrict__ rs,
