@@ -85,7 +85,7 @@ def one_case_bf16(rng, verbose=False):
                   dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
     B = rng.randrange(1, 5)
     T_mel = 8 * rng.randrange(4, 40)
-    T_phn = 8 * rng.randrange(1, 6)
+    T_phn = min(8 * rng.randrange(1, 6), T_mel - 8)          # (every phone needs at least one frame: case 27 of the seed-2026 sweep)
     store = ParamStore(c, DEV)
     xavier_init_(store, seed=rng.randrange(1000), bn_gamma=1.0)
     batch = synthetic_batch(c, B, T_mel, T_phn, seed=rng.randrange(1 << 20), device=DEV)
