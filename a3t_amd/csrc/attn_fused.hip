@@ -1086,10 +1086,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         pr4 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 256 + lane), pr5 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 320 + lane);  \
         pr6 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 384 + lane), pr7 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 448 + lane);  \
         pr8 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 512 + lane), pr9 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 576 + lane);  \
-        _Pragma("unroll") for (int kk = 0; kk < KS; ++kk)                                                           \
-            in_fd[kk] = ld_frag_g(dcB_ + (int64_t)i_ * p.ldo + 16 * kk + 8 * lh, i_ < T);                           \
-        in_rsc = i_ < T ? p.rowscale[(int64_t)P##bh * T + i_] * p.scale : 0.f;                                      \
-        in_dl = i_ < T ? p.delta[(int64_t)P##bh * T + i_] : 0.f;                                                    \
+        if (fetch_rows) {       /* (wave-uniform: a new query block) */                                            \
+            _Pragma("unroll") for (int kk = 0; kk < KS; ++kk)                                                       \
+                in_fd[kk] = ld_frag_g(dcB_ + (int64_t)i_ * p.ldo + 16 * kk + 8 * lh, i_ < T);                       \
+            in_rsc = i_ < T ? p.rowscale[(int64_t)P##bh * T + i_] * p.scale : 0.f;                                  \
+            in_dl = i_ < T ? p.delta[(int64_t)P##bh * T + i_] : 0.f;                                                \
+        }                                                                                                           \
     } while (0)
 #define A3T_DS_PUT(u_, v_)                                                          \
     do {                                                                            \
@@ -1097,8 +1099,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         if (ci < npair) *(uint4*)(img + row * RS + ch * 16) = (v_);                 \
     } while (0)
 
-    int64_t task = blockIdx.x;
-    if (task >= ntasks) return;
+    // a workgroup walks a CONTIGUOUS range of tasks = the key strips of one query block after the other: the dctx fragments and
+    // row factors are requested once per query block, not once per strip (193 MB less through the CU's address path per launch)
+    const int64_t tper = (ntasks + gridDim.x - 1) / gridDim.x;
+    int64_t task = (int64_t)blockIdx.x * tper;
+    const int64_t tend = task + tper < ntasks ? task + tper : ntasks;
+    if (task >= tend) return;
 #ifdef A3T_DS_TIMING
     unsigned long long tacc[8] = {}, tprev = __builtin_readcyclecounter();
 #define DSTAMP(k) do { PHASE_FENCE(); const unsigned long long tn = __builtin_readcyclecounter(); tacc[k] += tn - tprev; tprev = tn; PHASE_FENCE(); } while (0)
@@ -1110,10 +1116,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
     int gt = 0;                                          // running tile count of this workgroup: ring slot = gt % NRING
     A3T_DS_ISSUE_V(c_, 0, 0);
     if (c_nt > 1) A3T_DS_ISSUE_V(c_, 1, 1);
+    bool fetch_rows = true;
     A3T_DS_FETCH(c_);
     while (true) {
-        const int64_t ntask = task + gridDim.x;
-        const bool more = ntask < ntasks;
+        const int64_t ntask = task + 1;
+        const bool more = ntask < tend;
         A3T_DS_DECODE(n_, (more ? ntask : task));
         const int cpr = 4 * c_nt, npair = 32 * cpr;
         const unsigned mg_cpr = ds_magic(cpr), mg_slot = ds_magic(cpr + 1);
@@ -1175,6 +1182,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
             A3T_DS_ISSUE_V(n_, 1, (gt + 1) % NRING);
         }
         // ---- the next task's inputs travel while this one's image leaves
+        fetch_rows = n_bh != c_bh || n_q0 != c_q0;
         if (more) A3T_DS_FETCH(n_);
         DSTAMP(5);
         // ---- dS rows

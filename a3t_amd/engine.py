@@ -210,8 +210,8 @@ class MLMEngine:
         self.attn_hm = os.environ.get("A3T_ATTN_DBD_HM", "0") == "1"
         self.attn_regen = os.environ.get("A3T_ATTN_REGEN_MASK", "1") != "0"
         # dS / dBD straight from the saved probabilities in one launch (a3t_attn_bwd_ds) instead of the dprobs GEMM + softmax
-        # backward: opt-in -- 208 us against 220 alone, but a persistent 79-KB-LDS kernel shares the chip with the weight-gradient
-        # stream worse than the pair it replaces (configs[1]: 46.6 ms per step against 45.6)
+        # backward: opt-in -- 177 us against 216 alone, but a persistent 79-KB-LDS kernel shares the chip with the weight-gradient
+        # stream worse than the pair it replaces (configs[1]: 46.7 ms per step against 46.2)
         self.attn_bwd_ds = os.environ.get("A3T_ATTN_BWD_DS", "0") == "1"
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
         # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
