@@ -527,6 +527,6 @@ int a3t_gemm_bf16_pn(const GP& p, int batch, int ly, hipStream_t stream) {
         launch_pn<true>(pv, grid, stream);
     else
         launch_pn<false>(pv, grid, stream);
-    a3t_note_kernel("gemm_bf16_pn_kernel<%s>", conv ? "true" : "false");
+    a3t_note_kernel("gemm_bf16_pn_kernel<%s, false>", conv ? "true" : "false");
     return (int)hipGetLastError();
 }

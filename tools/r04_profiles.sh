@@ -65,6 +65,8 @@ for k, d in agg.items():
 json.dump(out, open("gpurun_out/r04_attn_pmc.json", "w"), indent=1)
 PY
 rm -rf gpurun_out/r04_pmca_*
+bash tools/r04_gemm_pmc.sh > gpurun_out/r04_gemm_pmc.log 2>&1
+cd $R
 python tools/attn_bench.py > gpurun_out/r04_attn_bench.txt 2>&1
 for v in 32 16; do A3T_ATTN_FWD=$v python tools/attn_fwd_time.py >> gpurun_out/r04_attn_bench.txt 2>&1; done
 TRAIN=1 python tools/attn_fwd_time.py >> gpurun_out/r04_attn_bench.txt 2>&1
