@@ -988,9 +988,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 //   delta_i = dctx_i . ctx_i (a3t_attn_delta), written twice: row-major (operand of dK = dS^T (q+u) and d(q+u) = dS K) and
 //   through the inverse legacy skew (attention.py:145-165) into the compact dBD matrix (operand of d(q+v) and d linear_pos).
 // It replaces the dprobs GEMM (a T x T write) and a3t_relpos_softmax_bwd (a T x T read): 480 MB per launch at configs[1] instead
-// of 800.  No state is carried along the keys (delta is known up front), so the unit of work is a 32-query x (KT x 32)-key
-// strip and a wave walks strips independently: V fragments come straight from L2, the probability tile and the two outputs go
-// through a per-wave LDS image that turns the MFMA layout (lane = query, 4 x 4 keys) into 16 rows x 64 B per instruction.
+// of 800.  No state is carried along the keys (delta is known up front), so the unit of work is a strip of 128 queries x
+// (KT x 32) keys; the kernel below says how a workgroup moves one.
 struct DsArgs {
     const u16* dctx;      // [B*T][ldo]
     const u16* v;         // [B*T][ldkv], head h at column h*dk

@@ -74,4 +74,4 @@ for name, fn in (("new", new), ("old", old), ("delta", delta_only), ("ds", ds_on
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"{name} KT={os.environ.get('A3T_ATTN_DS_KT', '5')}: {us:.1f} us  ({3 * 2.0 * B * H * T * T / us / 1e6:.2f} TB/s of the 3 T x T tensors of the fused kernel)")
+    print(f"{name}: {us:.1f} us  ({3 * 2.0 * B * H * T * T / us / 1e6:.2f} TB/s of the 3 T x T tensors of the fused kernel)")
