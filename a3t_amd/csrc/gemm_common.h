@@ -119,7 +119,11 @@ __device__ __forceinline__ void epilogue_store(const GP& p, int64_t zoff, int ro
     else if (p.accumulate == A3T_ACC_ADD)
         C[idx] += v;
     else
+#ifdef A3T_EXPERIMENT_NOATOMIC      // measurement build only (wrong sums): what do the split-K atomics cost?
+        C[idx] = v;
+#else
         atomicAdd(&C[idx], v);
+#endif
 }
 
 
