@@ -463,6 +463,8 @@ def _split_restore(old):
     (16, 2, 1120, 64, None),                                   # 288 blocks = 256 + 32 -> the tail runs as 4 key ranges
     (12, 3, 1000, 32, [1000, 640, 0, 977] + [1000] * 8),        # 288 blocks; an empty utterance, ragged lengths in and out of the tail
     (43, 1, 896, 96, [896] * 40 + [100, 896, 30]),              # 301 blocks = 256 + 45 -> 4 ranges; keys end inside the first range
+    (16, 2, 1120, 192, [1120] * 15 + [777]),                    # the benchmark's instantiation (d_k = 192), 288 blocks
+    (9, 4, 1000, 128, [1000] * 8 + [520]),                      # d_k = 128 (configs[3]'s head width), 288 blocks
 ])
 def test_key_split_tail_blocks_equal_the_unsplit_launch(B, H, T, dk, lengths, train, drop_p):
     """A launch whose last round of 128-query blocks fills at most half the chip runs those blocks split into key ranges
