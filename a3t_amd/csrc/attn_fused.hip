@@ -1140,9 +1140,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
             for (int c = lane; c < T - 1; c += 64) dbB[c] = 0;
         DSTAMP(2);
         // ---- tiles
+        bool issued_prev = false;
         for (int k = 0; k < c_nt; ++k, ++gt) {
-            // V(k) has landed: of the DMA issued after it only tile k+1 may still be in flight (tile k+2 is issued below)
-            if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // V(k) has landed: of the DMA issued after it only the tile requested during tile k-1 may still be in flight (if one
+            // was requested then: the last tiles of a workgroup's last task request nothing, and vmcnt(N) with N pieces of V(k)
+            // itself outstanding would let them through -- a race the full test suite found under A3T_ATTN_BWD_DS=1)
+            if (k == 0 || !issued_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (NPMIN >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if (NPMIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (NPMIN == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
@@ -1150,8 +1153,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
             __syncthreads();
             DSTAMP(3);
             // two tiles ahead, into the slot every wave left before this barrier; past the end of the task: the next task's
+            issued_prev = true;
             if (k + 2 < c_nt) A3T_DS_ISSUE_V(c_, k + 2, (gt + 2) % NRING);
             else if (more && k + 2 - c_nt < n_nt) A3T_DS_ISSUE_V(n_, k + 2 - c_nt, (gt + 2) % NRING);
+            else issued_prev = false;
             const unsigned char* Vt = smem + (gt % NRING) * TB;
             f32x16 dP = zero16();
 #pragma unroll
