@@ -616,3 +616,35 @@ def test_score_gradients_from_saved_probabilities_in_one_launch(B, H, T, dk, len
     err2 = float((ds2.double() - want).abs().max()) / sc
     assert err <= err2 + 2e-3, (err, err2)              # no worse than the path through a bf16 dprobs
     assert float((ds2.float() - ds.float()).abs().max()) / sc < 2e-2
+
+
+@pytest.mark.parametrize("B,H,T,dk", [(32, 2, 1120, 192), (16, 4, 1800, 128)])
+def test_score_gradient_kernel_is_deterministic_at_full_size(B, H, T, dk):
+    """a3t_attn_bwd_ds at configs[1]'s and configs[3]'s attention shapes, five launches: bit-identical outputs.  (Regression: a
+    counted vmcnt in front of the LAST V tiles of a workgroup let a tile through before its DMA had landed -- results moved in
+    the 4th digit from run to run; the small-shape parity tests never saw it.)"""
+    from a3t_amd import ops
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=11)
+    d = H * dk
+    scale = 1.0 / math.sqrt(dk)
+    drop = (0.2, 31337)
+    ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, T, device=DEV)
+    probs = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    pdrop = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    rs = torch.zeros(B, H, T, device=DEV)
+    ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, scale, drop=drop)
+    del pdrop
+    dctx = torch.randn(B * T, d, device=DEV).bfloat16()
+    delta = torch.zeros(B, H, T, device=DEV)
+    ops.attn_delta(dctx, ctx, delta, B, H, T)
+    outs = []
+    for _ in range(5):
+        ds = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+        dbd = torch.zeros(H, B, T, T, device=DEV, dtype=torch.bfloat16)
+        ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
+        torch.cuda.synchronize()
+        outs.append((ds, dbd))
+    for ds, dbd in outs[1:]:
+        assert torch.equal(ds, outs[0][0]) and torch.equal(dbd, outs[0][1])
+    assert bool(torch.isfinite(outs[0][0].float()).all()) and float(outs[0][0].float().abs().max()) > 0
