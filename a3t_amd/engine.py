@@ -245,6 +245,10 @@ class MLMEngine:
         self._ffn_plans = {}
         self._lin_plans = {}
         self._wt = {}        # transposed FFN weight shadows (8-phase data gradients), built on demand
+        self._late_cast = os.environ.get("A3T_LATE_CAST", "1") != "0"
+        self._cast_ev = self._wt_ev = None
+        dec = [o for k, (o, _) in store.offsets.items() if k.startswith("dec.")]
+        self._cast_split = min(dec) if dec else 0        # flat offset of the first decoder parameter (a multiple of 64 elements)
 
     # ------------------------------------------------------------------ helpers
     def _drop(self, p, tag):
@@ -274,11 +278,35 @@ class MLMEngine:
         return self.p16[name] if self.bf16 else self.store.p[name]
 
     def refresh_weights(self):
-        if self.bf16:
-            ops.cast_bf16(self.store.flat, self.flat16)
-            if self._need_grad:       # transposed shadows feed data gradients only
-                for suf, (src_off, dst_off, _, flat, shp) in self._wt.items():
-                    ops.cast_bf16_conv_t(self.store.flat, flat, src_off, dst_off, *shp)
+        """bf16 shadows of the fp32 master weights, once per forward.  The flat buffer is laid out in forward order (prologue,
+        encoder, decoder, head): only the part in front of the decoder is cast on the main stream; the rest, and the transposed
+        shadows that only the backward reads, are cast on the (idle) side stream under the encoder's GEMMs -- forward() waits
+        for the first before the decoder, backward() for the second (A3T_LATE_CAST=0: everything up front, 0.33 ms of HBM-bound
+        kernels with nothing beside them)."""
+        self._cast_ev = self._wt_ev = None
+        if not self.bf16:
+            return
+        split = self._cast_split if (self.side is not None and self._late_cast) else 0
+        flat, flat16 = self.store.flat, self.flat16
+        wt = list(self._wt.values()) if self._need_grad else []      # transposed shadows feed data gradients only
+
+        def transposed():
+            for src_off, dst_off, _, tflat, shp in wt:
+                ops.cast_bf16_conv_t(flat, tflat, src_off, dst_off, *shp)
+        if split <= 0:
+            ops.cast_bf16(flat, flat16)
+            transposed()
+            return
+        ops.cast_bf16(flat[:split], flat16[:split])
+        self._cast_ev = self._side(lambda: ops.cast_bf16(flat[split:], flat16[split:]), want_event=True)
+        if wt:
+            self._wt_ev = self._side(transposed, want_event=True)
+
+    def _wait_cast(self, which):
+        ev = getattr(self, which, None)
+        if ev is not None:
+            ev.wait_on(torch.cuda.current_stream())
+            setattr(self, which, None)
 
     def _setup_wt(self, suf, shape):
         """Transposed, tap-reversed bf16 shadows of every weight `*.suf` of `shape` = [n][k][c] -> [c][k'][n] (Linear: k = 1, stored
@@ -955,6 +983,7 @@ class MLMEngine:
         else:
             ops.scale(x, xd, xscale)
         x = xd
+        self._wait_cast("_cast_ev")       # decoder / head shadows cast on the side stream (refresh_weights)
         for i in range(c.dec_blocks):
             x = self.block_fwd(f"dec.{i}", x, pos_d, keymask, B, T)
         x = self._ln_fwd("dec.after", x, "dec.after", out_dtype=torch.float32)
@@ -1023,6 +1052,8 @@ class MLMEngine:
         B, Tm, Tp, T = self.dims
         d = c.adim
         cmp = self.cmp
+        self._wait_cast("_cast_ev")
+        self._wait_cast("_wt_ev")         # transposed weight shadows cast on the side stream (refresh_weights)
         self._arena_clear("bwd64")
         self._arena_clear("bwd32")
         hs, before, after, db, da = self.sv["head"]
