@@ -246,6 +246,8 @@ class MLMEngine:
         self._lin_plans = {}
         self._wt = {}        # transposed FFN weight shadows (8-phase data gradients), built on demand
         self._late_cast = os.environ.get("A3T_LATE_CAST", "1") != "0"
+        self._pos_ahead = os.environ.get("A3T_POS_AHEAD", "1") != "0"
+        self._P_ahead, self._pos_ev = {}, None
         self._cast_ev = self._wt_ev = None
         dec = [o for k, (o, _) in store.offsets.items() if k.startswith("dec.")]
         self._cast_split = min(dec) if dec else 0        # flat offset of the first decoder parameter (a multiple of 64 elements)
@@ -620,8 +622,15 @@ class MLMEngine:
         qu = self._act(tag + ".qu", (M, d))
         qv = self._act(tag + ".qv", (M, d))
         ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
-        P = self._act(tag + ".P", (T, d))
-        ops.linear_fwd(pos, self.W(pre + ".wpos"), P, compute=cmp)
+        P = getattr(self, "_P_ahead", {}).get(tag)
+        if P is not None:       # projected ahead on the side stream (forward())
+            ev = self._pos_ev.get(tag[:3]) if self._pos_ev else None
+            if ev is not None:
+                ev.wait_on(torch.cuda.current_stream())
+                self._pos_ev[tag[:3]] = None
+        else:
+            P = self._act(tag + ".P", (T, d))
+            ops.linear_fwd(pos, self.W(pre + ".wpos"), P, compute=cmp)
         if self._fused_now and ops.attn_fused_supported(dk, T):
             adr = self._drop(c.attention_dropout_rate, tag + ".att")
             ctx = self._act(tag + ".ctx", (M, d))
@@ -971,6 +980,21 @@ class MLMEngine:
             pos_d.copy_(self.pe[:T])
             ws.pos_key = (Tm, Tp, pos_e.data_ptr(), pos_d.data_ptr())     # (on the workspace: engines may share it)
         self.sv["embed"] = (xm, e, text, spos, tpos, masked, speech2)
+        # linear_pos(pos_emb) of every block (attention.py:188-189) depends on nothing but the table and the weights: all of
+        # them are projected up front on the side stream, which is idle in the forward (A3T_POS_AHEAD=0: inside each block)
+        self._P_ahead, self._pos_ev = {}, None
+        if self.side is not None and self._pos_ahead:
+            def project(kind, posx, n):
+                def run():
+                    for i in range(n):
+                        tag = f"{kind}.{i}.mha"
+                        P = self._act(tag + ".P", (T, d))
+                        ops.linear_fwd(posx, self.W(tag + ".wpos"), P, compute=self.cmp)
+                        self._P_ahead[tag] = P
+                return run
+            ev_e = self._side(project("enc", pos_e, c.enc_blocks), want_event=True)
+            ev_d = self._side(project("dec", pos_d, c.dec_blocks), want_event=True)     # (behind the decoder-side weight cast)
+            self._pos_ev = {"enc": ev_e, "dec": ev_d}
         x = xs
         for i in range(c.enc_blocks):
             x = self.block_fwd(f"enc.{i}", x, pos_e, keymask, B, T)
