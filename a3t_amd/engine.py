@@ -247,6 +247,7 @@ class MLMEngine:
         self._wt = {}        # transposed FFN weight shadows (8-phase data gradients), built on demand
         self._late_cast = os.environ.get("A3T_LATE_CAST", "1") != "0"
         self._pos_ahead = os.environ.get("A3T_POS_AHEAD", "1") != "0"
+        self._head_side = os.environ.get("A3T_HEAD_WGRAD_SIDE", "1") != "0"     # postnet / feat_out weight gradients on the side stream
         self._P_ahead, self._pos_ev = {}, None
         self._cast_ev = self._wt_ev = None
         dec = [o for k, (o, _) in store.offsets.items() if k.startswith("dec.")]
@@ -1088,7 +1089,7 @@ class MLMEngine:
                 W = self.W(f"post.{l}.w")
                 oc = W.shape[0]
                 last = (l == c.postnet_layers - 1)
-                dz = ws.get(f"tmp.post.dz{oc}", (B * Tm, oc))
+                dz = ws.get(f"tmp.post.dz{oc}.{l}", (B * Tm, oc))      # (per layer: the side stream reads it after the main stream moved on)
                 pdr = self._drop(c.postnet_dropout_rate, f"post.{l}")
                 if pdr:
                     gd = ws.get(f"tmp.post.gd{oc}", (B * Tm, oc))
@@ -1096,12 +1097,14 @@ class MLMEngine:
                     g = gd
                 self._bn_bwd(f"post.{l}", g, f"post.{l}.bn", ACT_NONE if last else ACT_TANH, dz)
                 if self.bf16:
-                    dz16 = ws.get(f"tmp.post.dz16.{oc}", (B * Tm, oc), torch.bfloat16)
+                    dz16 = ws.get(f"tmp.post.dz16.{oc}.{l}", (B * Tm, oc), torch.bfloat16)
                     ops.cast_bf16(dz, dz16)
                     dz = dz16
                 yin = self.sv[f"post.{l}"]
                 ic = yin.shape[1]
-                ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=cmp)
+                # (weight gradients of the head: the side stream is idle at the start of the backward)
+                (self._side if self._head_side else (lambda f: f()))(
+                    lambda dz=dz, yin=yin, l=l: ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=cmp))
                 gi = ws.get(f"tmp.post.g{l % 2}.{ic}", (B * Tm, ic))
                 ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=cmp)
                 g = gi
@@ -1113,7 +1116,7 @@ class MLMEngine:
             ops.cast_bf16(db, dba)
         dhs = ws.get("tmp.dhs", (B * Tm, d))
         ops.linear_bwd_data(dba, self.W("sfc.w"), dhs, compute=cmp)
-        ops.linear_bwd_weight(dba, hs, gr["sfc.w"], compute=cmp)
+        (self._side if self._head_side else (lambda f: f()))(lambda: ops.linear_bwd_weight(dba, hs, gr["sfc.w"], compute=cmp))
         self._bias_grad(db, gr["sfc.b"])
         done("sfc.w")
         g = ws.get("grad.x", (B * T, d), zero=True)
