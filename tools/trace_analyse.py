@@ -61,3 +61,12 @@ for r in rs:
         print(f"loss gradient at {(r['s'] - t0) / 1e6:.3f} ms")
 cp = [r for r in step if "copyBuffer" in r["Kernel_Name"]]
 print("copyBuffer launches in the step:", len(cp), "total us", sum(r["e"] - r["s"] for r in cp) / 1e3)
+# the tail of the step: last kernels of every queue
+print("last launches of the step per queue (ms since the previous optimizer ended):")
+for q, v in byq.items():
+    for r in v[-4:]:
+        print(f"   q{q} {(r['s'] - t0) / 1e6:8.3f} .. {(r['e'] - t0) / 1e6:8.3f}  {r['Kernel_Name'][:70]}")
+print("first launches of the step per queue:")
+for q, v in byq.items():
+    for r in v[:3]:
+        print(f"   q{q} {(r['s'] - t0) / 1e6:8.3f} .. {(r['e'] - t0) / 1e6:8.3f}  {r['Kernel_Name'][:70]}")
