@@ -248,6 +248,7 @@ class MLMEngine:
         self._late_cast = os.environ.get("A3T_LATE_CAST", "1") != "0"
         self._pos_ahead = os.environ.get("A3T_POS_AHEAD", "1") != "0"
         self._head_side = os.environ.get("A3T_HEAD_WGRAD_SIDE", "1") != "0"     # postnet / feat_out weight gradients on the side stream
+        self._attn_small_side = os.environ.get("A3T_ATTN_SMALL_SIDE", "1") != "0"   # attn_scale_rows / attn_bias_fold off the main stream
         self._P_ahead, self._pos_ev = {}, None
         self._cast_ev = self._wt_ev = None
         dec = [o for k, (o, _) in store.offsets.items() if k.startswith("dec.")]
@@ -738,8 +739,7 @@ class MLMEngine:
         rs = self.sv.get(tag + ".rs")      # fused training forward: probs / pdrop are exp(s - m_ref), rs = 1 / row sum
         dctx_v = dctx
         if rs is not None:                 # dV = pdrop^T (rs * dctx): fold the row normalisation into the small operand
-            dctx_v = self._act(self._t("tmp.dctxs"), (M, d))
-            ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
+            dctx_v = self._act(self._t("tmp.dctxs"), (M, d))      # (scaled on the side stream, in front of the one GEMM that reads it)
         adr = self._drop(c.attention_dropout_rate, tag + ".att") if pdrop is not None else None
         # bf16 path: the attention-dropout mask comes back from the counter RNG (same key and index as the forward) instead
         # of being read off the dropped probabilities: one T x T read less in the most HBM-bound kernel of the step
@@ -764,9 +764,16 @@ class MLMEngine:
         sl = self._arena_slot("bwd32", tag + ".bsl", S * 4 * d) if fz else None
         csk = dict(colsum_bs1=dk, colsum_slots=S, colsum_ss=4 * d)
         # (independent of the dprobs -> softmax-backward chain: runs beside it on the side stream)
-        self._side(lambda: ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
-                                    batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
-                                    compute=cmp, colsum=sl[3 * d:] if fz else None, **csk), urgent=True)
+        if rs is not None and not self._attn_small_side:
+            ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
+
+        def dv_gemm():
+            if rs is not None and self._attn_small_side:
+                ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
+            ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
+                     batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
+                     compute=cmp, colsum=sl[3 * d:] if fz else None, **csk)
+        self._side(dv_gemm, urgent=True)
         # dBD is laid out head-major [H][B][T][T] (bf16 mode): the gradient of linear_pos, sum_b dbd[b,h]^T (q+v)[b,h], is then ONE
         # token-reduction GEMM per head with K = B*T (split-K) instead of B*H products of K = T accumulated by atomics
         hm = self.bf16 and self.attn_hm
@@ -815,8 +822,9 @@ class MLMEngine:
         ops.add_pos_bias_bwd(dqu, dqv, dqkv)      # (the dq slice only)
         if dk_done is not None:      # the dV / dK slices of dqkv and their column sums come from the side stream
             dk_done.wait_on(torch.cuda.current_stream())
-        if fz:   # d u, d v, d b_q = d u + d v, d b_k, d b_v from the slot sums (all four GEMMs have drained here)
-            ops.attn_bias_fold(sl, S, d, gr[pre + ".u"], gr[pre + ".v"], gbq)
+        if fz:   # d u, d v, d b_q = d u + d v, d b_k, d b_v from the slot sums (all four GEMMs have drained here); feeds nothing
+            (self._side if self._attn_small_side else (lambda f: f()))(
+                lambda: ops.attn_bias_fold(sl, S, d, gr[pre + ".u"], gr[pre + ".v"], gbq))       # but the optimizer
         else:
             self._bias_grad(dqu, gr[pre + ".u"])
             self._bias_grad(dqv, gr[pre + ".v"])
