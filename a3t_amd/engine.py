@@ -974,13 +974,19 @@ class MLMEngine:
                              drop=self._drop(pp, "emb.x") or (0.0, 0), spk=spk)
         pos_e = self._act("pos.enc", (T, d))
         pos_d = self._act("pos.dec", (T, d))
+        pos_on_side = None
         if self._drop(pp, "pos.enc"):      # dropout(pos_emb) (embedding.py:170)
-            pf = ws.get("pos.f32", (T, d))
-            pf[:Tm].copy_(self.pe[:Tm])
-            pf[Tm:].copy_(self.pe[:Tp])
-            ops.dropout(pf, pos_e, *self._drop(pp, "pos.enc"))
-            pf.copy_(self.pe[:T])
-            ops.dropout(pf, pos_d, *self._drop(pp, "pos.dec"))
+            def drop_pos():
+                pf = ws.get("pos.f32", (T, d))
+                pf[:Tm].copy_(self.pe[:Tm])
+                pf[Tm:].copy_(self.pe[:Tp])
+                ops.dropout(pf, pos_e, *self._drop(pp, "pos.enc"))
+                pf.copy_(self.pe[:T])
+                ops.dropout(pf, pos_d, *self._drop(pp, "pos.dec"))
+            if self.side is not None and self._pos_ahead:
+                pos_on_side = drop_pos       # only the positional projections (side stream, below) read the dropped tables
+            else:
+                drop_pos()
             ws.pos_key = None
         elif getattr(ws, "pos_key", None) != (Tm, Tp, pos_e.data_ptr(), pos_d.data_ptr()):
             # (constant for a given (T_mel, T_phn): rebuilt only when the shape or the workspace buffers change)
@@ -995,6 +1001,8 @@ class MLMEngine:
         if self.side is not None and self._pos_ahead:
             def project(kind, posx, n):
                 def run():
+                    if kind == "enc" and pos_on_side is not None:
+                        pos_on_side()
                     for i in range(n):
                         tag = f"{kind}.{i}.mha"
                         P = self._act(tag + ".P", (T, d))
