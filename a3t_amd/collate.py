@@ -204,7 +204,9 @@ class MLMCollateFn:
 def _collate_finish_on_device(self, ds, feats, flen, text, tlen, a_s, a_e, alen, slen):
     from . import ops
     dev = feats.device
-    flen_np = flen.cpu().numpy() if flen.is_cuda else flen.numpy()       # (lengths are computed on the host: no sync)
+    # (the feature extractor derives the frame counts from the host-side sample counts it is handed, so `flen` is a host
+    #  tensor here and nothing waits for the device; a caller that passes device lengths pays one sync for them)
+    flen_np = flen.cpu().numpy() if flen.is_cuda else flen.numpy()
     fe_x = self.feats_extract
     fs_ = align_to_frames(a_s, fe_x.fs, fe_x.hop_length)
     fe_ = align_to_frames(a_e, fe_x.fs, fe_x.hop_length)
@@ -247,11 +249,12 @@ def _collate_device_pipeline(self, ds, slen):
     fe_x = self.feats_extract
     dev = torch.device(fe_x.device)
     B, N = len(ds), int(slen.max())
-    key = (B, N)
-    if getattr(self, "_pin_key", None) != key:
-        self._pin = torch.empty(B, N, dtype=torch.float32).pin_memory()
-        self._pin_key = key
-    pin = self._pin
+    # pinned staging buffer: flat and grow-only (a hipHostMalloc per batch shape would cost more than the copy it serves);
+    # the (B, N) view of its head is contiguous, so every chunk is one plain async H2D copy
+    if getattr(self, "_pin", None) is None or self._pin.numel() < B * N:
+        self._pin = torch.empty(max(B * N, int(1.25 * getattr(self, "_pin_cap", 0))), dtype=torch.float32).pin_memory()
+        self._pin_cap = self._pin.numel()
+    pin = self._pin[:B * N].view(B, N)
     pnp = pin.numpy()
     nchunk = int(os.environ.get("A3T_COLLATE_CHUNKS", "1"))   # measured (tools/collate_time.py): 1 chunk 6.1 ms, 2: 6.6, 4: 6.9, 8: 8.4 -- the memcpy is 1.3 ms
     chunk = max(1, (B + nchunk - 1) // nchunk)
@@ -272,6 +275,7 @@ def _collate_device_pipeline(self, ds, slen):
         flens.append(fl)
     self._pin_ev = torch.cuda.Event()
     self._pin_ev.record()
+    # (every chunk is padded to the batch-wide N above, so all chunks have the same frame width)
     feats = torch.cat(feats, 0) if len(feats) > 1 else feats[0]
     flen = torch.cat(flens, 0)
     text = pad_list([d["text"] for d in ds], self.int_pad_value)

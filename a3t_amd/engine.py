@@ -47,11 +47,36 @@ def shared_stream(dev, kind, high=False):
     (GPU_MAX_HW_QUEUES, 4 by default) round-robin: a process that builds a second engine / trainer with streams of its own
     gets a main and a side stream on the SAME hardware queue sooner or later and the two-stream schedule silently runs as
     one (bench.py's configs[3] leg, the third trainer of its process: 84 ms per step instead of 66)."""
-    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), kind)
+    idx = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    key = (idx, kind)
     if key not in _STREAMS:
-        pr = torch.cuda.Stream.priority_range()[1] if high else 0
-        _STREAMS[key] = torch.cuda.Stream(device=dev, priority=pr)
+        cus = int(os.environ.get("A3T_%s_CUS" % kind.upper(), "0"))
+        if cus > 0:
+            _STREAMS[key] = _cu_masked_stream(idx, cus)
+        else:
+            pr = torch.cuda.Stream.priority_range()[1] if high else 0
+            _STREAMS[key] = torch.cuda.Stream(device=dev, priority=pr)
     return _STREAMS[key]
+
+
+def _cu_masked_stream(idx, cus):
+    """A HIP stream whose kernels may only be placed on `cus` of the chip's compute units (hipExtStreamCreateWithCUMask):
+    A3T_SIDE_CUS / A3T_SIDE2_CUS give the weight-gradient streams a partition of the chip instead of every wave slot, so
+    that a main-stream row kernel that becomes eligible in the middle of a 1000-workgroup weight-gradient burst finds free
+    CUs.  The driver spreads the mask bits round-robin over the XCDs: the lowest n bits are n / 8 CUs of every XCD."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    total = torch.cuda.get_device_properties(idx).multi_processor_count
+    cus = max(8, min(cus, total))
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for b in range(cus):
+        mask[b // 32] |= 1 << (b % 32)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(idx):
+        if hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask) != 0:
+            raise RuntimeError("hipExtStreamCreateWithCUMask failed")
+    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
 
 
 class _FastEvent:
@@ -63,17 +88,26 @@ class _FastEvent:
     _pools = {}        # device -> [events, next]: an event belongs to the device that was current when it was created
 
     @classmethod
-    def get(cls):
+    def create(cls):
+        """A fresh event that belongs to its caller (never handed out again)."""
         import ctypes
         if cls._hip is None:
             cls._hip = ctypes.CDLL("libamdhip64.so")
+        h = ctypes.c_void_p()
+        if cls._hip.hipEventCreateWithFlags(ctypes.byref(h), ctypes.c_uint(0x2 | 0x20000000)) != 0:
+            raise RuntimeError("hipEventCreateWithFlags failed")
+        e = cls.__new__(cls)
+        e.h = h
+        return e
+
+    @classmethod
+    def get(cls):
+        """An event from the per-device ring, for hand-overs that are recorded and waited for back to back (a wait captures
+        the record that precedes it, so re-recording a ring event later is safe).  Anything a holder keeps across other
+        hand-overs must NOT come from here (MLMEngine._owned_event): 1024 later get() calls would re-record it."""
         pool = cls._pools.setdefault(torch.cuda.current_device(), [[], 0])
-        if len(pool[0]) < 1024:            # ring of events: a wait captures the record that precedes it, so re-recording is safe
-            h = ctypes.c_void_p()
-            if cls._hip.hipEventCreateWithFlags(ctypes.byref(h), ctypes.c_uint(0x2 | 0x20000000)) != 0:
-                raise RuntimeError("hipEventCreateWithFlags failed")
-            e = cls.__new__(cls)
-            e.h = h
+        if len(pool[0]) < 1024:
+            e = cls.create()
             pool[0].append(e)
             return e
         pool[1] = (pool[1] + 1) % len(pool[0])
@@ -102,11 +136,11 @@ class _TorchEvent:
         stream.wait_event(self.e)
 
 
-def _new_event():
+def _new_event(owned=False):
     global _FAST_EVENTS
     if _FAST_EVENTS:
         try:
-            return _FastEvent.get()
+            return _FastEvent.create() if owned else _FastEvent.get()
         except (OSError, RuntimeError):          # no libamdhip64 by that name: torch's events do the same job
             _FAST_EVENTS = False
     return _TorchEvent()
@@ -135,14 +169,6 @@ class Workspace:
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
-
-
-# measurement only (tools/step_ab.sh): what the FFN weight gradients cost inside the two-stream step -- the step WITHOUT them
-# (wrong gradients, never set in production) bounds what any faster weight-gradient kernel can buy
-_SKIP_FFN_WGRAD = os.environ.get("A3T_EXPERIMENT_SKIP_FFN_WGRAD", "0") == "1"
-# the same kind of bound for a fused attention backward: 1 = the step without dprobs GEMM, softmax backward and the dQu GEMM
-# (what a query-pass kernel reading the saved probabilities would replace), 2 = without the first two only
-_SKIP_ATTN_BWD_MAIN = int(os.environ.get("A3T_EXPERIMENT_SKIP_ATTN_BWD", "0"))
 
 
 class MLMEngine:
@@ -176,6 +202,7 @@ class MLMEngine:
             # queued behind the weight gradients they would hand the main stream the whole backlog to wait for
             self.side2 = (shared_stream(self.dev, "side2", high=True)
                           if os.environ.get("A3T_SIDE2", "1") != "0" else self.side)
+        self._owned = {}       # events a holder keeps across other hand-overs: one per role, owned by this engine
         self._par = 0
         self._depth = max(2, int(os.environ.get("A3T_SIDE_DEPTH", "48")))   # scratch sets the main stream may run ahead by
         self._side_ev = [None] * self._depth
@@ -302,9 +329,9 @@ class MLMEngine:
             transposed()
             return
         ops.cast_bf16(flat[:split], flat16[:split])
-        self._cast_ev = self._side(lambda: ops.cast_bf16(flat[split:], flat16[split:]), want_event=True)
+        self._cast_ev = self._side(lambda: ops.cast_bf16(flat[split:], flat16[split:]), want_event="cast")
         if wt:
-            self._wt_ev = self._side(transposed, want_event=True)
+            self._wt_ev = self._side(transposed, want_event="wt")
 
     def _wait_cast(self, which):
         ev = getattr(self, which, None)
@@ -486,10 +513,18 @@ class MLMEngine:
             ev.wait_on(torch.cuda.current_stream())
             self._side_ev[self._par] = None
 
+    def _owned_event(self, key):
+        """The engine's own event for one long-lived role (scratch-set slot, weight casts, positional projections): held from
+        its record to a wait that may come a whole backward later, so it cannot be a ring event (_FastEvent.get)."""
+        ev = self._owned.get(key)
+        if ev is None:
+            ev = self._owned[key] = _new_event(owned=True)
+        return ev
+
     def _sub_end(self):
         if self.side is not None:
             self._side_flush()
-            ev = _new_event()
+            ev = self._owned_event(("slot", self._par))
             ev.record(self.side)
             self._side_ev[self._par] = ev
 
@@ -521,8 +556,8 @@ class MLMEngine:
         with torch.cuda.stream(st):
             ev.wait_on(st)
             fn()
-            if want_event:
-                done = _new_event()
+            if want_event:     # True: waited for inside the same sub-layer (ring event); a key: kept by the caller (owned event)
+                done = _new_event() if want_event is True else self._owned_event(("side", want_event))
                 done.record()
                 return done
         return None
@@ -582,8 +617,7 @@ class MLMEngine:
         self._sub_begin()
         g16 = self._g16(g)
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".b2"], 0.5)
-        if not _SKIP_FFN_WGRAD:
-            self._side(lambda: ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp))
+        self._side(lambda: ops.conv_bwd_weight(ga, h, gr[pre + ".w2"], T, pad, alpha=0.5, compute=self.cmp))
         dh = self._act(self._t("tmp.dh"), (M, c.ff))
         # (without dropout b2's gradient = 0.5*colsum(g) was accumulated by the LayerNorm backward that
         #  produced g; the dropout on h folds into the relu mask S=h>0 and the 1/(1-p) factor)
@@ -598,8 +632,7 @@ class MLMEngine:
         else:
             ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=a_dh,
                               compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
-        if not _SKIP_FFN_WGRAD:
-            self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp), late=True)
+        self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp), late=True)
         dy = self._act("tmp.dy", (M, c.adim))
         if self._ffn_plan(M)[1]:
             ops.conv_fwd(dh, self._wt["w1"][2][pre + ".w1"], dy, T, c.ff_kernel - 1 - pad, compute=self.cmp)
@@ -751,9 +784,8 @@ class MLMEngine:
         if not ds_fused:
             dpr = self.ws.get("tmp.ac", (B, H, T, T), sdt)      # reuse the score buffers
             # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
-            if not _SKIP_ATTN_BWD_MAIN:
-                ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
-                         b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
+            ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk),
+                     b_bs=(T * 3 * d, dk), c_bs=zb, compute=cmp)
         # dV[b,h] = probs[b,h]^T dctx[b,:,h,:]
         fz = self.bf16   # bias / pos-bias gradients ride on the GEMM epilogues as column sums
         gbq = gr[pre + ".bqkv"]
@@ -785,11 +817,10 @@ class MLMEngine:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
         if ds_fused:
-            if not _SKIP_ATTN_BWD_MAIN:
-                delta = self.ws.get("tmp.attn.delta", (B, H, T))
-                ops.attn_delta(dctx, ctx, delta, B, H, T)
-                ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0), dbd_head_major=hm)
-        elif not _SKIP_ATTN_BWD_MAIN:
+            delta = self.ws.get("tmp.attn.delta", (B, H, T))
+            ops.attn_delta(dctx, ctx, delta, B, H, T)
+            ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0), dbd_head_major=hm)
+        else:
             ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
                                    drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0, rowscale=rs)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
@@ -810,9 +841,8 @@ class MLMEngine:
         dqu = self._act("tmp.dqu", (M, d))
         dqv = self._act("tmp.dqv", (M, d))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
-        if _SKIP_ATTN_BWD_MAIN != 1:
-            ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
-                     b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=sl if fz else None, **csk)
+        ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
+                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=sl if fz else None, **csk)
         dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
                                               a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
                                               colsum=sl[2 * d:] if fz else None, **csk), want_event=True, urgent=True)
@@ -1009,8 +1039,8 @@ class MLMEngine:
                         ops.linear_fwd(posx, self.W(tag + ".wpos"), P, compute=self.cmp)
                         self._P_ahead[tag] = P
                 return run
-            ev_e = self._side(project("enc", pos_e, c.enc_blocks), want_event=True)
-            ev_d = self._side(project("dec", pos_d, c.dec_blocks), want_event=True)     # (behind the decoder-side weight cast)
+            ev_e = self._side(project("enc", pos_e, c.enc_blocks), want_event="pos.enc")
+            ev_d = self._side(project("dec", pos_d, c.dec_blocks), want_event="pos.dec")     # (behind the decoder-side weight cast)
             self._pos_ev = {"enc": ev_e, "dec": ev_d}
         x = xs
         for i in range(c.enc_blocks):

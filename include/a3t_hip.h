@@ -212,7 +212,12 @@ int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprob
  *   columns h*dk .. h*dk+dk-1 of every operand;  keymask uint8 [B][T];  ctx out [B*T][ldo] (bf16);
  *   lse out [B][H][T] fp32: log sum_j exp(scaled score) per query (+inf for a fully masked row), kept for backward.
  * drop_p / drop_key: attention dropout with the same counter RNG and element index ((b*H+h)*T+i)*T+j as
- * a3t_relpos_softmax_fwd's probs_drop.  dk in {32, 64, 96, 128, 192}, T % 8 == 0; A3T_EINVAL otherwise. */
+ * a3t_relpos_softmax_fwd's probs_drop.  dk in {32, 64, 96, 128, 192}, T % 8 == 0; A3T_EINVAL otherwise.
+ * STREAM CONTRACT (a3t_attn_fwd, a3t_attn_fwd_train, a3t_attn_split_mode): the overflow ("redo") flags and the key-split
+ * partial-sum workspace are ONE set per device, and the workspace is (re)allocated with hipMalloc when a launch needs more
+ * than any launch before it.  All fused-attention forward launches on a device must therefore be issued on one stream, or
+ * be ordered by the caller (event / stream wait) so that no two of them are in flight at once; launches on different
+ * DEVICES are independent.  Every other entry point of this header keeps no state between calls. */
 int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos, const uint8_t* keymask,
                  void* ctx, float* lse, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo,
                  float scale, float drop_p, uint32_t drop_key, void* stream);
