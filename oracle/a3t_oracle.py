@@ -435,6 +435,10 @@ def attention(x, pos, mask, p, pre, c: A3TConfig, return_probs=False):
     ac = torch.matmul(qu, k.transpose(-2, -1))
     bd = rel_shift_legacy(torch.matmul(qv, pp.transpose(-2, -1)))
     scores = (ac + bd) / math.sqrt(dk)
+    if scores.dtype == torch.bfloat16:
+        # only under torch.autocast("cpu", bfloat16) (the bf16 yardstick of the tests): bf16 logits, fp32 softmax -- the same
+        # promotion tests/golden/make_golden.py::gen_bf16ref applies to the reference, whose attention.py:81 cannot take bf16
+        scores = scores.float()
     m = mask.unsqueeze(1).eq(0)
     min_value = float(np.finfo(np.float32).min) if scores.dtype == torch.float32 else float(np.finfo(np.float64).min)
     scores = scores.masked_fill(m, min_value)
