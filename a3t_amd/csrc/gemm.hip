@@ -466,6 +466,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.drop_inv = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 0.f;
     p.keep_out = (unsigned char*)d->keep_out, p.keep_in = (const unsigned char*)d->keep_in;
     p.a_bytes = p.b_bytes = 0;
+    p.slab = nullptr;
     p.ln_g = d->ln_gamma, p.ln_b = d->ln_beta, p.ln_y = d->ln_y, p.ln_mean = d->ln_mean, p.ln_rstd = d->ln_rstd;
     p.ln_eps = d->ln_eps, p.ln_y_dtype = d->ln_y_dtype;
     if (p.ln_y && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16 || !p.ln_g || !p.ln_b || !p.ln_mean ||

@@ -667,6 +667,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
     WAIT_VM(0);
 
     // ---- epilogue: lane (g, pp) holds rows a*128 + wr*64 + i*16 + g*4 + r, column hb*128 + wc*32 + j*16 + pp
+    if (p.slab) {
+        // split-K partial of this (tile, K split): the accumulators go out as they lie in the registers -- 16 bytes per lane and
+        // fragment, 1 KiB contiguous per wave instruction (tn_slab_index) -- and gemm_8p_tn_fold_kernel sums the splits of a tile
+        // in a fixed order.  (As fp32 atomics straight into C the same 64 values per lane are 64 instructions of 256 scattered
+        // bytes each and resolve at the memory side: 48 us for 240 workgroups against 5 us of stores, tools/probes/atomic_epilogue.hip.)
+        float* slab = p.slab + ((int64_t)ks * p.ntiles + bid) * 65536 + (w * 64 + lane) * 4;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (tm * 256 + a * 128 >= p.M) continue;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (tn * 256 + b * 128 >= p.N) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        *(f32x4*)(slab + ((((a * 2 + b) * 4 + i) * 2 + j) * 2048)) = acc[a][b][i][j];
+            }
+        }
+        return;
+    }
     float* C = (float*)p.C;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -696,6 +717,312 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(3);
 #endif
+}
+
+
+// =====================================================================================================================
+// TN3 variant (round 5): the same token reduction on a 128 x 384 tile = ONE A half x THREE B halves, three phases per K-tile.
+// Every weight gradient of the model has a 384-multiple of input channels per tap (d_model = 384, ff = 1536 = 4 x 384), so
+// 128 x 384 tiles cover dW exactly: 1536 x (3 x 384) and 384 x (3 x 1536) are 36 full tiles each, where 256 x 256 tiles fill
+// 0.90 / 0.75 of their 30 / 36 tiles; the Linear weight gradients (N = 384) are one tile wide.  The A fragments (64 rows per wave,
+// the larger operand) are read once per K-tile and stay in registers for the three B halves: 20 KiB of LDS reads per wave and
+// K-tile for 64 x 96 outputs (the 2 x 2 tile: 24 KiB for 128 x 64).
+//   phase 1 of K-tile t: read B0 + A0 | DMA B1(t+1),          vmcnt(8)  -> B1(t) landed        | A0 x B0
+//   phase 2:             read B1      | DMA B2(t+1), B0(t+2), vmcnt(10) -> B2(t) landed        | A0 x B1
+//   phase 3:             read B2      | DMA A0(t+2),          vmcnt(8)  -> B0, A0(t+1) landed  | A0 x B2
+//   One counted wait per phase, each retiring exactly the half that is read in the NEXT phase and was requested three (B0: four)
+//   phases earlier; four to five half-tiles stay in flight across every barrier.  (A first version waited once per K-tile with
+//   vmcnt(4): that wait also retired B1 / B2 of tile t+1, requested one and two phases earlier -- their L2 latency was exposed in
+//   every K-tile: 138 us per FFN weight gradient against the figure in DESIGN.md.)
+// Restaging distances: B0 one phase after its reads (retired by the lgkmcnt in front of phase 1's first barrier), A0 / B1 / B2
+// two phases after theirs -- the rules of the 2 x 2 kernel above.  Epilogue: split-K partial tile by plain stores (slab).
+template <bool WG>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    enum { H3A = 0, H3B0 = 1, H3B1 = 2, H3B2 = 3 };
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    int wi = blockIdx.x;
+    {   // slice-major, XCD-contiguous: the tiles of one K split (same operand slabs) stay inside one XCD's L2
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
+        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
+    }
+    const int bid = wi % p.ntiles, ks = wi / p.ntiles;
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int nkt = (p.K + 63) >> 6;
+    int per = (nkt + p.splitk - 1) / p.splitk;
+    per += per & 1;
+    const int kt0 = ks * per;
+    if (kt0 >= nkt) return;                       // (the host folds only the splits that have K-tiles)
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+
+    // ---- DMA lane geometry (as the 2 x 2 kernel): instruction (half, q) fills k-rows (q*8 + w)*4 + (lane>>4), chunk position lane&15
+    const int krl = w * 4 + (lane >> 4);
+    const int sc = (lane & 15) ^ (((lane >> 4) << 2) | (((w >> 1) & 1) << 1));
+    const unsigned a_csb = (unsigned)p.a_cs * 2u, b_csb = (unsigned)p.b_cs * 2u;
+    const int mA = tm * 128 + sc * 8;
+    const unsigned voffA = (unsigned)krl * a_csb + (unsigned)mA * 2u;
+    const int cin = WG ? p.N / p.taps : p.N;
+    int shiftB[3], c0B[3];
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+        const int n0 = tn * 384 + h * 128;
+        const int tap = WG ? n0 / cin : 0;
+        shiftB[h] = WG ? (tap - p.pad) * p.dil : 0;
+        c0B[h] = n0 - tap * cin;
+    }
+    const unsigned voffB = (unsigned)krl * b_csb + (unsigned)(sc * 16);
+    int tpos = 0;
+    if (WG) {
+        const int t0 = (kt0 * 64 + krl) % p.Tseq, t1 = (kt0 * 64 + krl + 32) % p.Tseq;
+        tpos = t0 | (t1 << 16);
+    }
+    int c_kt = kt0;
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++c_kt;
+        if (WG) {
+            int t0 = (tpos & 0xffff) + 64, t1 = (tpos >> 16) + 64;
+            if (p.Tseq >= 64) {
+                t0 = t0 >= p.Tseq ? t0 - p.Tseq : t0, t1 = t1 >= p.Tseq ? t1 - p.Tseq : t1;
+            } else {
+                t0 %= p.Tseq, t1 %= p.Tseq;
+            }
+            tpos = t0 | (t1 << 16);
+        }
+    };
+    // kt / tp: K-tile and token positions the half belongs to (the B1 / B2 halves of K-tile t+1 are requested after the cursor
+    // has moved on to t+2 for B0: the caller hands in the values it saved)
+    auto issue = [&](const int H, const int buf, const int kt, const int tp) __attribute__((always_inline)) {
+        int wv = w;
+        unsigned acs = a_csb, bcs = b_csb;
+        asm volatile("" : "+s"(wv), "+s"(acs), "+s"(bcs));
+        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + wv * 1024;
+        const int krem = p.K - kt * 64 - krl;
+        if (H == H3A) {
+            const bool colok = mA < p.M;
+            const unsigned so = (unsigned)kt * 64u * acs;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned vb = voffA + (unsigned)(q * 32) * acs;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_AS(dst + q * 8192), 16, (colok && krem > q * 32) ? vb : OOB, so, 0, 0);
+            }
+        } else {
+            const int h = H - 1;
+            const bool colok = tn * 384 + h * 128 + sc * 8 < p.N;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int t = q ? (tp >> 16) : (tp & 0xffff);
+                const bool ok = colok && (krem > q * 32) && (!WG || ((unsigned)(t + shiftB[h]) < (unsigned)p.Tseq));
+                const unsigned vb = voffB + (unsigned)(kt * 64 + q * 32 + shiftB[h]) * bcs + (unsigned)(c0B[h] * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_AS(dst + q * 8192), 16, ok ? vb : OOB, 0, 0, 0);
+            }
+        }
+    };
+
+    const int g = lane >> 4, pp = lane & 15;
+    const unsigned swz = (unsigned)(((pp >> 2) << 2) | ((g & 1) << 1));
+    const unsigned kbyte = (unsigned)(g * 8 + (pp >> 2)) * 256u + (unsigned)(pp & 1) * 8u;
+    unsigned offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offA[i] = kbyte + ((((unsigned)(wr * 8 + i * 2) + (unsigned)((pp & 3) >> 1)) ^ swz) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) offB[j] = kbyte + ((((unsigned)(wc * 4 + j * 2) + (unsigned)((pp & 3) >> 1)) ^ swz) << 4);
+    auto frag = [&](const unsigned char* img, unsigned off, int s) __attribute__((always_inline)) -> bf16x8 {
+        const unsigned char* a0 = img + off + s * 8192;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_AS(a0 + 1024));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    f32x4 acc[3][4][2];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 fa[4][2], fb[2][2][2];        // fb[parity]: the B fragments of a phase are read while the previous phase's are in use
+    auto readA = [&](const unsigned char* img, const int i0, const int i1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i) fa[i][0] = frag(img, offA[i], 0), fa[i][1] = frag(img, offA[i], 1);
+    };
+    auto readB = [&](const unsigned char* img, bf16x8(&f)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f[j][0] = frag(img, offB[j], 0), f[j][1] = frag(img, offB[j], 1);
+    };
+    auto quad = [&](const int hb, const bf16x8(&f)[2][2]) __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[hb][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][s], f[j][s], acc[hb][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // K-tile kt0 -> buffer 0 (all four halves), B0 / A0 of K-tile kt0 + 1 -> buffer 1
+    issue(H3B0, 0, c_kt, tpos), issue(H3A, 0, c_kt, tpos), issue(H3B1, 0, c_kt, tpos), issue(H3B2, 0, c_kt, tpos);
+    advance();
+    issue(H3B0, 1, c_kt, tpos), issue(H3A, 1, c_kt, tpos);
+    WAIT_VM(4);
+    BAR();
+    if (wr == 1) BAR();
+
+    auto ktile = [&](const int buf) __attribute__((always_inline)) {
+        const unsigned char* cur = smem + buf * TILE_BYTES;
+        // at entry the cursor (c_kt, tpos) is K-tile t+1, whose B0 / A0 are in flight or landed in buf ^ 1
+        const int kt1 = c_kt, tp1 = tpos;
+        // phase 1: A0 x B0
+        readB(cur + H3B0 * HALF_BYTES, fb[0]);
+        SB();
+        readA(cur + H3A * HALF_BYTES, 0, 2);
+        WAIT_LGKM(8);                    // the B0 reads (issued first) are retired before the barrier: B0 is restaged in phase 2
+        SB();
+        readA(cur + H3A * HALF_BYTES, 2, 4);
+        issue(H3B1, buf ^ 1, kt1, tp1);
+        WAIT_VM(8);                      // retires B1 of the current tile (requested 3 phases ago, read in phase 2)
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(0, fb[0]);
+        BAR();
+        // phase 2: A0 x B1
+        readB(cur + H3B1 * HALF_BYTES, fb[1]);
+        issue(H3B2, buf ^ 1, kt1, tp1);
+        advance();
+        issue(H3B0, buf, c_kt, tpos);
+        WAIT_VM(10);                     // retires B2 of the current tile (requested 3 phases ago, read in phase 3)
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(1, fb[1]);
+        BAR();
+        // phase 3: A0 x B2
+        readB(cur + H3B2 * HALF_BYTES, fb[0]);
+        issue(H3A, buf, c_kt, tpos);
+        WAIT_VM(8);                      // retires B0 / A0 of the next tile (requested 4 / 3 phases ago)
+        BAR();
+        WAIT_LGKM(0);
+        SB();
+        quad(2, fb[0]);
+        BAR();
+    };
+    for (int u = 0; u < per; u += 2) {
+        ktile(0);
+        ktile(1);
+    }
+    if (wr == 0) BAR();
+    WAIT_VM(0);
+
+    // ---- epilogue: lane (g, pp) holds rows wr*64 + i*16 + g*4 + r, column b*128 + wc*32 + j*16 + pp of the tile
+    float* slab = p.slab + ((int64_t)ks * p.ntiles + bid) * 49152 + (w * 64 + lane) * 4;
+    if (tm * 128 >= p.M) return;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (tn * 384 + b * 128 >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *(f32x4*)(slab + (((b * 4 + i) * 2 + j) * 2048)) = acc[b][i][j];
+    }
+}
+
+// Fold of the TN3 kernel's partial tiles (128 x 384, 12288 16-byte pieces per tile).
+__global__ __launch_bounds__(256) void gemm_8p_tn3_fold_kernel(GP p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int bid = blockIdx.y;
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int lane = t & 63, w = (t >> 6) & 7, q = t >> 9;
+    const int j = q & 1, i = (q >> 1) & 3, b = q >> 3;
+    const int wr = w >> 2, wc = w & 3, g = lane >> 4, pp = lane & 15;
+    const int m = tm * 128 + wr * 64 + i * 16 + g * 4;
+    const int n = tn * 384 + b * 128 + wc * 32 + j * 16 + pp;
+    if (tn * 384 + b * 128 >= p.N || n >= p.N || m >= p.M) return;
+    const float* s = p.slab + (int64_t)bid * 49152 + (int64_t)t * 4;
+    const int64_t sstride = (int64_t)p.ntiles * 49152;
+    f32x4 v = *(const f32x4*)s;
+    for (int k = 1; k < p.splitk; ++k) {
+        const f32x4 u = *(const f32x4*)(s + k * sstride);
+        v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+    }
+    float* C = (float*)p.C + (int64_t)m * p.c_rs + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (m + r >= p.M) break;
+        const float x = p.alpha * v[r];
+        if (p.accumulate == A3T_ACC_ATOMIC)
+            atomicAdd(C + (int64_t)r * p.c_rs, x);
+        else if (p.accumulate == A3T_ACC_ADD)
+            C[(int64_t)r * p.c_rs] += x;
+        else
+            C[(int64_t)r * p.c_rs] = x;
+    }
+}
+
+
+// Fold of the split-K partial tiles written by gemm_bf16_8p_tn_kernel: C (+)= alpha * sum_s slab[s][tile], splits summed in
+// ascending order (deterministic).  One thread per 16-byte fragment piece: rows m..m+3 of one column.
+__global__ __launch_bounds__(256) void gemm_8p_tn_fold_kernel(GP p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;            // 16384 pieces per tile
+    const int bid = blockIdx.y;
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    const int lane = t & 63, w = (t >> 6) & 7, q = t >> 9;
+    const int j = q & 1, i = (q >> 1) & 3, b = (q >> 3) & 1, a = q >> 4;
+    const int wr = w >> 2, wc = w & 3, g = lane >> 4, pp = lane & 15;
+    const int m = tm * 256 + a * 128 + wr * 64 + i * 16 + g * 4;
+    const int n = tn * 256 + b * 128 + wc * 32 + j * 16 + pp;
+    if (tm * 256 + a * 128 >= p.M || tn * 256 + b * 128 >= p.N) return;        // (never written)
+    const float* s = p.slab + (int64_t)bid * 65536 + (int64_t)t * 4;
+    const int64_t sstride = (int64_t)p.ntiles * 65536;
+    f32x4 v = *(const f32x4*)s;
+    for (int k = 1; k < p.splitk; ++k) {
+        const f32x4 u = *(const f32x4*)(s + k * sstride);
+        v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
+    }
+    if (n >= p.N) return;
+    float* C = (float*)p.C + (int64_t)m * p.c_rs + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (m + r >= p.M) break;
+        const float x = p.alpha * v[r];
+        if (p.accumulate == A3T_ACC_ATOMIC)
+            atomicAdd(C + (int64_t)r * p.c_rs, x);
+        else if (p.accumulate == A3T_ACC_ADD)
+            C[(int64_t)r * p.c_rs] += x;
+        else
+            C[(int64_t)r * p.c_rs] = x;
+    }
+}
+
+// Split-K partial workspace: one per (device, stream) -- a launch and its fold are ordered on their stream, launches on
+// different streams must not share slabs.  Grow-only (hipMalloc on first use / growth; a few launches during warm-up).
+#include <map>
+#include <mutex>
+static float* g8_slab(hipStream_t stream, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> ws;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& e = ws[{dev, stream}];
+    if (e.second < bytes) {
+        if (e.first) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(e.first);
+        }
+        e.first = nullptr, e.second = 0;
+        if (hipMalloc((void**)&e.first, bytes) != hipSuccess) return nullptr;
+        e.second = bytes;
+    }
+    return e.first;
 }
 
 static int g8_cus() {          // per device (a process may drive several GPUs)
@@ -792,6 +1119,59 @@ static void launch_8p_tn(const GP& pv, int grid, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_bf16_8p_tn_kernel<WGF>), dim3(grid), dim3(512), 2 * TILE_BYTES, stream, pv);
 }
 
+template <bool WGF>
+static void launch_8p_tn3(const GP& pv, int grid, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_8p_tn3_kernel<WGF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES);
+    hipLaunchKernelGGL((gemm_bf16_8p_tn3_kernel<WGF>), dim3(grid), dim3(512), 2 * TILE_BYTES, stream, pv);
+}
+
+// 128 x 384 tiles (gemm_bf16_8p_tn3_kernel): -1 = not applicable / not chosen.  A3T_GEMM_8P_TN3 = 0 never, 1 whenever legal,
+// 2 (default) when the tiles fit the output exactly enough and there is enough K per workgroup.
+static int g_tn3_mode = -1;
+static int tn3_mode() {
+    if (g_tn3_mode < 0) {
+        const char* e = getenv("A3T_GEMM_8P_TN3");
+        g_tn3_mode = e ? atoi(e) : 2;
+    }
+    return g_tn3_mode;
+}
+extern "C" int a3t_gemm_tn3_mode(int mode) {
+    const int old = tn3_mode();
+    g_tn3_mode = mode;
+    return old;
+}
+static int gemm_8p_tn3(const GP& p, hipStream_t stream, int64_t a_bytes, int64_t b_bytes) {
+    const int on = tn3_mode();
+    if (on == 0) return -1;
+    const long tm = (p.M + 127) / 128, tn = (p.N + 383) / 384, tiles = tm * tn;
+    const int cus = g8_cus(), nkt = (p.K + 63) / 64;
+    int splits = (int)(cus / tiles);
+    if (splits < 1) splits = 1;
+    if (splits > nkt / 16) splits = nkt / 16 > 0 ? nkt / 16 : 1;       // >= 16 K-tiles per workgroup
+    if (on == 2) {
+        const double fill = (double)p.M * p.N / ((double)tm * 128 * tn * 384);
+        if (fill < 0.85 || tiles * splits < 96) return -1;
+    }
+    int per = (nkt + splits - 1) / splits;
+    per += per & 1;
+    GP pv = p;
+    pv.tiles_n = (int)tn, pv.ntiles = (int)tiles, pv.splitk = splits;
+    pv.a_bytes = (unsigned)a_bytes, pv.b_bytes = (unsigned)b_bytes;
+    pv.slab = g8_slab(stream, (size_t)tiles * splits * 49152 * sizeof(float));
+    if (!pv.slab) return (int)hipErrorOutOfMemory;
+    const bool wg = p.taps > 1;
+    const int grid = (int)(tiles * splits);
+    if (wg)
+        launch_8p_tn3<true>(pv, grid, stream);
+    else
+        launch_8p_tn3<false>(pv, grid, stream);
+    GP pf = pv;
+    pf.splitk = (nkt + per - 1) / per;
+    hipLaunchKernelGGL(gemm_8p_tn3_fold_kernel, dim3(48, (unsigned)tiles), dim3(256), 0, stream, pf);
+    a3t_note_kernel("gemm_bf16_8p_tn3_kernel<%s>", wg ? "true" : "false");
+    return (int)hipGetLastError();
+}
+
 // weight gradients: reduction-strided operands, K (tokens) split over workgroups
 static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
     // Its K loop runs 1.55 us per K-tile (1.39 PFLOP/s) but the ~240 workgroups of a split-K grid finish together and their
@@ -814,6 +1194,10 @@ static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
     if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return -1;
     const int64_t a_bytes = (int64_t)p.K * p.a_cs * 2, b_bytes = (int64_t)p.K * p.b_cs * 2;
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || p.a_cs % 8 || p.b_cs % 8) return -1;
+    {
+        const int r3 = gemm_8p_tn3(p, stream, a_bytes, b_bytes);
+        if (r3 != -1) return r3;
+    }
     const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn;
     const int cus = g8_cus(), nkt = (p.K + 63) / 64;
     int splits = (int)(cus / tiles);
@@ -830,11 +1214,28 @@ static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
     GP pv = p;
     pv.tiles_n = (int)tn, pv.ntiles = (int)tiles, pv.splitk = splits;
     pv.a_bytes = (unsigned)a_bytes, pv.b_bytes = (unsigned)b_bytes;
+    pv.slab = nullptr;
+    static int slab_on = -1;
+    if (slab_on < 0) {
+        const char* e = getenv("A3T_GEMM_8P_TN_SLAB");       // 0: fp32 atomics straight from the accumulators (rounds 3-4)
+        slab_on = e ? atoi(e) : 1;
+    }
+    if (splits > 1 && slab_on) {
+        pv.slab = g8_slab(stream, (size_t)tiles * splits * 65536 * sizeof(float));
+        if (!pv.slab) return (int)hipErrorOutOfMemory;
+    }
     const int grid = (int)(tiles * splits);
     if (wg)
         launch_8p_tn<true>(pv, grid, stream);
     else
         launch_8p_tn<false>(pv, grid, stream);
+    if (pv.slab) {
+        int per = (nkt + splits - 1) / splits;       // as the kernel computes it: splits past the last K-tile write nothing
+        per += per & 1;
+        GP pf = pv;
+        pf.splitk = (nkt + per - 1) / per;
+        hipLaunchKernelGGL(gemm_8p_tn_fold_kernel, dim3(64, (unsigned)tiles), dim3(256), 0, stream, pf);
+    }
     a3t_note_kernel("gemm_bf16_8p_tn_kernel<%s>", wg ? "true" : "false");
     return (int)hipGetLastError();
 }

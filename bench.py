@@ -25,6 +25,7 @@ import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # TFLOP/s dense, MI355X_MICROARCH.md
 HBM_PEAK = 8000.0                            # GB/s
+TRAFFIC_FILE = "r05_hbm_traffic_per_kernel.json"   # this round's PMC summary (tools/r05_profiles.sh)
 
 
 def fwd_flops_per_step(c, B, Tm, Tp):
@@ -363,6 +364,7 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--fake-cpu", action="store_true", help="N-rank launch-path test on gloo/CPU (no kernels)")
     ap.add_argument("--comm-dtype", default="f32", choices=["f32", "bf16"], help="gradient all-reduce bucket dtype")
+    ap.add_argument("--strict-traffic", action="store_true", help="exit instead of reporting traffic = null when this round's PMC file is missing")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -523,20 +525,31 @@ def main():
         name, (fl, tt, n) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = fl / tt / 1e12
         peak = MFMA_PEAK["bf16" if "bf16" in name else "f32"]
+        # HBM traffic of that kernel: ONLY from THIS round's PMC passes of this command (tools/r05_profiles.sh -> separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 for gfx950); no silent fall-back to an older round's file
         traffic, traffic_source = None, None
-        for tf in ("r04_hbm_traffic_per_kernel.json", "r03_hbm_traffic_per_kernel.json", "r02_hbm_traffic_per_kernel.json", "r01_hbm_traffic_per_kernel.json"):
-            tfp = os.path.join(ROOT, "profiles", tf)                # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-            if os.path.exists(tfp) and traffic is None:
-                for k, v in json.load(open(tfp)).items():
-                    if name in k:
-                        traffic = v["hbm_bytes_per_launch"]
-                        traffic_source = ("profiles/" + tf + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                          "command, FETCH_SIZE x2 for gfx950; a tracked file, not measured in this run)")
-        # algorithmic bytes of one launch of that kernel (every operand read once, output written / atomically updated once
-        # per K-split): averaged over its launches of the profiled step
-        alg = [2.0 * (K_ * M_ + K_ * (N_ // max(tp_, 1)) if "<2," in nm else M_ * K_ // max(tp_, 1) + N_ * K_) * b_
-               + (4.0 * M_ * N_ * b_ * sk_ if "<2," in nm else 2.0 * M_ * N_ * b_)
-               for nm, _f, _e0, _e1, (M_, N_, K_, b_, tp_, sk_) in prof_rows if nm == name]
+        tfp = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+        if os.path.exists(tfp):
+            for k, v in json.load(open(tfp)).items():
+                if name in k:
+                    traffic = v["hbm_bytes_per_launch"]
+                    traffic_source = ("profiles/" + TRAFFIC_FILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command, FETCH_SIZE x2 for gfx950; a tracked file, not measured in this run)")
+        if traffic is None:
+            traffic_source = (f"MISSING: profiles/{TRAFFIC_FILE} has no entry for {name} -- run tools/r05_profiles.sh on the GPU box and "
+                              "commit its output; traffic is null, not borrowed from an older round")
+            print("[bench] WARNING: " + traffic_source, file=sys.stderr, flush=True)
+            if a.strict_traffic:
+                raise SystemExit(traffic_source)
+
+        # algorithmic bytes of one launch of that kernel = the SINGLE-PASS minimum: every operand read once (the taps of a conv
+        # share their rows), the output written once (a K split adds nothing); averaged over its launches of the profiled step
+        def alg_bytes(nm, M_, N_, K_, b_, tp_):
+            tp_ = max(tp_, 1)
+            if "<2," in nm or "_tn_" in nm or "_tn3_" in nm:     # token reduction: dy [K][M] + x [K][N / taps] in bf16, dW [M][N] fp32
+                return b_ * (2.0 * K_ * M_ + 2.0 * K_ * (N_ // tp_) + 4.0 * M_ * N_)
+            return b_ * (2.0 * M_ * (K_ // tp_) + 2.0 * N_ * K_ + 2.0 * M_ * N_)
+        alg = [alg_bytes(nm, M_, N_, K_, b_, tp_) for nm, _f, _e0, _e1, (M_, N_, K_, b_, tp_, sk_) in prof_rows if nm == name]
         traffic_alg = sum(alg) / len(alg) if alg else None
         fa, ta, na = alone.get(name, (fl, tt, n))
         # per-class table of the conv-FFN GEMMs (75 % of the FLOPs), from the one-stream pass: forward / data gradient /
@@ -546,7 +559,7 @@ def main():
         for nm, fl_, e0_, e1_, (M_, N_, K_, b_, tp_, sk_) in alone_rows:
             if tp_ != cfg.ff_kernel or b_ != 1 or (N_, K_) not in fwd_shapes and (M_, N_) not in wg_shapes:
                 continue
-            is_wg = sk_ > 1 or "<2," in nm or "_tn_" in nm
+            is_wg = sk_ > 1 or "<2," in nm or "_tn_" in nm or "_tn3_" in nm
             seen_wgrad = seen_wgrad or is_wg
             cls = "wgrad" if is_wg else ("dgrad" if seen_wgrad else "fwd")
             c_ = classes.setdefault(cls, [0, 0.0, 0.0])

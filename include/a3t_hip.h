@@ -10,8 +10,12 @@
  *
  * Conventions
  *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted.
- *   - `stream` is a hipStream_t passed as void*.  Launches are stream-ordered, no allocation,
- *     no host sync, no global mutable state (thread-compatible).
+ *   - `stream` is a hipStream_t passed as void*.  Launches are stream-ordered and do not sync the host.  The caller owns
+ *     every buffer; the library keeps exactly three pieces of state of its own, all grow-only and allocated on first use
+ *     (hipMalloc during warm-up, never in steady state): the kernel-selection modes (a3t_gemm_*_mode, a3t_attn_split_mode:
+ *     process-wide switches for tests / A-B runs), the per-DEVICE key-split workspace + overflow flags of the fused attention
+ *     forward (stream contract at a3t_attn_fwd), and the per-(device, STREAM) split-K partial slab of the weight-gradient
+ *     kernel (a launch and its fold are ordered on their stream; different streams never share a slab).
  *   - every function returns 0 on success or a hipError_t / negative A3T_E* code.
  *   - activations are row-major (rows = tokens m = b*T + t, cols = channels), fp32 unless a
  *     dtype field says otherwise.
@@ -382,6 +386,11 @@ const char* a3t_gemm_last_kernel(void);
 int a3t_gemm_8p_mode(int mode);
 /* The same switch for the 384-column panel GEMM (A3T_GEMM_PN). */
 int a3t_gemm_pn_mode(int mode);
+/* Weight gradients (token reductions, multi_layer_conv.py:52-63 / torch.nn.Linear backward): 0 = never use the 128 x 384-tile
+ * 8-phase kernel with the deterministic split-K fold, 1 = whenever the descriptor is legal for it, 2 (default) = when its tiles
+ * cover the output to >= 85 % and the launch has >= 96 workgroups, -1 = re-read A3T_GEMM_8P_TN3.  Returns the previous mode.
+ * (a3t_gemm_8p_mode(0) switches it off together with every other 8-phase kernel.) */
+int a3t_gemm_tn3_mode(int mode);
 /* Fused attention forward (a3t_attn_fwd, a3t_attn_fwd_train): 1 (default) = when the last round of 128-query blocks would fill at
  * most half of the chip, those blocks run as a launch of their own, split into 2..4 key ranges whose partial sums a small kernel
  * folds (attention.py:64-96 is associative in the keys once every range uses the block's one reference maximum); 0 = one

@@ -792,3 +792,62 @@ def test_dropout_masks_of_two_keys_are_not_shifted_copies_of_each_other():
     worst = max(worst_dev(ms[i], ms[j])[0] for i, j in ((0, 1), (0, 2), (1, 2)))
     print(f"engine keys: largest deviation of mask agreement from chance: {worst:.4f}")
     assert worst < 5e-3
+
+
+def test_tn3_weight_gradient_kernel_and_its_deterministic_fold():
+    """Round 5: the 128 x 384-tile token-reduction kernel (gemm_bf16_8p_tn3_kernel) with split-K partials folded in a fixed order
+    (no atomics).  Every weight-gradient shape family of the model -- fused Conv1d gradients whose 384-column tile lies in one tap
+    (cin = 384, 1536), spans taps (cin = 128, 512) or is cut by N (cin = 128 x 3 taps = one tile; N = 256, 640), row tails
+    (cout = 136, 200, 264), token counts that are no multiple of the 64-token K-tile or of the utterance length -- against fp32
+    torch math and the 128 x 128 kernel; run twice: bit-identical (the atomics of the kernels it replaces are not); store /
+    add / atomic accumulation modes."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import ACC_ATOMIC, BF16
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    old8, old3 = lib.a3t_gemm_8p_mode(1), lib.a3t_gemm_tn3_mode(1)
+    try:
+        for (B, T, cin, cout, taps) in [(3, 200, 128, 512, 3), (5, 1120, 384, 1536, 3), (5, 1120, 1536, 384, 3), (4, 264, 256, 264, 1),
+                                        (2, 1800, 512, 2048, 3), (7, 333, 384, 384, 1), (3, 77, 128, 136, 3), (9, 1120, 640, 200, 1)]:
+            M = B * T
+            dy, x = rn(M, cout).bfloat16(), rn(M, cin).bfloat16()
+
+            def run(mode8, base=None):
+                lib.a3t_gemm_8p_mode(mode8)
+                dW = (torch.zeros(cout, taps, cin, device=DEV) if taps > 1 else torch.zeros(cout, cin, device=DEV)) if base is None else base.clone()
+                if taps > 1:
+                    ops.conv_bwd_weight(dy, x, dW, T, 1, alpha=0.5, compute=BF16)
+                else:
+                    ops.linear_bwd_weight(dy, x, dW, alpha=0.5, compute=BF16)
+                return dW, lib.a3t_gemm_last_kernel().decode()
+            d128, k128 = run(0)
+            d3, k3 = run(1)
+            d3b, _ = run(1)
+            base = rn(*d3.shape)
+            d3acc, _ = run(1, base)
+            torch.cuda.synchronize()
+            assert "8p_tn3" in k3 and "8p" not in k128, (k3, k128)
+            assert torch.equal(d3, d3b), "the fold sums the K splits in a fixed order"
+            if taps > 1:
+                xs, dyf = x.float().view(B, T, cin), dy.float().view(B, T, cout)
+                ref = torch.zeros(cout, taps, cin, device=DEV)
+                for t in range(taps):
+                    xsft = torch.zeros_like(xs)
+                    sh = t - 1
+                    if sh < 0:
+                        xsft[:, -sh:] = xs[:, :sh]
+                    elif sh > 0:
+                        xsft[:, :-sh] = xs[:, sh:]
+                    else:
+                        xsft = xs
+                    ref[:, t, :] = 0.5 * torch.einsum("btn,btc->nc", dyf, xsft)
+            else:
+                ref = 0.5 * dy.float().t() @ x.float()
+            sc = float(ref.abs().max())
+            assert float((d3 - ref).abs().max()) / sc < 1e-4 and float((d128 - ref).abs().max()) / sc < 1e-4
+            assert float((d3acc - (base + ref)).abs().max()) / sc < 1e-4        # accumulates onto what the buffer holds
+    finally:
+        lib.a3t_gemm_8p_mode(old8)
+        lib.a3t_gemm_tn3_mode(old3)

@@ -17,7 +17,9 @@ def timeit(fn, n=50):
     return e0.elapsed_time(e1) / n * 1e3
 
 bad = 0
-for (B, T, cin, cout, taps) in [(3, 200, 128, 512, 3), (5, 1120, 384, 1536, 3), (5, 1120, 1536, 384, 3), (4, 264, 256, 264, 1), (4, 1000, 384, 1152, 1)]:
+for (B, T, cin, cout, taps) in [(3, 200, 128, 512, 3), (5, 1120, 384, 1536, 3), (5, 1120, 1536, 384, 3), (4, 264, 256, 264, 1), (4, 1000, 384, 1152, 1),
+                               (2, 1800, 512, 2048, 3), (2, 1800, 2048, 512, 3), (7, 333, 384, 384, 1), (6, 520, 384, 768, 1), (3, 77, 128, 136, 3),
+                               (9, 1120, 640, 200, 1)]:
     M = B * T
     dy, x = rn(M, cout).bfloat16(), rn(M, cin).bfloat16()
     outs = []
@@ -48,23 +50,32 @@ for (B, T, cin, cout, taps) in [(3, 200, 128, 512, 3), (5, 1120, 384, 1536, 3), 
         ref = 0.5 * dy.float().t() @ x.float()
     e0 = float((outs[0][0] - ref).abs().max() / ref.abs().max())
     e1 = float((outs[1][0] - ref).abs().max() / ref.abs().max())
-    ok = "8p_tn" in outs[1][1] and e1 < 2e-3
+    ok = "8p_tn" in outs[1][1] and e1 < 2e-3 and e1 < 4 * e0 + 1e-6
     bad += not ok
     print(f"wgrad B={B} T={T} {cin}->{cout} taps={taps}: {outs[1][1]} err {e1:.2e} (128^2: {e0:.2e}) {'ok' if ok else 'FAIL'}")
 
 if len(sys.argv) < 2:
     B, T = 32, 1120
     M = B * T
+    NSET = 4          # operand sets in rotation: 4 x (dy + x) exceeds the 256 MiB Infinity Cache for the FFN shapes ("cold" = as inside the step)
     for (cin, cout, taps) in [(384, 1536, 3), (1536, 384, 3), (384, 1152, 1), (384, 384, 1), (384, 768, 1)]:
-        dy, x = rn(M, cout).bfloat16(), rn(M, cin).bfloat16()
+        sets = [(rn(M, cout).bfloat16(), rn(M, cin).bfloat16()) for _ in range(NSET)]
         dW = torch.zeros(cout, taps, cin, device=DEV) if taps > 1 else torch.zeros(cout, cin, device=DEV)
         fl = 2.0 * M * cout * cin * taps
         res = []
         for mode in (0, 1):
             lib.a3t_gemm_8p_mode(mode)
-            f = (lambda: ops.conv_bwd_weight(dy, x, dW, T, 1, compute=BF16)) if taps > 1 else (lambda: ops.linear_bwd_weight(dy, x, dW, compute=BF16))
-            t = timeit(f)
-            res.append(f"{lib.a3t_gemm_last_kernel().decode()} {t:.1f} us ({fl / t / 1e6:.0f} TF)")
+            for cold in (0, 1):
+                it = [0]
+                def f():
+                    dy, x = sets[it[0] % NSET if cold else 0]
+                    it[0] += 1
+                    if taps > 1:
+                        ops.conv_bwd_weight(dy, x, dW, T, 1, compute=BF16)
+                    else:
+                        ops.linear_bwd_weight(dy, x, dW, compute=BF16)
+                t = timeit(f)
+                res.append(f"{lib.a3t_gemm_last_kernel().decode()} {'cold' if cold else 'warm'} {t:.1f} us ({fl / t / 1e6:.0f} TF)")
         lib.a3t_gemm_8p_mode(2)
         print(f"wgrad {cin}->{cout} taps={taps}: " + " | ".join(res))
 print("FAILED" if bad else "all ok")
