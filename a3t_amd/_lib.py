@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("A3T_LIB_PATH") or os.path.join(HERE, "lib", "liba3t_h
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SWISH = 0, 1, 2, 3
-ACC_STORE, ACC_ADD, ACC_ATOMIC = 0, 1, 2
+ACC_STORE, ACC_ADD, ACC_ATOMIC, ACC_SOLE = 0, 1, 2, 3
 
 
 class GemmDesc(ctypes.Structure):
@@ -106,6 +106,7 @@ _SIGS = {
     "a3t_gemm_8p_supported": [c_int, c_int, c_int, c_int, c_int],
     "a3t_gemm_pn_mode": [c_int],
     "a3t_gemm_tn3_mode": [c_int],
+    "a3t_gemm_tn3_group": [_P, c_int, _P],
     "a3t_attn_split_mode": [c_int],
     "a3t_gemm_pn_supported": [c_int, c_int, c_int, c_int, c_int],
     "a3t_dropout_bwd_cast": [_P, _P, c_int, _P, c_float, c_int, c_int, c_float, ctypes.c_uint32, _P],

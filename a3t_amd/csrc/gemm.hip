@@ -453,6 +453,8 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.kshift_mode = (p.taps == 1 && d->Tseq > 0) ? 1 : 0;
     if (p.taps > 1 && p.Tseq <= 0) return A3T_EINVAL;
     p.alpha = d->alpha, p.act = d->act, p.accumulate = d->accumulate;
+    p.sole_writer = 0;
+    if (p.accumulate == A3T_ACC_SOLE) p.accumulate = A3T_ACC_ATOMIC, p.sole_writer = 1;
     p.splitk = d->splitk < 1 ? 1 : d->splitk;
     if (p.splitk > 1 && p.accumulate != A3T_ACC_ATOMIC) return A3T_EINVAL;
     p.c_dtype = d->c_dtype;

@@ -720,6 +720,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
 }
 
 
+// Several token reductions over the SAME tokens in one launch (a3t_gemm_tn3_group): problem i owns tiles [tile0, next tile0) of
+// every K split.  Passed by value beside GP; n == 0: the single problem described by GP.
+struct TN3Prob {
+    const void* A;
+    const void* B;
+    float* C;
+    int64_t c_rs;
+    int M, N;
+    unsigned a_csb, b_csb;      // operand row strides in bytes
+    unsigned a_bytes, b_bytes;
+    float alpha;
+    int accumulate, tile0, tiles_n;
+};
+struct TN3Group {
+    int n;
+    TN3Prob q[8];
+};
+
 // =====================================================================================================================
 // TN3 variant (round 5): the same token reduction on a 128 x 384 tile = ONE A half x THREE B halves, three phases per K-tile.
 // Every weight gradient of the model has a 384-multiple of input channels per tap (d_model = 384, ff = 1536 = 4 x 384), so
@@ -737,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
 // Restaging distances: B0 one phase after its reads (retired by the lgkmcnt in front of phase 1's first barrier), A0 / B1 / B2
 // two phases after theirs -- the rules of the 2 x 2 kernel above.  Epilogue: split-K partial tile by plain stores (slab).
 template <bool WG>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p, TN3Group grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -751,23 +769,35 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p) {
         wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
     const int bid = wi % p.ntiles, ks = wi / p.ntiles;
-    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    // the problem this tile belongs to (uniform): a group member or GP itself
+    const void* Ap = p.A;
+    const void* Bp = p.B;
+    int Mp = p.M, Np = p.N, tiles_n = p.tiles_n, lbid = bid;
+    unsigned a_csb = (unsigned)p.a_cs * 2u, b_csb = (unsigned)p.b_cs * 2u, a_bytes = p.a_bytes, b_bytes = p.b_bytes;
+    if (grp.n > 0) {
+        int k = 0;
+        for (int i = 1; i < grp.n; ++i)
+            if (bid >= grp.q[i].tile0) k = i;
+        Ap = grp.q[k].A, Bp = grp.q[k].B, Mp = grp.q[k].M, Np = grp.q[k].N, tiles_n = grp.q[k].tiles_n;
+        a_csb = grp.q[k].a_csb, b_csb = grp.q[k].b_csb, a_bytes = grp.q[k].a_bytes, b_bytes = grp.q[k].b_bytes;
+        lbid = bid - grp.q[k].tile0;
+    }
+    const int tn = lbid % tiles_n, tm = lbid / tiles_n;
     const int nkt = (p.K + 63) >> 6;
     int per = (nkt + p.splitk - 1) / p.splitk;
     per += per & 1;
     const int kt0 = ks * per;
     if (kt0 >= nkt) return;                       // (the host folds only the splits that have K-tiles)
 
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Ap, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bp, 0, (int)b_bytes, 0x00020000);
 
     // ---- DMA lane geometry (as the 2 x 2 kernel): instruction (half, q) fills k-rows (q*8 + w)*4 + (lane>>4), chunk position lane&15
     const int krl = w * 4 + (lane >> 4);
     const int sc = (lane & 15) ^ (((lane >> 4) << 2) | (((w >> 1) & 1) << 1));
-    const unsigned a_csb = (unsigned)p.a_cs * 2u, b_csb = (unsigned)p.b_cs * 2u;
     const int mA = tm * 128 + sc * 8;
     const unsigned voffA = (unsigned)krl * a_csb + (unsigned)mA * 2u;
-    const int cin = WG ? p.N / p.taps : p.N;
+    const int cin = WG ? Np / p.taps : Np;
     int shiftB[3], c0B[3];
 #pragma unroll
     for (int h = 0; h < 3; ++h) {
@@ -804,7 +834,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p) {
         unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + wv * 1024;
         const int krem = p.K - kt * 64 - krl;
         if (H == H3A) {
-            const bool colok = mA < p.M;
+            const bool colok = mA < Mp;
             const unsigned so = (unsigned)kt * 64u * acs;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -813,7 +843,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p) {
             }
         } else {
             const int h = H - 1;
-            const bool colok = tn * 384 + h * 128 + sc * 8 < p.N;
+            const bool colok = tn * 384 + h * 128 + sc * 8 < Np;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int t = q ? (tp >> 16) : (tp & 0xffff);
@@ -924,10 +954,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p) {
 
     // ---- epilogue: lane (g, pp) holds rows wr*64 + i*16 + g*4 + r, column b*128 + wc*32 + j*16 + pp of the tile
     float* slab = p.slab + ((int64_t)ks * p.ntiles + bid) * 49152 + (w * 64 + lane) * 4;
-    if (tm * 128 >= p.M) return;
+    if (tm * 128 >= Mp) return;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-        if (tn * 384 + b * 128 >= p.N) continue;
+        if (tn * 384 + b * 128 >= Np) continue;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -936,37 +966,55 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p) {
 }
 
 // Fold of the TN3 kernel's partial tiles (128 x 384, 12288 16-byte pieces per tile).
-__global__ __launch_bounds__(256) void gemm_8p_tn3_fold_kernel(GP p) {
+__global__ __launch_bounds__(256) void gemm_8p_tn3_fold_kernel(GP p, TN3Group grp) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int bid = blockIdx.y;
-    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
+    float* Cp = (float*)p.C;
+    int64_t c_rs = p.c_rs;
+    int Mp = p.M, Np = p.N, tiles_n = p.tiles_n, lbid = bid, accumulate = (p.accumulate == A3T_ACC_ATOMIC && p.sole_writer) ? A3T_ACC_ADD : p.accumulate;
+    float alpha = p.alpha;
+    if (grp.n > 0) {
+        int k = 0;
+        for (int i = 1; i < grp.n; ++i)
+            if (bid >= grp.q[i].tile0) k = i;
+        Cp = grp.q[k].C, c_rs = grp.q[k].c_rs, Mp = grp.q[k].M, Np = grp.q[k].N, tiles_n = grp.q[k].tiles_n;
+        accumulate = grp.q[k].accumulate, alpha = grp.q[k].alpha, lbid = bid - grp.q[k].tile0;       // (SOLE arrives as ADD)
+    }
+    const int tn = lbid % tiles_n, tm = lbid / tiles_n;
     const int lane = t & 63, w = (t >> 6) & 7, q = t >> 9;
     const int j = q & 1, i = (q >> 1) & 3, b = q >> 3;
     const int wr = w >> 2, wc = w & 3, g = lane >> 4, pp = lane & 15;
     const int m = tm * 128 + wr * 64 + i * 16 + g * 4;
     const int n = tn * 384 + b * 128 + wc * 32 + j * 16 + pp;
-    if (tn * 384 + b * 128 >= p.N || n >= p.N || m >= p.M) return;
+    if (tn * 384 + b * 128 >= Np || n >= Np || m >= Mp) return;
     const float* s = p.slab + (int64_t)bid * 49152 + (int64_t)t * 4;
     const int64_t sstride = (int64_t)p.ntiles * 49152;
+    // splits in ascending order, four loads in flight at a time (a fixed order: the result does not depend on the launch)
     f32x4 v = *(const f32x4*)s;
-    for (int k = 1; k < p.splitk; ++k) {
+    int k = 1;
+    for (; k + 4 <= p.splitk; k += 4) {
+        const f32x4 u0 = *(const f32x4*)(s + (k + 0) * sstride), u1 = *(const f32x4*)(s + (k + 1) * sstride);
+        const f32x4 u2 = *(const f32x4*)(s + (k + 2) * sstride), u3 = *(const f32x4*)(s + (k + 3) * sstride);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (((v[r] + u0[r]) + u1[r]) + u2[r]) + u3[r];
+    }
+    for (; k < p.splitk; ++k) {
         const f32x4 u = *(const f32x4*)(s + k * sstride);
         v[0] += u[0], v[1] += u[1], v[2] += u[2], v[3] += u[3];
     }
-    float* C = (float*)p.C + (int64_t)m * p.c_rs + n;
+    float* C = Cp + (int64_t)m * c_rs + n;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (m + r >= p.M) break;
-        const float x = p.alpha * v[r];
-        if (p.accumulate == A3T_ACC_ATOMIC)
-            atomicAdd(C + (int64_t)r * p.c_rs, x);
-        else if (p.accumulate == A3T_ACC_ADD)
-            C[(int64_t)r * p.c_rs] += x;
+        if (m + r >= Mp) break;
+        const float x = alpha * v[r];
+        if (accumulate == A3T_ACC_ATOMIC)
+            atomicAdd(C + (int64_t)r * c_rs, x);
+        else if (accumulate == A3T_ACC_ADD)
+            C[(int64_t)r * c_rs] += x;
         else
-            C[(int64_t)r * p.c_rs] = x;
+            C[(int64_t)r * c_rs] = x;
     }
 }
-
 
 // Fold of the split-K partial tiles written by gemm_bf16_8p_tn_kernel: C (+)= alpha * sum_s slab[s][tile], splits summed in
 // ascending order (deterministic).  One thread per 16-byte fragment piece: rows m..m+3 of one column.
@@ -993,9 +1041,9 @@ __global__ __launch_bounds__(256) void gemm_8p_tn_fold_kernel(GP p) {
     for (int r = 0; r < 4; ++r) {
         if (m + r >= p.M) break;
         const float x = p.alpha * v[r];
-        if (p.accumulate == A3T_ACC_ATOMIC)
+        if (p.accumulate == A3T_ACC_ATOMIC && !p.sole_writer)
             atomicAdd(C + (int64_t)r * p.c_rs, x);
-        else if (p.accumulate == A3T_ACC_ADD)
+        else if (p.accumulate != A3T_ACC_STORE)
             C[(int64_t)r * p.c_rs] += x;
         else
             C[(int64_t)r * p.c_rs] = x;
@@ -1120,9 +1168,9 @@ static void launch_8p_tn(const GP& pv, int grid, hipStream_t stream) {
 }
 
 template <bool WGF>
-static void launch_8p_tn3(const GP& pv, int grid, hipStream_t stream) {
+static void launch_8p_tn3(const GP& pv, const TN3Group& grp, int grid, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_8p_tn3_kernel<WGF>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE_BYTES);
-    hipLaunchKernelGGL((gemm_bf16_8p_tn3_kernel<WGF>), dim3(grid), dim3(512), 2 * TILE_BYTES, stream, pv);
+    hipLaunchKernelGGL((gemm_bf16_8p_tn3_kernel<WGF>), dim3(grid), dim3(512), 2 * TILE_BYTES, stream, pv, grp);
 }
 
 // 128 x 384 tiles (gemm_bf16_8p_tn3_kernel): -1 = not applicable / not chosen.  A3T_GEMM_8P_TN3 = 0 never, 1 whenever legal,
@@ -1161,14 +1209,66 @@ static int gemm_8p_tn3(const GP& p, hipStream_t stream, int64_t a_bytes, int64_t
     if (!pv.slab) return (int)hipErrorOutOfMemory;
     const bool wg = p.taps > 1;
     const int grid = (int)(tiles * splits);
+    TN3Group none = {};
     if (wg)
-        launch_8p_tn3<true>(pv, grid, stream);
+        launch_8p_tn3<true>(pv, none, grid, stream);
     else
-        launch_8p_tn3<false>(pv, grid, stream);
+        launch_8p_tn3<false>(pv, none, grid, stream);
     GP pf = pv;
     pf.splitk = (nkt + per - 1) / per;
-    hipLaunchKernelGGL(gemm_8p_tn3_fold_kernel, dim3(48, (unsigned)tiles), dim3(256), 0, stream, pf);
+    hipLaunchKernelGGL(gemm_8p_tn3_fold_kernel, dim3(48, (unsigned)tiles), dim3(256), 0, stream, pf, none);
     a3t_note_kernel("gemm_bf16_8p_tn3_kernel<%s>", wg ? "true" : "false");
+    return (int)hipGetLastError();
+}
+
+// Several Linear weight gradients over the same tokens (dW_i[M_i][N_i] (+)= alpha_i * dy_i^T x_i, K tokens each) in ONE launch of
+// the 128 x 384-tile kernel: their tiles share the K splits, so the four small gradients of a Conformer block (linear_out,
+// linear_q/k/v, pointwise_conv1/2: 3 + 9 + 3 + 6 tiles) fill the chip with 47 K-tiles per workgroup instead of 16-20 each, and pay
+// one prologue / slab / fold instead of four.  Returns -1 when a member does not fit (the caller launches them one by one).
+extern "C" int a3t_gemm_tn3_group(const a3t_gemm_desc* d, int n, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || n < 1 || n > 8) return A3T_EINVAL;
+    if (g8_mode() == 0 || tn3_mode() == 0) return -1;
+    TN3Group grp = {};
+    grp.n = n;
+    long tiles = 0;
+    const int K = d[0].K;
+    for (int i = 0; i < n; ++i) {
+        const a3t_gemm_desc& e = d[i];
+        if (!e.A || !e.B || !e.C || e.M <= 0 || e.N <= 0 || e.K != K) return A3T_EINVAL;
+        if (e.compute != A3T_BF16 || e.a_dtype != A3T_BF16 || e.b_dtype != A3T_BF16 || e.c_dtype != A3T_F32) return -1;
+        if (e.a_rs != 1 || e.b_rs != 1 || e.taps > 1 || e.batch > 1 || e.Tseq > 0 || e.kshift) return -1;
+        if (e.bias || e.R || e.S || e.colsum || e.act != A3T_ACT_NONE || e.drop_p > 0.f || e.keep_in || e.keep_out || e.ln_y) return -1;
+        if (e.M % 8 || e.N % 8 || e.a_cs % 8 || e.b_cs % 8 || (((uintptr_t)e.A | (uintptr_t)e.B | (uintptr_t)e.C) & 15)) return -1;
+        const int64_t ab = (int64_t)K * e.a_cs * 2, bb = (int64_t)K * e.b_cs * 2;
+        if (ab >= (1ll << 31) || bb >= (1ll << 31)) return -1;
+        TN3Prob& q = grp.q[i];
+        q.A = e.A, q.B = e.B, q.C = (float*)e.C, q.c_rs = e.c_rs, q.M = e.M, q.N = e.N;
+        q.a_csb = (unsigned)(e.a_cs * 2), q.b_csb = (unsigned)(e.b_cs * 2), q.a_bytes = (unsigned)ab, q.b_bytes = (unsigned)bb;
+        q.alpha = e.alpha, q.accumulate = e.accumulate == A3T_ACC_SOLE ? A3T_ACC_ADD : e.accumulate;
+        q.tile0 = (int)tiles, q.tiles_n = (e.N + 383) / 384;
+        tiles += (long)((e.M + 127) / 128) * q.tiles_n;
+    }
+    if (tn3_mode() == 2) {       // partly empty 384-column tiles (input widths that are no multiple of 384) lose to the single launches
+        double out = 0.0;
+        for (int i = 0; i < n; ++i) out += (double)d[i].M * d[i].N;
+        if (out / ((double)tiles * 128 * 384) < 0.85) return -1;
+    }
+    const int cus = g8_cus(), nkt = (K + 63) / 64;
+    int splits = (int)(cus / tiles);
+    if (splits < 1) splits = 1;
+    if (splits > nkt / 16) splits = nkt / 16 > 0 ? nkt / 16 : 1;
+    int per = (nkt + splits - 1) / splits;
+    per += per & 1;
+    GP pv = {};
+    pv.K = K, pv.taps = 1, pv.Tseq = 1, pv.ntiles = (int)tiles, pv.splitk = splits, pv.tiles_n = 1;
+    pv.slab = g8_slab(stream, (size_t)tiles * splits * 49152 * sizeof(float));
+    if (!pv.slab) return (int)hipErrorOutOfMemory;
+    launch_8p_tn3<false>(pv, grp, (int)(tiles * splits), stream);
+    GP pf = pv;
+    pf.splitk = (nkt + per - 1) / per;
+    hipLaunchKernelGGL(gemm_8p_tn3_fold_kernel, dim3(48, (unsigned)tiles), dim3(256), 0, stream, pf, grp);
+    a3t_note_kernel("gemm_bf16_8p_tn3_kernel<false>");
     return (int)hipGetLastError();
 }
 
@@ -1194,23 +1294,28 @@ static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
     if (((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) & 15) return -1;
     const int64_t a_bytes = (int64_t)p.K * p.a_cs * 2, b_bytes = (int64_t)p.K * p.b_cs * 2;
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || p.a_cs % 8 || p.b_cs % 8) return -1;
-    {
-        const int r3 = gemm_8p_tn3(p, stream, a_bytes, b_bytes);
-        if (r3 != -1) return r3;
-    }
     const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256, tiles = tm * tn;
     const int cus = g8_cus(), nkt = (p.K + 63) / 64;
     int splits = (int)(cus / tiles);
     if (splits < 1) splits = 1;
     if (splits > nkt / 16) splits = nkt / 16 > 0 ? nkt / 16 : 1;       // >= 16 K-tiles per workgroup
-    if (splits > 1 && p.accumulate != A3T_ACC_ATOMIC) splits = 1;
+    // Which tile: 256 x 256 (four quadrants per K-tile, 1.55 us: the better K loop) when it covers the output exactly --
+    // configs[3]'s 2048 x 1536 / 512 x 6144: 67.97 ms per step against 68.70 on the 128 x 384 tile -- and 128 x 384 (three
+    // quadrants, 1.41 us, 176 registers: leaves the CU's other wave slots to the main stream's kernels) where 256 x 256 tiles
+    // would be partly empty -- configs[1]'s 1536 x 1152 / 384 x 4608 (fill 0.90 / 0.75): 43.2 ms per step against 44.6.
+    const double fill = (double)p.M * p.N / ((double)tm * 256 * tn * 256);
+    bool ok22 = true;
     if (mode == 2 && tn_on == 2) {
-        const double fill = (double)p.M * p.N / ((double)tm * 256 * tn * 256);
-        if (fill < 0.7 || tiles * splits < 160 || nkt / splits < 32) return -1;
-        const double t8 = (double)((nkt + splits - 1) / splits) * 1.55 + 35.0;      // us: K loop + the atomic burst
+        const double t8 = (double)((nkt + splits - 1) / splits) * 1.55 + 25.0;      // us: K loop + prologue, partial stores, fold
         const double t128 = 2.0 * p.M * p.N * (double)p.K / 680e6;                 // us at the 128x128 kernel's ~680 TFLOP/s
-        if (t8 > 0.7 * t128) return -1;
+        ok22 = !(fill < 0.7 || tiles * splits < 160 || nkt / splits < 32 || t8 > 0.7 * t128);
     }
+    const int t3 = tn3_mode();
+    if (t3 == 1 || (t3 == 2 && !(ok22 && fill >= 0.95))) {
+        const int r3 = gemm_8p_tn3(p, stream, a_bytes, b_bytes);
+        if (r3 != -1) return r3;
+    }
+    if (!ok22) return -1;
     GP pv = p;
     pv.tiles_n = (int)tn, pv.ntiles = (int)tiles, pv.splitk = splits;
     pv.a_bytes = (unsigned)a_bytes, pv.b_bytes = (unsigned)b_bytes;

@@ -36,6 +36,7 @@ struct GP {
     const unsigned char* keep_in;   // optional: keep bits applied as a mask (written by the GEMM with the same M x N tiling)
     unsigned int a_bytes, b_bytes;  // operand extents for the buffer descriptors
     float* slab;                    // token-reduction variant: split-K partial tiles (plain stores) for the deterministic fold
+    int sole_writer;                // A3T_ACC_SOLE: the fold may add with plain read-modify-writes
     // panel kernel (gemm_bf16_pn.hip), N == 384: LayerNorm of the finished output rows in the epilogue
     const float* ln_g;
     const float* ln_b;

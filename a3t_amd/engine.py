@@ -210,6 +210,10 @@ class MLMEngine:
         #  per GEMM -- 47.1 ms per step against 45.4: the weight gradients have to start as early as they can)
         self._side_defer = os.environ.get("A3T_SIDE_DEFER", "0") == "1"
         self._side_pending = []
+        # Linear weight gradients collected for one grouped launch (_lin_wgrad): 4 = one Conformer block's; needs the deep scratch ring
+        self._wg_group = 4 if (self.bf16 and self.side is not None and self._depth >= 8 and
+                               os.environ.get("A3T_WGRAD_GROUP", "1") != "0") else 1
+        self._wg_pending = []
         # (A3T_SIDE_LATE=1, experiment: 46.5 ms per step against 45.2 -- see _pre_ln)
         self._side_late = os.environ.get("A3T_SIDE_LATE", "0") == "1"
         self._gm_ready = None
@@ -237,9 +241,13 @@ class MLMEngine:
         self.attn_hm = os.environ.get("A3T_ATTN_DBD_HM", "0") == "1"
         self.attn_regen = os.environ.get("A3T_ATTN_REGEN_MASK", "1") != "0"
         # dS / dBD straight from the saved probabilities in one launch (a3t_attn_bwd_ds) instead of the dprobs GEMM + softmax
-        # backward: opt-in -- 177 us against 216 alone, but a persistent 79-KB-LDS kernel shares the chip with the weight-gradient
-        # stream worse than the pair it replaces (configs[1]: 46.7 ms per step against 46.2)
-        self.attn_bwd_ds = os.environ.get("A3T_ATTN_BWD_DS", "0") == "1"
+        # backward: dprobs is never stored.  Round 4: 177 us against 216 alone but +0.5 ms per step beside the 128x128 weight
+        # gradients (a persistent 79-KB-LDS kernel left them nothing).  Round 5, with the weight gradients on the 128x384-tile
+        # kernel: configs[1] (d_k = 192) 42.94 / 43.04 ms per step against 43.56 / 43.57 on one box -- default there.  configs[3]
+        # (d_k = 128, 2.6x the scores per layer for 2/3 of the product work per score): 68.70 against 67.51 -- the kernel is bound
+        # by score traffic, the GEMM it replaces shrinks with d_k: materialised pair there.  A3T_ATTN_BWD_DS=0 / 1: never / always.
+        ds_env = os.environ.get("A3T_ATTN_BWD_DS", "auto")
+        self.attn_bwd_ds = ds_env == "1" or (ds_env not in ("0", "1") and cfg.dk >= 160)
         # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
         # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
         # at the benchmark shape; whole eval forward 4.32 vs 4.74 ms at B = 8, 10.5 vs 11.3 ms at B = 32, 4+4 blocks), except
@@ -562,11 +570,31 @@ class MLMEngine:
                 return done
         return None
 
+    def _lin_wgrad(self, dy, x, dW, late=False):
+        """Weight gradient of a Linear (dW += dy^T x), off the main stream.  bf16 path: the Linear weight gradients of a block
+        (linear_out, linear_q/k/v, pointwise_conv2, pointwise_conv1 -- all reductions over the same tokens with 384 input
+        channels) are collected and handed over as ONE grouped launch (ops.linear_bwd_weight_group): they feed nothing until the
+        optimizer, their operands live in the scratch ring / the saved activations, and four of them fill the chip where each
+        alone has 16-20 K-tiles per workgroup.  A3T_WGRAD_GROUP=0: one launch each."""
+        if self._wg_group > 1:
+            self._wg_pending.append((dy, x, dW, 1.0))
+            if len(self._wg_pending) >= self._wg_group:
+                self._wg_flush()
+            return
+        self._side(lambda: ops.linear_bwd_weight(dy, x, dW, compute=self.cmp), late=late)
+
+    def _wg_flush(self):
+        items, self._wg_pending = self._wg_pending, []
+        if items:
+            cmp = self.cmp
+            self._side(lambda: ops.linear_bwd_weight_group(items, compute=cmp))
+
     def join_side(self):
         """Make the current stream wait for every weight gradient issued so far (for on_group_done hooks that read gradients)."""
         self._side_join()
 
     def _side_join(self):
+        self._wg_flush()
         if self.side is not None:
             self._side_flush()
             torch.cuda.current_stream().wait_stream(self.side)
@@ -585,6 +613,8 @@ class MLMEngine:
             # Measured: the LayerNorm backwards drop from 6.6 to 5.1 ms per step, but the late weight gradients then collide with
             # the next sub-layer's first GEMMs (+2.8 ms): off by default.
             self._side_flush()
+        if ga is g or ga is g16:
+            self._wg_flush()              # (collected Linear weight gradients read the gradient in place too)
         if self.side is not None and (ga is g or ga is g16):
             self._side_flush()
             torch.cuda.current_stream().wait_stream(self.side)
@@ -731,7 +761,7 @@ class MLMEngine:
         self._sub_begin()
         g16 = self._g16(g)
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".bo"], 1.0)
-        self._side(lambda: ops.linear_bwd_weight(ga, ctx, gr[pre + ".wo"], compute=cmp))
+        self._lin_wgrad(ga, ctx, gr[pre + ".wo"])
         dctx = self._act("tmp.dctx", (M, d))
         self._lin_dgrad(ga, pre + ".wo", dctx)
         kk = qkv.view(-1)[d:]
@@ -759,7 +789,7 @@ class MLMEngine:
                 ops.linear_bwd_weight(dP16, pos, gr[pre + ".wpos"], compute=cmp)
             self._side(pos_weight_grad_fused)
             ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gr[pre + ".u"], gr[pre + ".v"], gr[pre + ".bqkv"])
-            self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp), late=True)
+            self._lin_wgrad(dqkv, y, gr[pre + ".wqkv"], late=True)
             dy = self._act("tmp.dy", (M, d))
             self._lin_dgrad(dqkv, pre + ".wqkv", dy)
             self._pre_ln(ga, g, g16)
@@ -859,7 +889,7 @@ class MLMEngine:
             self._bias_grad(dqu, gr[pre + ".u"])
             self._bias_grad(dqv, gr[pre + ".v"])
             self._bias_grad(dqkv, gbq)
-        self._side(lambda: ops.linear_bwd_weight(dqkv, y, gr[pre + ".wqkv"], compute=cmp), late=True)
+        self._lin_wgrad(dqkv, y, gr[pre + ".wqkv"], late=True)
         dy = self._act("tmp.dy", (M, d))
         self._lin_dgrad(dqkv, pre + ".wqkv", dy)
         self._pre_ln(ga, g, g16)
@@ -916,7 +946,7 @@ class MLMEngine:
         self._sub_begin()
         g16 = self._g16(g)
         ga = self._gm(g, tag + ".o", c.dropout_rate, gr[pre + ".pb2"], 1.0)
-        self._side(lambda: ops.linear_bwd_weight(ga, s, gr[pre + ".pw2"], compute=cmp))
+        self._lin_wgrad(ga, s, gr[pre + ".pw2"])
         ds = self.ws.get("tmp.ds", (M, d))
         self._lin_dgrad(ga, pre + ".pw2", ds)
         dz = self.ws.get("tmp.dz", (M, d))
@@ -924,7 +954,7 @@ class MLMEngine:
         dg = self._act(self._t("tmp.dg"), (M, 2 * d))
         ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T,
                            dgsum=gr[pre + ".pb1"])
-        self._side(lambda: ops.linear_bwd_weight(dg, y, gr[pre + ".pw1"], compute=cmp), late=True)
+        self._lin_wgrad(dg, y, gr[pre + ".pw1"], late=True)
         dy = self._act("tmp.dy", (M, d))
         self._lin_dgrad(dg, pre + ".pw1", dy)
         self._pre_ln(ga, g, g16)

@@ -6,7 +6,7 @@ import os
 import torch
 
 from . import _lib as L
-from ._lib import ACC_ADD, ACC_ATOMIC, ACC_STORE, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
+from ._lib import ACC_ADD, ACC_ATOMIC, ACC_SOLE, ACC_STORE, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
 
 __all__ = ["gemm", "linear_fwd", "linear_bwd_data", "linear_bwd_weight", "conv_fwd", "conv_bwd_data",
            "conv_bwd_weight"]
@@ -110,8 +110,45 @@ def linear_bwd_weight(dy, x, dW, alpha=1.0, compute=F32):
     M, N = dy.shape
     K = x.shape[1]
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    gemm(dy, x, dW, N, K, M, 1, N, 1, K, K, alpha=alpha, acc=ACC_ATOMIC, splitk=_splitk_for(tiles, M),
+    # ACC_SOLE: a parameter gradient has one writer at a time -- kernels that fold split-K partials need no atomics for it
+    gemm(dy, x, dW, N, K, M, 1, N, 1, K, K, alpha=alpha, acc=ACC_SOLE, splitk=_splitk_for(tiles, M),
          compute=compute)
+
+
+def linear_bwd_weight_group(items, compute=F32):
+    """items = [(dy, x, dW, alpha), ...] over the same tokens: dW_i += alpha_i * dy_i^T @ x_i.  On the bf16 path all of them run
+    as ONE launch of the 128 x 384-tile token-reduction kernel (a3t_gemm_tn3_group); when the library declines (fp32 compute,
+    shapes outside the kernel's contract, kernel switched off) they are launched one by one."""
+    if compute == BF16 and len(items) > 1 and len(items) <= 8:
+        lib = L.load()
+        arr = (L.GemmDesc * len(items))()
+        for d, (dy, x, dW, alpha) in zip(arr, items):
+            M, N = dy.shape
+            K = x.shape[1]
+            d.A, d.B, d.C = dy.data_ptr(), x.data_ptr(), dW.data_ptr()
+            d.M, d.N, d.K = N, K, M
+            d.a_rs, d.a_cs, d.b_rs, d.b_cs, d.b_ts, d.c_rs = 1, N, 1, K, 0, K
+            d.batch, d.batch_inner, d.taps, d.dil = 1, 1, 1, 1
+            d.alpha, d.act, d.accumulate, d.splitk = alpha, ACT_NONE, ACC_SOLE, 1
+            d.a_dtype, d.b_dtype, d.c_dtype, d.compute, d.s_dtype = _dt(dy), _dt(x), _dt(dW), compute, F32
+            d.colsum_slots = 1
+        if PROFILE is not None:      # bench.py: one table row for the whole group
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = lib.a3t_gemm_tn3_group(ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
+        if rc == 0:
+            if PROFILE is not None:
+                e1.record()
+                tok, cin = items[0][0].shape[0], items[0][1].shape[1]
+                cout = sum(dy.shape[1] for dy, _, _, _ in items)
+                PROFILE.append((lib.a3t_gemm_last_kernel().decode() + f" x{len(items)} grouped", 2.0 * tok * cout * cin, e0, e1,
+                                (cout, cin, tok, 1, 1, 1)))
+            return True
+        if rc != -1:
+            L.check(rc, "a3t_gemm_tn3_group")
+    for dy, x, dW, alpha in items:
+        linear_bwd_weight(dy, x, dW, alpha=alpha, compute=compute)
+    return False
 
 
 # ---- Conv1d over time as implicit-im2col GEMM; weights kept as Wk[N][taps][Cin] --------------
@@ -184,7 +221,7 @@ def conv_bwd_weight(dy, x, dWk, Tseq, pad, dil=1, alpha=1.0, compute=F32):
         # one launch: output columns (tap, c); every 128-column tile carries its own token shift
         tiles = ((N + 127) // 128) * (taps * Cin // 128)
         gemm(dy, x, dWk, N, taps * Cin, M, 1, N, 1, Cin, taps * Cin, taps=taps, pad=pad, dil=dil, Tseq=Tseq,
-             alpha=alpha, acc=ACC_ATOMIC, splitk=_splitk_for(tiles, M), compute=compute)
+             alpha=alpha, acc=ACC_SOLE, splitk=_splitk_for(tiles, M), compute=compute)
         return
     tiles = ((N + 127) // 128) * ((Cin + 127) // 128)
     sk = _splitk_for(tiles, M)

@@ -41,6 +41,9 @@ extern "C" {
 #define A3T_ACC_STORE 0  /* C  = v           */
 #define A3T_ACC_ADD 1    /* C += v           */
 #define A3T_ACC_ATOMIC 2 /* atomicAdd(C, v)  */
+#define A3T_ACC_SOLE 3   /* C += v, K may be split; the caller guarantees that nothing else writes C while the launch runs (a
+                            parameter gradient has one writer per backward pass): kernels that fold split-K partials add them
+                            with plain read-modify-writes, kernels that accumulate in place use atomics as for A3T_ACC_ATOMIC */
 
 /* One descriptor drives every dense contraction on the path (torch.nn.Linear, Conv1d as
  * implicit-im2col GEMM, the attention bmm's and all their weight/data gradients):
@@ -57,7 +60,7 @@ extern "C" {
  *          (k % Tseq) + kshift is outside [0,Tseq)   (Conv1d weight gradient, one tap per launch)
  * One of a_rs/a_cs (and of b_rs/b_cs) must be 1.
  * Batching: z in [0,batch): z0 = z / batch_inner, z1 = z % batch_inner; X += z0*x_bs0 + z1*x_bs1.
- * splitk>1 splits K over extra workgroups; requires accumulate == A3T_ACC_ATOMIC.
+ * splitk>1 splits K over extra workgroups; requires accumulate == A3T_ACC_ATOMIC or A3T_ACC_SOLE.
  */
 typedef struct a3t_gemm_desc {
     const void* A;
@@ -391,6 +394,13 @@ int a3t_gemm_pn_mode(int mode);
  * cover the output to >= 85 % and the launch has >= 96 workgroups, -1 = re-read A3T_GEMM_8P_TN3.  Returns the previous mode.
  * (a3t_gemm_8p_mode(0) switches it off together with every other 8-phase kernel.) */
 int a3t_gemm_tn3_mode(int mode);
+/* n (1..8) Linear weight gradients over the SAME K tokens -- dW_i[M_i][N_i] (op_i)= alpha_i * dy_i^T x_i, descriptors as a3t_gemm
+ * takes them for a token reduction (a_rs == b_rs == 1, bf16 operands, fp32 C, taps <= 1, no epilogue options) -- in ONE launch of
+ * the 128 x 384-tile kernel + one fold: the four small gradients of a Conformer block (linear_out and linear_q/k/v of
+ * attention.py:40-96, pointwise_conv1/2 of convolution.py:56-79) share the K splits of one grid instead of paying four
+ * prologues / folds on 16-20 K-tiles each.  Returns 0, a hipError_t, A3T_EINVAL (bad arguments) or -1: a member does not meet
+ * the kernel's contract or the kernel is switched off -- nothing was launched, call a3t_gemm per member. */
+int a3t_gemm_tn3_group(const a3t_gemm_desc* d, int n, void* stream);
 /* Fused attention forward (a3t_attn_fwd, a3t_attn_fwd_train): 1 (default) = when the last round of 128-query blocks would fill at
  * most half of the chip, those blocks run as a launch of their own, split into 2..4 key ranges whose partial sums a small kernel
  * folds (attention.py:64-96 is associative in the keys once every range uses the block's one reference maximum); 0 = one

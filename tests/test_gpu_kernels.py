@@ -851,3 +851,45 @@ def test_tn3_weight_gradient_kernel_and_its_deterministic_fold():
     finally:
         lib.a3t_gemm_8p_mode(old8)
         lib.a3t_gemm_tn3_mode(old3)
+
+
+def test_grouped_linear_weight_gradients_equal_the_single_launches():
+    """a3t_gemm_tn3_group: the Linear weight gradients of a Conformer block (3 + 9 + 3 + 6 tiles of 128 x 384) in ONE launch of
+    the token-reduction kernel.  Same partial sums, same fold order as the single launches of the same kernel -> bit-identical to
+    them; against fp32 torch math 1e-4; accumulates onto what the buffers hold; a member outside the kernel's contract (fp32
+    operands) makes the library decline and the wrapper fall back to single launches."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import BF16
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(6)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    old8, old3 = lib.a3t_gemm_8p_mode(1), lib.a3t_gemm_tn3_mode(1)
+    try:
+        for M, couts in ((5 * 1120, (384, 1152, 384, 768)), (3 * 200, (136, 384)), (32 * 1120, (384, 1152, 384, 768))):
+            items = [(rn(M, co).bfloat16(), rn(M, 384).bfloat16(), rn(co, 384), 1.0 if i % 2 else 0.5) for i, co in enumerate(couts)]
+            base = [dW.clone() for _, _, dW, _ in items]
+            single = []
+            for (dy, x, _, al), b in zip(items, base):
+                dW = b.clone()
+                ops.linear_bwd_weight(dy, x, dW, alpha=al, compute=BF16)
+                assert "tn3" in lib.a3t_gemm_last_kernel().decode()
+                single.append(dW)
+            assert ops.linear_bwd_weight_group(items, compute=BF16) is True
+            torch.cuda.synchronize()
+            for (dy, x, dW, al), b, sg in zip(items, base, single):
+                ref = b + al * (dy.float().t() @ x.float())
+                assert float((dW - ref).abs().max() / ref.abs().max()) < 1e-4
+                assert torch.equal(dW, sg) or float((dW - sg).abs().max() / ref.abs().max()) < 2e-6   # (other K split count -> other rounding)
+        # a member the kernel does not take (132 output channels: not a multiple of 8): the wrapper reports the fall-back to single
+        # launches and the results are still right
+        its = [(rn(640, 384).bfloat16(), rn(640, 384).bfloat16(), torch.zeros(384, 384, device=DEV), 1.0),
+               (rn(640, 132).bfloat16(), rn(640, 384).bfloat16(), torch.zeros(132, 384, device=DEV), 1.0)]
+        assert ops.linear_bwd_weight_group(its, compute=BF16) is False
+        torch.cuda.synchronize()
+        for dy, x, dW, _ in its:
+            ref = dy.float().t() @ x.float()
+            assert float((dW - ref).abs().max() / ref.abs().max()) < 1e-4
+    finally:
+        lib.a3t_gemm_8p_mode(old8)
+        lib.a3t_gemm_tn3_mode(old3)
