@@ -67,9 +67,6 @@ _SIGS = {
     "a3t_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                      c_float, c_float, ctypes.c_uint32, _P],
     "a3t_attn_delta": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int64, _P],
-    "a3t_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64,
-                     c_int64, c_int64, c_int64, c_int64, c_float, c_float, ctypes.c_uint32, c_int, _P],
-    "a3t_attn_bwd_finish": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P],
     "a3t_pwg_block": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_mask_fill": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint32,

@@ -1260,12 +1260,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
 }
 
 // =====================================================================================================================
-// Backward.  Two passes that both recompute the probabilities from the saved log-sum-exp (two-pass flash backward):
-//   attn_bwd_q_kernel : query-block outer (lane = query).  dS^T per tile -> d(q+u) += dS K (registers), and through the
-//                       INVERSE skew (scatter dS into band coordinates in an LDS scratch) dBD band blocks ->
-//                       d(q+v) += dBD Pext (registers) and the compact dBD matrix for the d linear_pos GEMM.
-//   attn_bwd_kv_kernel: key-block outer (lane = key).  dV += Pd^T dO, dK += dS^T (q+u) (registers).
-// With dropout: Pd = P keep/(1-p), dP = (dO V^T) keep/(1-p), dS = P (dP - delta) scale, delta_i = dO_i . O_i.
+// Helpers of the backward.  (The two-pass flash backward of round 2 -- attn_bwd_q_kernel / attn_bwd_kv_kernel, recomputing the
+// probabilities from the saved log-sum-exp: 1.2 + 1.5 ms per layer against ~0.6 ms for the materialised path -- left the library
+// in round 5: tools/experiments/attn_flash_backward.patch.)
 // =====================================================================================================================
 #define GS_LD 72   // gradient scratch row stride in bf16 elements
 
@@ -1296,440 +1293,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const u16* __restrict__
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) delta[((int64_t)b * H + h) * T + i] = s;
-}
-
-template <int NDB>
-__global__ __launch_bounds__(256, 1) void attn_bwd_q_kernel(AttnArgs p) {
-    using TL = Tile<NDB>;
-    constexpr int DK = TL::DK, KS = DK / 16, RSB = TL::RSB, TB = TL::BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Kt = smem;
-    unsigned char* Vt = smem + TB;
-    unsigned char* Pr = smem + 2 * TB;                   // 6 ring slots (blocks s .. s+4 live at step s)
-    float* sc = (float*)(smem + 8 * TB);                 // band scratch  [4][32][SC_LD] fp32
-    u16* gs = (u16*)(smem + 8 * TB + 4 * 32 * SC_LD * 4);   // gradient scratch [4][32][GS_LD] bf16
-    unsigned int* kmw = (unsigned int*)(gs + 4 * 32 * GS_LD);
-
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = p.T, NQB = (T + 127) / 128, NS = (T + 31) / 32;
-    int wi = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
-        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
-    }
-    const int bh = wi / NQB, qb = wi - bh * NQB;
-    const int b = bh / p.H, h = bh - b * p.H;
-    const int Q0 = qb * 128, q0 = Q0 + 32 * w;
-    const int X0 = T - 32 - Q0;
-    const int i = q0 + lr;
-    const u16* quB = p.qu + (int64_t)b * T * p.ldq + h * DK;
-    const u16* qvB = p.qv + (int64_t)b * T * p.ldq + h * DK;
-    const u16* doB = p.dctx + (int64_t)b * T * p.ldo + h * DK;
-    const u16* kB = p.k + (int64_t)b * T * p.ldkv + h * DK;
-    const u16* vB = p.v + (int64_t)b * T * p.ldkv + h * DK;
-    const u16* pB = p.pos + h * DK;
-    const uint8_t* mkB = p.keymask + (int64_t)b * T;
-    float* scw = sc + w * 32 * SC_LD;
-    u16* gsw = gs + w * 32 * GS_LD;
-
-    auto prow = [&](int u, int r) -> int64_t {
-        const int x = X0 + 32 * (u - 3) + r;
-        if (x >= 0 && x < T) return x;
-        if (x > T && x - T - 1 < T) return x - T - 1;
-        return -1;
-    };
-    auto krow = [&](int s, int r) -> int64_t { return (32 * s + r < T) ? 32 * s + r : -1; };
-
-    bf16x8 fqu[KS], fqv[KS], fdo[KS];
-    bool upper = false;
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        const int off = 16 * kk + 8 * lh;
-        fqu[kk] = ld_frag_g(quB + (int64_t)i * p.ldq + off, i < T);
-        fqv[kk] = ld_frag_g(qvB + (int64_t)i * p.ldq + off, i < T);
-        fdo[kk] = ld_frag_g(doB + (int64_t)i * p.ldo + off, i < T);
-    }
-    const float lse_i = i < T ? p.lse[(int64_t)bh * T + i] : __builtin_inff();
-    const float del_i = i < T ? p.delta[(int64_t)bh * T + i] : 0.f;
-    {
-        TL tk, tv, tp[5];
-        tk.load(kB, p.ldkv, tid, [&](int r) { return krow(0, r); });
-        tv.load(vB, p.ldkv, tid, [&](int r) { return krow(0, r); });
-#pragma unroll
-        for (int u = 0; u < 5; ++u) tp[u].load(pB, p.ldp, tid, [&](int r) { return prow(u, r); });
-        tk.commit(Kt, tid);
-        tv.commit(Vt, tid);
-#pragma unroll
-        for (int u = 0; u < 5; ++u) tp[u].commit(Pr + u * TB, tid);
-    }
-    // gradient scratch starts clean: band entries that no key reaches (keys < 0, keys >= T) must read as zero
-    for (int e = lane; e < 32 * GS_LD / 4; e += 64) ((uint2*)gsw)[e] = make_uint2(0, 0);
-    for (int sb = w; sb < NS; sb += 4) {
-        const int jl = 32 * sb + lr;
-        const bool kvalid = (jl < T) && (mkB[jl < T ? jl : 0] != 0);
-        const unsigned int vmw = (unsigned int)__ballot(kvalid);
-        if (lane == 0) kmw[sb] = vmw;
-    }
-    __syncthreads();
-
-    auto band = [&](int u) {
-        const unsigned char* slot = Pr + (u % 6) * TB;
-        const bool useU = (u - 3) * 32 >= 32 + Q0;
-        if (useU && !upper) {
-            upper = true;
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) fqv[kk] = ld_frag_g(qvB + (int64_t)(i + 1) * p.ldq + 16 * kk + 8 * lh, i + 1 < T);
-        }
-        f32x16 acc = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RSB>(slot, lr, 2 * kk + lh), fqv[kk], acc, 0, 0, 0);
-        float* row = scw + lr * SC_LD + 32 * (u & 1) + 4 * lh;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *(float4*)(row + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
-    };
-    band(3 - w);
-
-    f32x16 dQu[NDB], dQv[NDB];
-#pragma unroll
-    for (int d = 0; d < NDB; ++d) dQu[d] = zero16(), dQv[d] = zero16();
-    bool gupper = false;            // side of the band the dQv accumulator currently belongs to
-    const float NEG_INF = -__builtin_inff();
-    const unsigned int ibase = (unsigned int)(((int64_t)bh * T + i) * T);
-    u16* dbdB = p.dbd + (int64_t)bh * T * T;
-
-    auto store_rows = [&](u16* base, int64_t ld, int row, const f32x16* acc) {     // this lane's query row of a [d][q] accumulator
-        if (row < 0 || row >= T) return;
-        u16* o = base + ((int64_t)b * T + row) * ld + h * DK + 4 * lh;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) st4_bf16(o + 32 * d + 8 * g, acc[d][4 * g], acc[d][4 * g + 1], acc[d][4 * g + 2], acc[d][4 * g + 3]);
-    };
-    // consume the COMPLETE band block u of the gradient scratch: dQv += dBD Pext, compact dBD rows to HBM, clear the half
-    auto consume = [&](int u) {
-        const unsigned char* slot = Pr + (u % 6) * TB;
-        const bool useU = (u - 3) * 32 >= 32 + Q0;
-        if (useU && !gupper) {          // first block of the x > T half: what was accumulated belongs to (q+v)[i]
-            gupper = true;
-            if (i < T) store_rows(p.dqvl, p.ldq, i, dQv);
-#pragma unroll
-            for (int d = 0; d < NDB; ++d) dQv[d] = zero16();
-        }
-        u16* grow = gsw + lr * GS_LD + 32 * (u & 1) + 4 * lh;
-        uint2 gq[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            gq[g] = *(const uint2*)(grow + 8 * g);
-            *(uint2*)(grow + 8 * g) = make_uint2(0, 0);
-        }
-        const uint4 f0 = make_uint4(gq[0].x, gq[0].y, gq[1].x, gq[1].y), f1 = make_uint4(gq[2].x, gq[2].y, gq[3].x, gq[3].y);
-        const bf16x8 b0 = __builtin_bit_cast(bf16x8, f0), b1 = __builtin_bit_cast(bf16x8, f1);
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-            dQv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(slot, 0, 32 * d, lane), b0, dQv[d], 0, 0, 0);
-            dQv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(slot, 16, 32 * d, lane), b1, dQv[d], 0, 0, 0);
-        }
-        // compact dBD: x < T -> row i, column x (x >= T-1-i);  x > T -> row i+1, column x-T-1 (<= T-2-(i+1)... j <= T-1)
-        const int xb = X0 + 32 * (u - 3);
-        if (i < T) {
-            if (!useU) {
-                u16* drow = dbdB + (int64_t)i * T;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int x0 = xb + 8 * g + 4 * lh;
-                    if (x0 >= T - 1 - i && x0 + 3 < T && x0 >= 0) {
-                        *(uint2*)(drow + x0) = gq[g];
-                    } else {
-                        const unsigned int wv[2] = {gq[g].x, gq[g].y};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int x = x0 + e;
-                            if (x >= T - 1 - i && x < T && x >= 0) drow[x] = (u16)(wv[e >> 1] >> (16 * (e & 1)));
-                        }
-                    }
-                }
-            } else if (i + 1 < T) {
-                u16* drow = dbdB + (int64_t)(i + 1) * T;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned int wv[2] = {gq[g].x, gq[g].y};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = xb + 8 * g + 4 * lh + e - T - 1;      // = j - i - 2
-                        if (c >= 0 && c <= T - 3 - i) drow[c] = (u16)(wv[e >> 1] >> (16 * (e & 1)));
-                    }
-                }
-            }
-        }
-    };
-
-    for (int s = 0; s < NS; ++s) {
-        TL tk, tv, tp;
-        const bool more = s + 1 < NS;
-        if (more) {
-            tk.load(kB, p.ldkv, tid, [&](int r) { return krow(s + 1, r); });
-            tv.load(vB, p.ldkv, tid, [&](int r) { return krow(s + 1, r); });
-        }
-        tp.load(pB, p.ldp, tid, [&](int r) { return prow(s + 5, r); });      // (block s+5 is also needed by the tail)
-        f32x16 sa = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RSB>(Kt, lr, 2 * kk + lh), fqu[kk], sa, 0, 0, 0);
-        const int u = s - w + 3;
-        band(u + 1);
-        f32x16 dp = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RSB>(Vt, lr, 2 * kk + lh), fdo[kk], dp, 0, 0, 0);
-        const unsigned int vm = kmw[s];
-        const int c0 = 32 * (u & 1) + 31 - lr;
-        const float* srow = scw + lr * SC_LD;
-        float ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kk = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float bd = srow[(c0 + kk) & 63];
-            const float sv = ((vm >> kk) & 1u) ? (sa[r] + bd) * p.scale : NEG_INF;
-            ds[r] = __expf(sv - lse_i);                  // probability (0 for masked keys and fully masked rows)
-        }
-        if (p.drop_thr) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bool kp[4];
-                rng_keep4(p.drop_key, ibase + (unsigned int)(32 * s + 8 * g + 4 * lh), p.drop_thr, kp);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dp[4 * g + e] = kp[e] ? dp[4 * g + e] * p.drop_inv : 0.f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = ds[r] * (dp[r] - del_i) * p.scale;
-        // ---- d(q+u)^T += K^T dS^T ---------------------------------------------------------------------------------
-        const bf16x8 sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-            dQu[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(Kt, 0, 32 * d, lane), sf0, dQu[d], 0, 0, 0);
-            dQu[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(Kt, 16, 32 * d, lane), sf1, dQu[d], 0, 0, 0);
-        }
-        // ---- inverse skew: (query ii, key kk) -> band column 31 - ii + kk of blocks u / u+1 ----------------------
-        {
-            u16* grow = gsw + lr * GS_LD;
-            const s16x8 h0 = __builtin_bit_cast(s16x8, sf0), h1 = __builtin_bit_cast(s16x8, sf1);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                grow[(c0 + kk) & 63] = (u16)(r < 8 ? h0[r] : h1[r - 8]);
-            }
-        }
-        consume(u);
-        __syncthreads();
-        if (more) {
-            tk.commit(Kt, tid);
-            tv.commit(Vt, tid);
-        }
-        tp.commit(Pr + ((s + 5) % 6) * TB, tid);      // slot of block s-1: last read in step s-1
-        __syncthreads();
-    }
-    consume(NS - 1 - w + 4);                           // the last block only received its kk > ii half
-    // ---- epilogue ---------------------------------------------------------------------------------------------------
-    if (i < T) {
-        store_rows(p.dqu, p.ldq, i, dQu);
-        f32x16 z[NDB];
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) z[d] = zero16();
-        if (gupper) {
-            store_rows(p.dqvu, p.ldq, i + 1, dQv);      // gradient of (q+v)[i+1]
-        } else {
-            store_rows(p.dqvl, p.ldq, i, dQv);
-            store_rows(p.dqvu, p.ldq, i + 1, z);
-        }
-        if (i == 0) store_rows(p.dqvu, p.ldq, 0, z);    // row 0 has no x > T contribution
-    }
-}
-
-template <int NDB>
-__global__ __launch_bounds__(256, 1) void attn_bwd_kv_kernel(AttnArgs p) {
-    using TL = Tile<NDB>;
-    constexpr int DK = TL::DK, KS = DK / 16, RSB = TL::RSB, TB = TL::BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Qt = smem;                            // (q+u) rows i0 .. i0+31
-    unsigned char* Dt = smem + TB;                       // dO rows
-    unsigned char* Pr = smem + 2 * TB;                   // 5 ring slots
-    unsigned char* Wt = smem + 7 * TB;                   // (q+v) rows i0 .. i0+32 (33 rows used, 34 allocated)
-    float* sc = (float*)(smem + 7 * TB + 34 * RSB);      // band scratch [4][32][SC_LD]
-    float* st = sc + 4 * 32 * SC_LD;                     // lse[32] | delta[32] of the query block
-
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = p.T, NKB = (T + 127) / 128, NS = (T + 31) / 32;
-    int wi = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wi & 7;
-        wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
-    }
-    const int bh = wi / NKB, kb = wi - bh * NKB;
-    const int b = bh / p.H, h = bh - b * p.H;
-    const int J0 = kb * 128, j0 = J0 + 32 * w;
-    const int j = j0 + lr;
-    const int XB0 = T - 32 + J0;                         // band base of (wave 0, query block 0)
-    const u16* quB = p.qu + (int64_t)b * T * p.ldq + h * DK;
-    const u16* qvB = p.qv + (int64_t)b * T * p.ldq + h * DK;
-    const u16* doB = p.dctx + (int64_t)b * T * p.ldo + h * DK;
-    const u16* kB = p.k + (int64_t)b * T * p.ldkv + h * DK;
-    const u16* vB = p.v + (int64_t)b * T * p.ldkv + h * DK;
-    const u16* pB = p.pos + h * DK;
-    const float* lseB = p.lse + (int64_t)bh * T;
-    const float* delB = p.delta + (int64_t)bh * T;
-    float* scw = sc + w * 32 * SC_LD;
-
-    // band block u (u >= 0) covers x in [XB0 - 32 (u - 4), +32); the tile of (wave w, query block t) uses blocks
-    // u = t - w + 4 (band columns 0..31) and u - 1 (columns 32..62)
-    auto prow = [&](int u, int r) -> int64_t {
-        const int x = XB0 - 32 * (u - 4) + r;
-        if (x >= 0 && x < T) return x;
-        if (x > T && x - T - 1 < T) return x - T - 1;
-        return -1;
-    };
-    auto qrow = [&](int t, int r) -> int64_t { return (32 * t + r < T) ? 32 * t + r : -1; };
-
-    bf16x8 fk[KS], fv[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-        const int off = 16 * kk + 8 * lh;
-        fk[kk] = ld_frag_g(kB + (int64_t)j * p.ldkv + off, j < T);
-        fv[kk] = ld_frag_g(vB + (int64_t)j * p.ldkv + off, j < T);
-    }
-    const bool jvalid = (j < T) && (p.keymask[(int64_t)b * T + (j < T ? j : 0)] != 0);
-
-    // 33-row (q+v) tile: rows 0..31 through the Tile loader, row 32 by the first CPR threads
-    auto load_w33 = [&](int t, uint4& extra) {
-        const int64_t g = qrow(t, 32);
-        const u16* src = (tid < TL::CPR && g >= 0) ? qvB + g * p.ldq + tid * 8 : (const u16*)attn_zero_page;
-        extra = *(const uint4*)src;
-    };
-    auto commit_w33 = [&](const uint4& extra) {
-        if (tid < TL::CPR) *(uint4*)(Wt + 32 * RSB + tid * 16) = extra;
-    };
-    {
-        TL tq, td, tw, tp[5];
-        uint4 ex;
-        tq.load(quB, p.ldq, tid, [&](int r) { return qrow(0, r); });
-        td.load(doB, p.ldo, tid, [&](int r) { return qrow(0, r); });
-        tw.load(qvB, p.ldq, tid, [&](int r) { return qrow(0, r); });
-        load_w33(0, ex);
-#pragma unroll
-        for (int u = 0; u < 5; ++u) tp[u].load(pB, p.ldp, tid, [&](int r) { return prow(u, r); });
-        tq.commit(Qt, tid);
-        td.commit(Dt, tid);
-        tw.commit(Wt, tid);
-        commit_w33(ex);
-#pragma unroll
-        for (int u = 0; u < 5; ++u) tp[u].commit(Pr + u * TB, tid);
-        if (tid < 32) st[tid] = (tid < T) ? lseB[tid] : __builtin_inff();
-        else if (tid < 64) st[tid] = (tid - 32 < T) ? delB[tid - 32] : 0.f;
-    }
-    __syncthreads();
-
-    // band block u for the query rows currently in Wt -> scratch half (u & 1), stored [query][band column]
-    auto band = [&](int u) {
-        const unsigned char* slot = Pr + (u % 5) * TB;
-        const bool useU = 32 - J0 + 32 * (u - 4) <= 0;        // block base xb >= T  <=>  T - xb <= 0
-        const int arow = lr + (useU ? 1 : 0);                  // (q+v)[i+1] for the x > T half
-        f32x16 acc = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RSB>(Wt, arow, 2 * kk + lh),
-                                                           frag_rows<RSB>(slot, lr, 2 * kk + lh), acc, 0, 0, 0);
-        float* col = scw + 32 * (u & 1) + lr;                  // lane = band column, registers = queries
-#pragma unroll
-        for (int r = 0; r < 16; ++r) col[((r & 3) + 8 * (r >> 2) + 4 * lh) * SC_LD] = acc[r];
-    };
-
-    f32x16 dK[NDB], dV[NDB];
-#pragma unroll
-    for (int d = 0; d < NDB; ++d) dK[d] = zero16(), dV[d] = zero16();
-    const float NEG_INF = -__builtin_inff();
-
-    for (int t = 0; t < NS; ++t) {
-        TL tq, td, tw, tp;
-        uint4 ex;
-        float nst = 0.f;
-        const bool more = t + 1 < NS;
-        if (more) {
-            tq.load(quB, p.ldq, tid, [&](int r) { return qrow(t + 1, r); });
-            td.load(doB, p.ldo, tid, [&](int r) { return qrow(t + 1, r); });
-            tw.load(qvB, p.ldq, tid, [&](int r) { return qrow(t + 1, r); });
-            load_w33(t + 1, ex);
-            tp.load(pB, p.ldp, tid, [&](int r) { return prow(t + 5, r); });
-            {   // lse | delta of the next query block (lanes 0-31 | 32-63 of wave 0), unconditional load
-                const int qi = 32 * (t + 1) + (tid & 31);
-                const float* src = (tid & 32) ? delB : lseB;
-                const float val = src[qi < T ? qi : 0];
-                nst = (qi < T) ? val : ((tid & 32) ? 0.f : __builtin_inff());
-            }
-        }
-        const int u = t - w + 4;
-        // the (q+v) tile changes every step, so BOTH band blocks of the tile are computed here (the u-1 block cannot be
-        // carried over: it was computed against the previous query block)
-        band(u);
-        band(u - 1);
-        // ---- S = (q+u) K^T, dPd = dO V^T (lane = key) -------------------------------------------------------------
-        f32x16 sa = zero16(), dp = zero16();
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RSB>(Qt, lr, 2 * kk + lh), fk[kk], sa, 0, 0, 0);
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<RSB>(Dt, lr, 2 * kk + lh), fv[kk], dp, 0, 0, 0);
-        const int c0 = 32 * (u & 1) + 31 + lr;
-        float pd[16], ds[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ii = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float bd = scw[ii * SC_LD + ((c0 - ii) & 63)];
-            const float sv = jvalid ? (sa[r] + bd) * p.scale : NEG_INF;
-            const float pr = __expf(sv - st[ii]);
-            float dpr = dp[r];
-            pd[r] = pr;
-            if (p.drop_thr) {
-                const unsigned int idx = (unsigned int)(((int64_t)bh * T + (32 * t + ii)) * T + j);
-                const bool kp = rng_keep(p.drop_key, idx, p.drop_thr);
-                dpr = kp ? dpr * p.drop_inv : 0.f;
-                pd[r] = kp ? pr * p.drop_inv : 0.f;
-            }
-            ds[r] = pr * (dpr - st[32 + ii]) * p.scale;
-        }
-        const bf16x8 pf0 = pack_frag(pd), pf1 = pack_frag(pd + 8), sf0 = pack_frag(ds), sf1 = pack_frag(ds + 8);
-#pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-            dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(Dt, 0, 32 * d, lane), pf0, dV[d], 0, 0, 0);
-            dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(Dt, 16, 32 * d, lane), pf1, dV[d], 0, 0, 0);
-            dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(Qt, 0, 32 * d, lane), sf0, dK[d], 0, 0, 0);
-            dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols<RSB>(Qt, 16, 32 * d, lane), sf1, dK[d], 0, 0, 0);
-        }
-        __syncthreads();
-        if (more) {
-            tq.commit(Qt, tid);
-            td.commit(Dt, tid);
-            tw.commit(Wt, tid);
-            commit_w33(ex);
-            tp.commit(Pr + ((t + 5) % 5) * TB, tid);     // slot of block t: blocks t+1 .. t+5 are live in step t+1
-            if (tid < 64) st[tid] = nst;
-        }
-        __syncthreads();
-    }
-    if (j < T) {
-        u16* ok = p.dk + ((int64_t)b * T + j) * p.lddkv + h * DK + 4 * lh;
-        u16* ov = p.dv + ((int64_t)b * T + j) * p.lddkv + h * DK + 4 * lh;
-#pragma unroll
-        for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                st4_bf16(ok + 32 * d + 8 * g, dK[d][4 * g], dK[d][4 * g + 1], dK[d][4 * g + 2], dK[d][4 * g + 3]);
-                st4_bf16(ov + 32 * d + 8 * g, dV[d][4 * g], dV[d][4 * g + 1], dV[d][4 * g + 2], dV[d][4 * g + 3]);
-            }
-    }
 }
 
 // Fold of the key-split tail blocks (launch_fwd16): O = sum of the parts' un-normalised sums, l likewise, both relative to
@@ -1898,60 +1461,6 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
 
 
 
-// dq = d(q+u) + d(q+v) (both halves of the band) -> dqkv[:, 0:d]; bias gradients as column sums:
-//   gu += colsum d(q+u), gv += colsum d(q+v), gbqkv += [colsum dq | colsum dK | colsum dV]   (attention.py:137-140, 63-65)
-__global__ __launch_bounds__(256) void attn_bwd_finish_kernel(const u16* __restrict__ dqu, const u16* __restrict__ dqvl,
-                                                              const u16* __restrict__ dqvu, u16* __restrict__ dqkv,
-                                                              float* gu, float* gv, float* gbqkv, int M, int d,
-                                                              int rows_per_block) {
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    const int ngq = d / 4, ng = 3 * d / 4;
-    for (int cg = threadIdx.x; cg < ng; cg += 256) {
-        float su[4] = {0.f, 0.f, 0.f, 0.f}, sv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (cg < ngq) {
-            const int c = cg * 4;
-            for (int r = r0; r < r1; ++r) {
-                const uint2 a = *(const uint2*)(dqu + (int64_t)r * d + c), bl = *(const uint2*)(dqvl + (int64_t)r * d + c),
-                            bu = *(const uint2*)(dqvu + (int64_t)r * d + c);
-                const float u4[4] = {io_bf2f(a.x & 0xffff), io_bf2f(a.x >> 16), io_bf2f(a.y & 0xffff), io_bf2f(a.y >> 16)};
-                const float v4[4] = {io_bf2f(bl.x & 0xffff) + io_bf2f(bu.x & 0xffff), io_bf2f(bl.x >> 16) + io_bf2f(bu.x >> 16),
-                                     io_bf2f(bl.y & 0xffff) + io_bf2f(bu.y & 0xffff), io_bf2f(bl.y >> 16) + io_bf2f(bu.y >> 16)};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) su[e] += u4[e], sv[e] += v4[e];
-                st4_bf16(dqkv + (int64_t)r * 3 * d + c, u4[0] + v4[0], u4[1] + v4[1], u4[2] + v4[2], u4[3] + v4[3]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(gu + c + e, su[e]);
-                atomicAdd(gv + c + e, sv[e]);
-                atomicAdd(gbqkv + c + e, su[e] + sv[e]);
-            }
-        } else {
-            const int c = cg * 4;                 // column of dqkv in [d, 3d)
-            for (int r = r0; r < r1; ++r) {
-                const uint2 a = *(const uint2*)(dqkv + (int64_t)r * 3 * d + c);
-                su[0] += io_bf2f(a.x & 0xffff), su[1] += io_bf2f(a.x >> 16), su[2] += io_bf2f(a.y & 0xffff), su[3] += io_bf2f(a.y >> 16);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(gbqkv + c + e, su[e]);
-        }
-    }
-}
-
-template <int NDB>
-static int launch_bwd(const AttnArgs& a, int which, hipStream_t s) {
-    constexpr int TB = Tile<NDB>::BYTES, RSB = Tile<NDB>::RSB;
-    constexpr int lds_q = 8 * TB + 4 * 32 * SC_LD * 4 + 4 * 32 * GS_LD * 2 + 4 * 128;
-    constexpr int lds_kv = 7 * TB + 34 * RSB + 4 * 32 * SC_LD * 4 + 64 * 4;
-    (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<NDB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    const int nb = (a.T + 127) / 128;
-    const dim3 grid((unsigned)(a.B * a.H * nb));
-    if (which & 1) hipLaunchKernelGGL(attn_bwd_q_kernel<NDB>, grid, dim3(256), lds_q, s, a);
-    if (which & 2) hipLaunchKernelGGL(attn_bwd_kv_kernel<NDB>, grid, dim3(256), lds_kv, s, a);
-    return (int)hipGetLastError();
-}
-
 static bool attn_shape_ok(int dk, int T) { return dk % 32 == 0 && dk <= 192 && dk != 160 && T % 8 == 0 && T >= 8 && T <= 4096; }
 
 extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* probs, const float* rowscale, const float* delta,
@@ -2006,42 +1515,6 @@ extern "C" int a3t_attn_delta(const void* dctx, const void* ctx, float* delta, i
     const int64_t n = (int64_t)B * T * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const u16*)dctx,
                        (const u16*)ctx, delta, B, H, T, dk, ldo);
-    return (int)hipGetLastError();
-}
-
-extern "C" int a3t_attn_bwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
-                            const uint8_t* keymask, const float* lse, const void* dctx, const float* delta, void* dqu,
-                            void* dqvl, void* dqvu, void* dbd, void* dk_out, void* dv_out, int B, int H, int T, int dk,
-                            int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo, int64_t lddkv, float scale, float drop_p,
-                            uint32_t drop_key, int which, void* stream) {
-    if (!attn_shape_ok(dk, T)) return A3T_EINVAL;
-    if (!(al16(qu) && al16(qv) && al16(k) && al16(v) && al16(pos) && al16(dctx))) return A3T_EINVAL;
-    if ((ldq % 8) || (ldkv % 8) || (ldp % 8) || (ldo % 8) || (lddkv % 4)) return A3T_EINVAL;
-    if (drop_p < 0.f || drop_p >= 1.f) return A3T_EINVAL;
-    AttnArgs a = {};
-    a.qu = (const u16*)qu, a.qv = (const u16*)qv, a.k = (const u16*)k, a.v = (const u16*)v, a.pos = (const u16*)pos;
-    a.keymask = keymask, a.lse = (float*)lse, a.dctx = (const u16*)dctx, a.delta = delta;
-    a.dqu = (u16*)dqu, a.dqvl = (u16*)dqvl, a.dqvu = (u16*)dqvu, a.dbd = (u16*)dbd, a.dk = (u16*)dk_out, a.dv = (u16*)dv_out;
-    a.B = B, a.H = H, a.T = T, a.ldq = ldq, a.ldkv = ldkv, a.ldp = ldp, a.ldo = ldo, a.lddkv = lddkv, a.scale = scale;
-    a.drop_thr = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u;
-    a.drop_key = drop_key, a.drop_inv = 1.f / (1.f - drop_p);
-    hipStream_t s = (hipStream_t)stream;
-    switch (dk / 32) {
-        case 1: return launch_bwd<1>(a, which, s);
-        case 2: return launch_bwd<2>(a, which, s);
-        case 3: return launch_bwd<3>(a, which, s);
-        case 4: return launch_bwd<4>(a, which, s);
-        case 6: return launch_bwd<6>(a, which, s);
-    }
-    return A3T_EINVAL;
-}
-
-extern "C" int a3t_attn_bwd_finish(const void* dqu, const void* dqvl, const void* dqvu, void* dqkv, float* gu, float* gv,
-                                   float* gbqkv, int M, int d, void* stream) {
-    if (d % 4) return A3T_EINVAL;
-    const int rpb = 64;
-    hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
-                       (const u16*)dqu, (const u16*)dqvl, (const u16*)dqvu, (u16*)dqkv, gu, gv, gbqkv, M, d, rpb);
     return (int)hipGetLastError();
 }
 

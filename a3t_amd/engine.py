@@ -233,12 +233,10 @@ class MLMEngine:
         # (the exact-fp32 MFMA for that layer and its two gradients cost 0.55 ms); gradients use hi only.
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
         self.sfc_f32 = os.environ.get("A3T_SFC_F32", "1") != "0"
-        # Round 3, measured on one box (tools/step_ab.sh, ms per step, two runs each): baseline 50.69 / 50.76; attention-dropout mask
-        # of the softmax backward regenerated from the counter RNG instead of read off the dropped probabilities 50.62 / 50.33
-        # (default); head-major dBD + ONE batch-folded token reduction per head for the gradient of linear_pos 51.36 / 51.40 -- the
-        # GEMM is faster alone (111 -> ~50 us per layer, all GEMMs alone 43.2 -> 42.7 ms) but as one 432-workgroup split-K burst
-        # on the side stream it costs the main stream more than the 64 small products did: opt-in (A3T_ATTN_DBD_HM=1).
-        self.attn_hm = os.environ.get("A3T_ATTN_DBD_HM", "0") == "1"
+        # the attention-dropout mask of the score gradients comes back from the counter RNG instead of being read off the dropped
+        # probabilities (round 3: 50.62 / 50.33 ms per step against 50.69 / 50.76); A3T_ATTN_REGEN_MASK=0 reads it.  (The head-major
+        # dBD layout with ONE batch-folded token reduction per head for the gradient of linear_pos lost inside the step in rounds
+        # 3-5 -- +0.7 / +0.2 ms -- and is tools/experiments/attn_dbd_head_major.patch.)
         self.attn_regen = os.environ.get("A3T_ATTN_REGEN_MASK", "1") != "0"
         # dS / dBD straight from the saved probabilities in one launch (a3t_attn_bwd_ds) instead of the dprobs GEMM + softmax
         # backward: dprobs is never stored.  Round 4: 177 us against 216 alone but +0.5 ms per step beside the 128x128 weight
@@ -248,25 +246,24 @@ class MLMEngine:
         # by score traffic, the GEMM it replaces shrinks with d_k: materialised pair there.  A3T_ATTN_BWD_DS=0 / 1: never / always.
         ds_env = os.environ.get("A3T_ATTN_BWD_DS", "auto")
         self.attn_bwd_ds = ds_env == "1" or (ds_env not in ("0", "1") and cfg.dk >= 160)
-        # Fused legacy rel-pos attention (csrc/attn_fused.hip: no T x T tensor in HBM on the forward pass, only the compact
-        # dBD on the backward pass).  On MI355X the forward kernel beats the materialised forward (291 vs 429 us per layer
-        # at the benchmark shape; whole eval forward 4.32 vs 4.74 ms at B = 8, 10.5 vs 11.3 ms at B = 32, 4+4 blocks), except
-        # when it has too few workgroups to hide its 94-us latency floor (B <= 2: +1..2 %); the two-pass backward does not
-        # beat the materialised backward.  Hence the default "auto": forward-only passes (need_grad=False)
-        # use the fused kernel when it launches >= 64 workgroups; training steps stay materialised.
-        # A3T_FUSED_ATTN=0: never; =fwd: every forward-only pass; =1: fused forward AND (flash, recomputing) backward.
-        # Round 4: training steps under "auto" take the fused FORWARD too (a3t_attn_fwd_train: one launch instead of two score
-        # GEMMs + softmax + probs @ V, no logits in HBM); it stores the un-normalised probabilities exp(s - m_ref) (+ their
-        # dropped copy and 1 / row sum) that the materialised backward consumes -- a flash backward has to recompute them,
-        # 10-11 score-sized products against 7, and loses at d_k = 192.  A3T_FUSED_ATTN_TRAIN=0 switches it off.
+        # Fused legacy rel-pos attention forward (csrc/attn_fused.hip: scores, shifted position term, softmax, dropout and PV in one
+        # launch, no logits in HBM).  A3T_FUSED_ATTN = auto (default) | fwd | 0:
+        #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; it beats the
+        #   materialised forward -- 291 vs 429 us per layer at the benchmark shape -- except below its 94-us latency floor, B <= 2);
+        #   training steps under "auto" use a3t_attn_fwd_train, which also stores the un-normalised probabilities exp(s - m_ref), their
+        #   dropped copy and 1 / row sum for the backward (A3T_FUSED_ATTN_TRAIN=0 switches that off, =2 lifts the 64-workgroup
+        #   threshold so that the small-batch parity fixtures go through it).
+        # The backward reads the saved probabilities (a3t_attn_bwd_ds or the materialised pair above); the recomputing flash backward
+        # of round 2 (A3T_FUSED_ATTN=1: 10-11 score-sized products against 7) is tools/experiments/attn_flash_backward.patch.
         fa = os.environ.get("A3T_FUSED_ATTN", "auto")
-        self.fused_attn = self.bf16 and fa == "1"
+        if fa not in ("auto", "fwd", "0"):
+            raise ValueError(f"A3T_FUSED_ATTN={fa!r}: expected auto, fwd or 0 (the flash backward behind '1' left the library in "
+                             "round 5, tools/experiments/attn_flash_backward.patch)")
         self.fused_attn_fwd_only = self.bf16 and fa == "fwd"
         self.fused_attn_auto = self.bf16 and fa == "auto"
         self.fused_attn_train = self.bf16 and fa == "auto" and os.environ.get("A3T_FUSED_ATTN_TRAIN", "1") != "0"
-        # (=2: also below the 64-workgroup threshold -- the small-batch parity fixtures go through the fused kernel that way)
         self.fused_attn_train_min = 1 if os.environ.get("A3T_FUSED_ATTN_TRAIN", "1") == "2" else 64
-        self._fused_now = self.fused_attn
+        self._fused_now = False
         self._fused_train_now = False
         self._need_grad = training
         self._mode_tag = None
@@ -704,8 +701,8 @@ class MLMEngine:
             xo = self.ws.get(tag + ".xo", (M, d))
             ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
                            drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, d))
-            self.sv[tag] = (y, qkv, qu, qv, P, None, ctx, pos, None)
-            self.sv[tag + ".fused"] = (keymask, lse, adr)
+            self.sv[tag] = None          # forward-only pass: nothing is kept for a backward
+            self.sv[tag + ".fused"] = True
             return xo
         self.sv.pop(tag + ".fused", None)
         self.sv.pop(tag + ".rs", None)
@@ -767,35 +764,6 @@ class MLMEngine:
         kk = qkv.view(-1)[d:]
         vv = qkv.view(-1)[2 * d:]
         dqkv = self._act(self._t("tmp.dqkv"), (M, 3 * d))
-        if (tag + ".fused") in self.sv:
-            keymask, lse, adr = self.sv[tag + ".fused"]
-            delta = self.ws.get("tmp.attn.delta", (B, H, T))
-            ops.attn_delta(dctx, ctx, delta, B, H, T)
-            dqu = self._act("tmp.dqu", (M, d))
-            dqvl = self._act("tmp.dqv", (M, d))
-            dqvu = self._act("tmp.dqvu", (M, d))
-            # compact dBD: every entry is written by the kernel except row 0, columns 0..T-2 (never reaches the scores)
-            dbd = self.ws.get(self._t("tmp.dbdf16"), (B, H, T, T), torch.bfloat16, zero_once=True)
-            ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale,
-                         drop=adr or (0.0, 0))
-            zbf = (H * T * T, T * T)
-
-            def pos_weight_grad_fused():
-                dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)
-                ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zbf, b_bs=(T * d, dk),
-                         c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
-                dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
-                ops.cast_bf16(dP, dP16)
-                ops.linear_bwd_weight(dP16, pos, gr[pre + ".wpos"], compute=cmp)
-            self._side(pos_weight_grad_fused)
-            ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gr[pre + ".u"], gr[pre + ".v"], gr[pre + ".bqkv"])
-            self._lin_wgrad(dqkv, y, gr[pre + ".wqkv"], late=True)
-            dy = self._act("tmp.dy", (M, d))
-            self._lin_dgrad(dqkv, pre + ".wqkv", dy)
-            self._pre_ln(ga, g, g16)
-            self._ln_bwd(tag + ".ln", dy, pre + ".ln", g, g, g16, nb, nxt)
-            self._sub_end()
-            return g
         dkk = dqkv.view(-1)[d:]
         dvv = dqkv.view(-1)[2 * d:]
         sdt = torch.bfloat16 if self.bf16 else torch.float32
@@ -836,32 +804,24 @@ class MLMEngine:
                      batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
                      compute=cmp, colsum=sl[3 * d:] if fz else None, **csk)
         self._side(dv_gemm, urgent=True)
-        # dBD is laid out head-major [H][B][T][T] (bf16 mode): the gradient of linear_pos, sum_b dbd[b,h]^T (q+v)[b,h], is then ONE
-        # token-reduction GEMM per head with K = B*T (split-K) instead of B*H products of K = T accumulated by atomics
-        hm = self.bf16 and self.attn_hm
-        zbd = (T * T, B * T * T) if hm else zb
+        zbd = zb
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
-            dbd = self.ws.get(self._t("tmp.dbd16"), (H, B, T, T), torch.bfloat16)
+            dbd = self.ws.get(self._t("tmp.dbd16"), (B, H, T, T), torch.bfloat16)
         else:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
         if ds_fused:
             delta = self.ws.get("tmp.attn.delta", (B, H, T))
             ops.attn_delta(dctx, ctx, delta, B, H, T)
-            ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0), dbd_head_major=hm)
+            ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0))
         else:
             ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
-                                   drop_p=adr[0] if adr else 0.0, dbd_head_major=hm, drop_key=adr[1] if regen else 0, rowscale=rs)
+                                   drop_p=adr[0] if adr else 0.0, drop_key=adr[1] if regen else 0, rowscale=rs)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
             dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
-            if hm:
-                tiles = ((T + 127) // 128) * ((dk + 127) // 128) * H
-                ops.gemm(dbd, qv, dP, T, dk, B * T, 1, T, 1, d, d, batch=H, batch_inner=H, a_bs=(0, B * T * T), b_bs=(0, dk),
-                         c_bs=(0, dk), acc=ACC_ATOMIC, splitk=ops._splitk_for(tiles, B * T), compute=cmp)
-            else:
-                ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                         c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
+            ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
+                     c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
             if self.bf16:
                 dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
                 ops.cast_bf16(dP, dP16)
@@ -994,7 +954,7 @@ class MLMEngine:
         if self.bf16 and (T % 8 or Tm % 8):
             raise ValueError(f"compute='bf16' needs T_mel and T_mel+T_phn to be multiples of 8, got {Tm}, {T}")
         self.dims = (B, Tm, Tp, T)
-        self._fused_now = self.fused_attn or (self.fused_attn_fwd_only and not need_grad) or \
+        self._fused_now = (self.fused_attn_fwd_only and not need_grad) or \
             (self.fused_attn_auto and not need_grad and B * c.heads * ((T + 127) // 128) >= 64)
         nblk = B * c.heads * ((T + 127) // 128)
         self._fused_train_now = self.fused_attn_train and need_grad and not self._fused_now and \

@@ -384,23 +384,6 @@ def attn_delta(dctx, ctx, delta, B, H, T):
     L.check(L.load().a3t_attn_delta(_ptr(dctx), _ptr(ctx), _ptr(delta), B, H, T, d // H, d, _stream()), "attn_delta")
 
 
-def attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale, drop=(0.0, 0), which=3):
-    """Fused attention backward: which & 1 -> dqu, dqvl, dqvu, dbd (query-block pass); which & 2 -> dK | dV into
-    dqkv[:, d:3d] (key-block pass)."""
-    d = qu.shape[1]
-    kk, vv = qkv.view(-1)[d:], qkv.view(-1)[2 * d:]
-    dkk, dvv = dqkv.view(-1)[d:], dqkv.view(-1)[2 * d:]
-    L.check(L.load().a3t_attn_bwd(_ptr(qu), _ptr(qv), _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(lse), _ptr(dctx),
-                                  _ptr(delta), _ptr(dqu), _ptr(dqvl), _ptr(dqvu), _ptr(dbd), _ptr(dkk), _ptr(dvv), B, H, T,
-                                  d // H, d, 3 * d, d, d, 3 * d, scale, drop[0], drop[1], which, _stream()), "attn_bwd")
-
-
-def attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gu, gv, gbqkv):
-    M, d = dqu.shape
-    L.check(L.load().a3t_attn_bwd_finish(_ptr(dqu), _ptr(dqvl), _ptr(dqvu), _ptr(dqkv), _ptr(gu), _ptr(gv), _ptr(gbqkv),
-                                         M, d, _stream()), "attn_bwd_finish")
-
-
 def mask_fill(speech, masked, mask_feature, out):
     M, C = out.shape
     L.check(L.load().a3t_mask_fill(_ptr(speech), _ptr(masked), _ptr(mask_feature), _ptr(out), _dt(out), M, C,

@@ -252,23 +252,9 @@ int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y, int B, in
 int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* probs, const float* rowscale, const float* delta, void* ds,
                     void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb, int64_t dbd_bsh,
                     float scale, float drop_p, uint32_t drop_key, void* stream);
-/* Backward of a3t_attn_fwd (the autograd graph of attention.py:167-209 restated): probabilities are recomputed from
- * lse, nothing T x T is read.
- *   a3t_attn_delta: delta[b][h][i] = sum_d dctx * ctx (= sum_j dP_ij P_ij, with or without dropout).
- *   a3t_attn_bwd, which & 1 (query-block pass): dqu [B*T][ldq] = d(q+u);  dqvl = the part of d(q+v)[i] that comes from
- *       the x < T half of the band (keys j <= i);  dqvu = the x > T half (keys j >= i+2), written AT row i+1 (row 0 = 0):
- *       d(q+v) = dqvl + dqvu;  dbd [B][H][T][T] = the compact dBD (same layout as a3t_relpos_softmax_bwd's dbd; entries
- *       dbd[.][0][0..T-2] are never touched -- the caller zeroes the buffer once), input of the d linear_pos GEMM.
- *   which & 2 (key-block pass): dk_out / dv_out [B*T][lddkv] (head h at column h*dk).
- *   a3t_attn_bwd_finish: dqkv[:, 0:d] = dqu + dqvl + dqvu (dqkv row stride 3d, dK | dV already in columns d..3d);
- *       gu += colsum dqu, gv += colsum (dqvl + dqvu), gbqkv[3d] += colsum dqkv  (pos_bias_u/v, linear_q/k/v.bias). */
+/* delta[b][h][i] = sum_d dctx * ctx (= sum_j dP_ij P_ij, with or without dropout): the row term of the softmax backward
+ * (attention.py:86 backward) that a3t_attn_bwd_ds subtracts.  dctx / ctx row stride ldo, head h at column h*dk. */
 int a3t_attn_delta(const void* dctx, const void* ctx, float* delta, int B, int H, int T, int dk, int64_t ldo, void* stream);
-int a3t_attn_bwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos, const uint8_t* keymask,
-                 const float* lse, const void* dctx, const float* delta, void* dqu, void* dqvl, void* dqvu, void* dbd,
-                 void* dk_out, void* dv_out, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp,
-                 int64_t ldo, int64_t lddkv, float scale, float drop_p, uint32_t drop_key, int which, void* stream);
-int a3t_attn_bwd_finish(const void* dqu, const void* dqvl, const void* dqvu, void* dqkv, float* gu, float* gv,
-                        float* gbqkv, int M, int d, void* stream);
 
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
 int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,

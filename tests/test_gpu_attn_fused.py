@@ -1,4 +1,4 @@
-"""Fused legacy rel-pos attention (a3t_attn_fwd / a3t_attn_bwd) against the materialised path (batched GEMMs +
+"""Fused legacy rel-pos attention (a3t_attn_fwd / a3t_attn_fwd_train / a3t_attn_bwd_ds) against the materialised path (batched GEMMs +
 a3t_relpos_softmax_*, itself pinned by block384.npz / the oracle) on the same bf16 operands, and against the oracle's
 fp32 attention on the reference's own block fixture."""
 import math
@@ -155,136 +155,6 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
 
 
-@pytest.mark.parametrize("drop_p", [0.0, 0.2])
-@pytest.mark.parametrize("B,H,T,dk,lengths", CASES)
-def test_fused_backward_against_fp64_autograd(B, H, T, dk, lengths, drop_p):
-    from a3t_amd import ops
-    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=7 * T + dk, lengths=lengths)
-    d, M = H * dk, B * T
-    rs = np.random.RandomState(T)
-    dctx = torch.from_numpy(rs.standard_normal((M, d)).astype(np.float32)).to(DEV).bfloat16()
-    drop = (drop_p, 0x51ED270B) if drop_p > 0 else (0.0, 0)
-    scale = 1.0 / math.sqrt(dk)
-    ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
-    lse = torch.zeros(B, H, T, device=DEV)
-    ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=drop)
-    delta = torch.zeros(B, H, T, device=DEV)
-    ops.attn_delta(dctx, ctx, delta, B, H, T)
-    z = lambda: torch.full((M, d), 3.0, device=DEV, dtype=torch.bfloat16)      # poisoned outputs
-    dqu, dqvl, dqvu = z(), z(), z()
-    dqkv = torch.full((M, 3 * d), 3.0, device=DEV, dtype=torch.bfloat16)
-    dbd = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
-    ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale, drop=drop)
-    gu, gv, gb = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV), torch.zeros(3 * d, device=DEV)
-    ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gu, gv, gb)
-    torch.cuda.synchronize()
-    keep = None
-    _, probs, pdrop = _materialised(qkv, qu, qv, P, keymask, B, H, T, dk, drop)
-    if drop_p > 0:
-        keep = ((pdrop.float().cpu() != 0) | (probs.float().cpu() == 0)).double()
-    ref = _exact_bwd(qkv, qu, qv, P, keymask, dctx, B, H, T, dk, keep, drop_p)
-    # delta = rowsum(dO * O)
-    dref = (dctx.double().cpu() * ctx.double().cpu()).view(B, T, H, dk).sum(-1).transpose(1, 2)
-    assert float((delta.cpu().double() - dref).abs().max()) < 1e-3 * max(1.0, float(dref.abs().max()))
-    got = dict(dqu=dqu.float().cpu(), dqv=(dqvl.float() + dqvu.float()).cpu(), dk=dqkv[:, d:2 * d].float().cpu(),
-               dv=dqkv[:, 2 * d:].float().cpu())
-    errs = {k: _rel(got[k], ref[k]) for k in got}
-    # d linear_pos(pos) through the compact dBD: dP_h[x] = sum_b sum_i dBD[b,h,i,x] (q+v)[b,i,h]
-    qvh = qv.float().view(B, T, H, dk).permute(0, 2, 1, 3)                     # [B][H][T][dk]
-    dpos = torch.einsum("bhix,bhid->xhd", dbd.float(), qvh).reshape(T, d).cpu()
-    errs["dpos"] = _rel(dpos, ref["dpos"])
-    print(f"[B{B} H{H} T{T} dk{dk} p{drop_p}] relative L2 errors:", {k: f"{v:.2e}" for k, v in errs.items()})
-    for k, v in errs.items():
-        assert v < 2e-2, (k, v)                                                # bf16 operands / outputs
-    # the finish kernel: dq = dqu + dqvl + dqvu and the five bias gradients
-    dq = dqkv[:, :d].float().cpu()
-    assert _rel(dq, ref["dqu"] + ref["dqv"]) < 2e-2
-    np.testing.assert_allclose(gu.cpu().numpy(), dqu.float().sum(0).cpu().numpy(), rtol=2e-2, atol=2e-2 * float(dqu.float().abs().sum(0).max()))
-    np.testing.assert_allclose(gv.cpu().numpy(), (dqvl.float() + dqvu.float()).sum(0).cpu().numpy(), rtol=2e-2,
-                               atol=2e-2 * float(dqvl.float().abs().sum(0).max() + 1e-3))
-    np.testing.assert_allclose(gb[d:].cpu().numpy(), dqkv[:, d:].float().sum(0).cpu().numpy(), rtol=2e-2,
-                               atol=2e-2 * float(dqkv[:, d:].float().abs().sum(0).max()))
-    # rows of padded / fully masked utterances still get their (zero-probability) gradients written: nothing poisoned
-    for t in (dqu, dqvl, dqvu, dqkv):
-        assert bool(torch.isfinite(t.float()).all())
-    assert float(dqvu.view(B, T, d)[:, 0].float().abs().max()) == 0.0
-
-
-@pytest.mark.parametrize("B,H,T,dk,lengths", CASES[:3])
-def test_fused_dbd_matches_materialised_softmax_backward_elementwise(B, H, T, dk, lengths):
-    """The compact dBD written by the fused query pass against a3t_relpos_softmax_bwd's (same layout, same meaning)."""
-    from a3t_amd import ops
-    from a3t_amd._lib import BF16
-    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=11 * T + dk, lengths=lengths)
-    d, M = H * dk, B * T
-    dctx = torch.randn(M, d, device=DEV).bfloat16()
-    scale = 1.0 / math.sqrt(dk)
-    ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
-    lse = torch.zeros(B, H, T, device=DEV)
-    ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale)
-    delta = torch.zeros(B, H, T, device=DEV)
-    ops.attn_delta(dctx, ctx, delta, B, H, T)
-    dqu, dqvl, dqvu = (torch.zeros(M, d, device=DEV, dtype=torch.bfloat16) for _ in range(3))
-    dqkv = torch.zeros(M, 3 * d, device=DEV, dtype=torch.bfloat16)
-    dbd = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
-    ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale, which=1)
-    _, probs, _ = _materialised(qkv, qu, qv, P, keymask, B, H, T, dk, (0.0, 0))
-    vv = qkv.view(-1)[2 * d:]
-    dpr = torch.empty(B, H, T, T, device=DEV, dtype=torch.bfloat16)
-    ops.gemm(dctx, vv, dpr, T, T, dk, d, 1, 3 * d, 1, T, batch=B * H, batch_inner=H, a_bs=(T * d, dk), b_bs=(T * 3 * d, dk),
-             c_bs=(H * T * T, T * T), compute=BF16)
-    ds = torch.empty_like(dpr)
-    dbd_m = torch.empty_like(dpr)
-    ops.relpos_softmax_bwd(probs, dpr, ds, dbd_m, B, H, T, scale)
-    torch.cuda.synchronize()
-    a, b_ = dbd.float().cpu(), dbd_m.float().cpu()
-    sc = float(b_.abs().max())
-    assert float((a - b_).abs().max()) < 3e-2 * sc, float((a - b_).abs().max()) / sc
-    assert _rel(a, b_) < 1.5e-2
-
-
-@pytest.mark.parametrize("dropout", [False, True])
-def test_engine_with_fused_attention_matches_materialised_engine(dropout, monkeypatch):
-    """The bf16 engine with A3T_FUSED_ATTN=1 (fused attention forward + backward, compact dBD -> d linear_pos GEMM, bias
-    gradients from the finish kernel) against the same engine on the materialised path: same loss, same gradients (same
-    counter-RNG masks with dropout on), d = 128 / H = 2 (d_k = 64), ragged batch."""
-    from a3t_amd.config import A3TConfig
-    from a3t_amd.engine import MLMEngine
-    from a3t_amd.params import ParamStore
-    oc = O.A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
-    c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab,
-                  dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
-    state = O.procedural_state(O.param_shapes(oc), 5)
-    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(oc, B=3, T_mel=200, T_phn=24, seed=9, lengths=[200, 141, 77],
-                                                        text_lengths=[24, 17, 9]).items()}
-    res = {}
-    for fused in ("0", "1"):
-        monkeypatch.setenv("A3T_FUSED_ATTN", fused)
-        store = ParamStore(c, DEV)
-        store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
-        eng = MLMEngine(c, store, compute="bf16", training=True, dropout=dropout)
-        assert eng.fused_attn == (fused == "1")
-        loss = float(eng.forward(batch)["loss"])
-        store.zero_grad()
-        eng.backward()
-        torch.cuda.synchronize()
-        res[fused] = (loss, store.state_dict(grads=True))
-    l0, g0 = res["0"]
-    l1, g1 = res["1"]
-    assert abs(l0 - l1) < 5e-3 * abs(l0), (l0, l1)
-    bad = []
-    for k in g0:
-        a, b_ = g1[k].double().flatten(), g0[k].double().flatten()
-        nb = float(b_.norm())
-        if nb < 1e-6 or k.endswith("depthwise_conv.bias") or k.endswith("linear_k.bias"):
-            continue
-        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
-        ratio = float(a.norm()) / nb
-        if cos < 0.985 or not (0.93 < ratio < 1.07):
-            bad.append((k, round(cos, 4), round(ratio, 4)))
-    assert not bad, bad[:10]
-
-
 def test_forward_only_passes_take_the_fused_kernel_by_default(monkeypatch):
     """Default A3T_FUSED_ATTN=auto: an eval / need_grad=False forward with >= 64 attention workgroups runs the fused forward
     kernel (no T x T tensor), a training forward and a tiny batch stay on the materialised path, and both give the same
@@ -303,7 +173,7 @@ def test_forward_only_passes_take_the_fused_kernel_by_default(monkeypatch):
     store = ParamStore(c, DEV)
     store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
     eng = MLMEngine(c, store, compute="bf16", training=False)
-    assert eng.fused_attn_auto and not eng.fused_attn
+    assert eng.fused_attn_auto
     out = eng.forward(batch, need_grad=False)                       # 16 * 2 * 2 = 64 workgroups
     assert sum(k.endswith(".fused") for k in eng.sv) == 3
     fused_after = out["after"].float().clone()

@@ -19,10 +19,6 @@ dctx = torch.randn(M, d, device="cuda").bfloat16()
 ctx = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
 lse = torch.zeros(B, H, T, device="cuda")
 delta = torch.zeros(B, H, T, device="cuda")
-dqu, dqvl, dqvu = (torch.zeros(M, d, device="cuda", dtype=torch.bfloat16) for _ in range(3))
-dqkv = torch.zeros(M, 3 * d, device="cuda", dtype=torch.bfloat16)
-dbd = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
-gu, gv, gb = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda"), torch.zeros(3 * d, device="cuda")
 
 
 def timeit(fn, reps=10):
@@ -42,10 +38,5 @@ res = {}
 res["fwd_fused_us"] = timeit(lambda: ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=DROP))
 res["fwd_materialised_us"] = timeit(lambda: _materialised(qkv, qu, qv, P, keymask, B, H, T, dk, DROP))
 res["bwd_delta_us"] = timeit(lambda: ops.attn_delta(dctx, ctx, delta, B, H, T))
-res["bwd_q_us"] = timeit(lambda: ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale, drop=DROP, which=1))
-res["bwd_kv_us"] = timeit(lambda: ops.attn_bwd(qu, qv, qkv, P, keymask, lse, dctx, delta, dqu, dqvl, dqvu, dbd, dqkv, B, H, T, scale, drop=DROP, which=2))
-res["bwd_finish_us"] = timeit(lambda: ops.attn_bwd_finish(dqu, dqvl, dqvu, dqkv, gu, gv, gb))
 res["fwd_tflops"] = 3 * unit / res["fwd_fused_us"] / 1e6
-res["bwd_q_tflops"] = 5 * unit / res["bwd_q_us"] / 1e6
-res["bwd_kv_tflops"] = 6 * unit / res["bwd_kv_us"] / 1e6
 print({k: round(v, 1) for k, v in res.items()})

@@ -1,4 +1,4 @@
-"""The attention kernels alone for rocprofv3 counter passes (tools/r04_profiles.sh): a few launches of the fused forward
+"""The attention kernels alone for rocprofv3 counter passes (tools/r05_profiles.sh): a few launches of the fused forward
 (inference and training variants) and of the materialised backward's kernels at the benchmark shape."""
 import math
 import os
@@ -21,4 +21,13 @@ rs = torch.zeros(B, H, T, device="cuda")
 for _ in range(3):
     ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
     ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
+torch.cuda.synchronize()
+# the score-gradient kernel of the backward (a3t_attn_bwd_ds: default at d_k >= 160 since round 5) on the same tensors
+dctx = (torch.randn(M, d, device="cuda") * 0.1).bfloat16()
+delta = torch.zeros(B, H, T, device="cuda")
+ds = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+dbd = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+for _ in range(3):
+    ops.attn_delta(dctx, ctx, delta, B, H, T)
+    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
 torch.cuda.synchronize()

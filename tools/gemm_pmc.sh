@@ -1,12 +1,12 @@
-# SQ counters of the FFN GEMM classes (workload: tools/pmc_gemm_r03.py = configs[1] on the 128x128 and panel kernels, configs[3]
-# on the 8-phase kernel) -> gpurun_out/r04_gemm_mfma_busy.json; part of the round-4 evidence set (tools/r04_profiles.sh calls it)
+# SQ counters of the FFN GEMM classes (workload: tools/gemm_pmc_workload.py = configs[1] on the 128x128 and panel kernels, configs[3]
+# on the 8-phase kernel) -> gpurun_out/${A3T_ROUND:-r05}_gemm_mfma_busy.json; part of the per-round evidence set (tools/r05_profiles.sh calls it)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   i=$((i+1))
   rm -rf /tmp/r04_pmcg_$i
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/r04_pmcg_$i -- python $R/tools/pmc_gemm_r03.py > /tmp/r04_pmcg_$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/r04_pmcg_$i -- python $R/tools/gemm_pmc_workload.py > /tmp/r04_pmcg_$i.log 2>&1
 done
 cd $R
 python - <<'PY'
@@ -31,5 +31,5 @@ for k, d in agg.items():
                 row[c + "_frac"] = row[c] / row["SQ_WAVE_CYCLES"]
     out[k] = row
     print(k[:70], {c: round(v, 3) for c, v in row.items() if c.endswith("_frac") or c == "mfma_util"})
-json.dump(out, open("gpurun_out/r04_gemm_mfma_busy.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/" + __import__("os").environ.get("A3T_ROUND", "r05") + "_gemm_mfma_busy.json", "w"), indent=1)
 PY

@@ -1,4 +1,4 @@
-"""GEMM launches for the SQ-counter passes of tools/r03_profiles.sh: the conv-FFN classes of BASELINE configs[1] on the
+"""GEMM launches for the SQ-counter passes of tools/gemm_pmc.sh: the conv-FFN classes of BASELINE configs[1] on the
 128x128 kernel (forward / data gradient / weight gradient) and on the 384-column panel kernel (second conv forward, both data
 gradients through the transposed weights), and of configs[3] on the 8-phase kernel (forward convs with their epilogues, data
 gradient with the keep-bit mask)."""
