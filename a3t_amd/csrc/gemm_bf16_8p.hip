@@ -48,6 +48,18 @@ typedef unsigned short u16;
 #define WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
+// LDS-DMA piece (64 lanes x 16 B -> 1 KiB at the wave-uniform LDS byte address `lds_addr`) as INLINE ASM, for the token-reduction
+// kernels: their fragments are read with __builtin_amdgcn_ds_read_tr16_b64, and in front of that builtin hipcc waits vmcnt(0) for
+// every LDS-DMA it has seen issued through __builtin_amdgcn_raw_ptr_buffer_load_lds (it cannot tell that the transposed read does
+// not alias the tiles in flight): one full drain of the DMA queue at the top of every phase -- the counted waits of the schedule
+// never got to wait for anything (found in round 5 in the .s of both TN kernels: 7 "s_waitcnt vmcnt(0)" in the K loop; the
+// k-contiguous kernels, whose fragments are plain ds_read_b128, have none).  An asm DMA is invisible to that bookkeeping; the
+// kernels wait for it themselves (counted vmcnt + s_barrier, as written).  M0 is set in the same statement that uses it.
+__device__ __forceinline__ unsigned g8_lds_base(const void* smem0) { return (unsigned)(uintptr_t)LDS_AS(smem0); }
+__device__ __forceinline__ void g8_dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
 #ifdef G8_TIMING
 __device__ unsigned long long g8_stamps[256 * 2 * 16];
 #define STAMP(k) do { if (lane == 0 && (w & 3) == 0 && (k) < 16) g8_stamps[(blockIdx.x * 2 + wr) * 16 + (k)] = wall_clock64(); } while (0)
@@ -536,11 +548,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
             tpos = t0 | (t1 << 16);
         }
     };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(g8_lds_base(smem));
     auto issue = [&](const int H, const int buf) __attribute__((always_inline)) {
         int wv = w;
         unsigned acs = a_csb, bcs = b_csb;
         asm volatile("" : "+s"(wv), "+s"(acs), "+s"(bcs));
-        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + wv * 1024;
+        const unsigned dst = lds0 + (unsigned)(buf * TILE_BYTES + H * HALF_BYTES) + (unsigned)wv * 1024u;
         const int krem = p.K - c_kt * 64 - krl;       // > q*32: the lane's token row exists
         const int h = H & 1;
         if (H < 2) {
@@ -549,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned vb = voffA + (unsigned)(h * 256) + (unsigned)(q * 32) * acs;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_AS(dst + q * 8192), 16, (colok && krem > q * 32) ? vb : OOB, so, 0, 0);
+                g8_dma16(rA, dst + q * 8192, (colok && krem > q * 32) ? vb : OOB, so);
             }
         } else {
             const bool colok = tn * 256 + h * 128 + sc * 8 < p.N;
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn_kernel(GP p) {
                 const bool ok = colok && (krem > q * 32) && (!WG || ((unsigned)(tp + shiftB[h]) < (unsigned)p.Tseq));
                 // (the whole token offset lives in voffset: the range check ignores soffset, and the tap shift may be negative)
                 const unsigned vb = voffB + (unsigned)(c_kt * 64 + q * 32 + shiftB[h]) * bcs + (unsigned)(c0B[h] * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_AS(dst + q * 8192), 16, ok ? vb : OOB, 0, 0, 0);
+                g8_dma16(rB, dst + q * 8192, ok ? vb : OOB, 0u);
             }
         }
     };
@@ -827,11 +840,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p, TN3Group
     };
     // kt / tp: K-tile and token positions the half belongs to (the B1 / B2 halves of K-tile t+1 are requested after the cursor
     // has moved on to t+2 for B0: the caller hands in the values it saved)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(g8_lds_base(smem));
     auto issue = [&](const int H, const int buf, const int kt, const int tp) __attribute__((always_inline)) {
         int wv = w;
         unsigned acs = a_csb, bcs = b_csb;
         asm volatile("" : "+s"(wv), "+s"(acs), "+s"(bcs));
-        unsigned char* dst = smem + buf * TILE_BYTES + H * HALF_BYTES + wv * 1024;
+        const unsigned dst = lds0 + (unsigned)(buf * TILE_BYTES + H * HALF_BYTES) + (unsigned)wv * 1024u;
         const int krem = p.K - kt * 64 - krl;
         if (H == H3A) {
             const bool colok = mA < Mp;
@@ -839,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p, TN3Group
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const unsigned vb = voffA + (unsigned)(q * 32) * acs;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_AS(dst + q * 8192), 16, (colok && krem > q * 32) ? vb : OOB, so, 0, 0);
+                g8_dma16(rA, dst + q * 8192, (colok && krem > q * 32) ? vb : OOB, so);
             }
         } else {
             const int h = H - 1;
@@ -849,7 +863,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p, TN3Group
                 const int t = q ? (tp >> 16) : (tp & 0xffff);
                 const bool ok = colok && (krem > q * 32) && (!WG || ((unsigned)(t + shiftB[h]) < (unsigned)p.Tseq));
                 const unsigned vb = voffB + (unsigned)(kt * 64 + q * 32 + shiftB[h]) * bcs + (unsigned)(c0B[h] * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, LDS_AS(dst + q * 8192), 16, ok ? vb : OOB, 0, 0, 0);
+                g8_dma16(rB, dst + q * 8192, ok ? vb : OOB, 0u);
             }
         }
     };
