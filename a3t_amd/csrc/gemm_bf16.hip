@@ -36,7 +36,7 @@ __device__ __attribute__((aligned(16))) unsigned int a3t_zero_page[16];
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 
-// -DGLDS_TIMING (A3T_EXTRA_FLAGS): per-workgroup phase times of the single-buffer K loop (tools/glds_timing.py)
+// -DGLDS_TIMING (A3T_EXTRA_FLAGS): per-workgroup phase times of the single-buffer K loop (round-2 tool, see profiles/NOTEBOOK_r01_r03.md)
 #ifdef GLDS_TIMING
 __device__ unsigned long long glds_dbg[16384 * 8];
 extern "C" int a3t_debug_read_glds(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glds_dbg), bytes); }

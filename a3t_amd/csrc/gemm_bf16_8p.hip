@@ -1138,7 +1138,7 @@ static bool g8_applicable(const GP& p, int batch, int ly, bool keep) {
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || (int64_t)p.M * p.c_rs >= (1ll << 32)) return false;
     if (keep && (p.N % 256 != 0)) return false;
     if (mode == 2) {
-        // Cost model fitted on MI355X (tools/g8_check.py, tools/g8_c4_shapes.py): one 128-KiB workgroup per CU runs its K loop
+        // Cost model fitted on MI355X (round 3: profiles/r03_g8_check.txt, r03_g8_c4_shapes.txt): one 128-KiB workgroup per CU runs its K loop
         // at ~1.65 us per 64-wide K-tile (1.3 PFLOP/s) but nothing overlaps a tile's fixed costs -- pipeline refill and
         // quadrant epilogues ~7 us, bias/activation 1.5, dropout hashes 5, keep bits / fp32 + residual 2 each -- nor the partially
         // filled last round of the grid; the 128x128 kernel (4 workgroups per CU, epilogues hidden behind its neighbours)

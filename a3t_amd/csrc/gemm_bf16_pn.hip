@@ -29,7 +29,7 @@
 //   * a workgroup owns a panel and walks its 384-column chunks (N = 1536: four; the panel's rows stay in L2); the epilogue is a
 //     plain tail (bias -> relu -> ReLU' mask S -> dropout -> alpha -> fp32 residual -> store bf16 | fp32, column sums through
 //     LDS) that runs while the next tile's first K-tiles are already in flight.
-// Tried on top of this kernel and taken out again (round 3, tools/pn_check.py of those commits):
+// Tried on top of this kernel and taken out again (round 3, profiles/r03_pn_check.txt):
 //   * batched operands for the attention scores (64 x 1120 x 1120 x 192 = 21 tiles of 3 K-tiles per batch element): 80 us against
 //     73 us on the 128x128 kernel -- ~9 us of fill and epilogue per tile against 4.7 us of K loop;
 //   * a 320 x 192 geometry (4 x 2 waves, same wave tile) for probabilities x V / dS x K / dBD x P with a transposed second
@@ -455,12 +455,12 @@ static bool pn_applicable(const GP& p, int batch, int ly) {
     }
     if (mode == 3 && p.N != PN_COLS) return false;
     if (mode >= 2) {
-        // Cost model fitted on MI355X (tools/probes/gemm_pn.hip, tools/pn_check.py): a tile (panel x 384-column chunk) costs ~1.55 us per
+        // Cost model fitted on MI355X (tools/probes/gemm_pn.hip, profiles/r03_pn_check.txt): a tile (panel x 384-column chunk) costs ~1.55 us per
         // 64-wide K-tile plus ~8 us of pipeline fill and epilogue (dropout hashes and an fp32 residual add ~3 more; the later
         // chunks of a panel overlap their fill with the previous epilogue: ~5), all panels of a round run together; the 128x128
         // kernel does these problems at ~700-780 TFLOP/s for long K and ~450 for K = 384.
         // Wider outputs (N = 768 / 1152 / 1536: pointwise_conv1, q/k/v, the first FFN conv) measure 5-12 % faster in a loop of
-        // their own (tools/pn_check.py) and NOT faster inside the training step (configs[1], same box: 48.7-48.9 ms per step with
+        // their own (profiles/r03_pn_check.txt) and NOT faster inside the training step (configs[1], same box: 48.7-48.9 ms per step with
         // them, 48.2-48.6 without, gpurun_out/pn_step_ab4.log) -- a loop of one 224-workgroup kernel fills the 32 idle CUs with the
         // next launch, a step does not.  The exception is the data gradient of the second FFN conv, whose ReLU' mask read makes the
         // 128x128 kernel's epilogue slow: -0.5 ms per step.  Hence: several chunks only for problems that carry a mask tensor.
