@@ -50,33 +50,9 @@ def shared_stream(dev, kind, high=False):
     idx = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     key = (idx, kind)
     if key not in _STREAMS:
-        cus = int(os.environ.get("A3T_%s_CUS" % kind.upper(), "0"))
-        if cus > 0:
-            _STREAMS[key] = _cu_masked_stream(idx, cus)
-        else:
-            pr = torch.cuda.Stream.priority_range()[1] if high else 0
-            _STREAMS[key] = torch.cuda.Stream(device=dev, priority=pr)
+        pr = torch.cuda.Stream.priority_range()[1] if high else 0
+        _STREAMS[key] = torch.cuda.Stream(device=dev, priority=pr)
     return _STREAMS[key]
-
-
-def _cu_masked_stream(idx, cus):
-    """A HIP stream whose kernels may only be placed on `cus` of the chip's compute units (hipExtStreamCreateWithCUMask):
-    A3T_SIDE_CUS / A3T_SIDE2_CUS give the weight-gradient streams a partition of the chip instead of every wave slot, so
-    that a main-stream row kernel that becomes eligible in the middle of a 1000-workgroup weight-gradient burst finds free
-    CUs.  The driver spreads the mask bits round-robin over the XCDs: the lowest n bits are n / 8 CUs of every XCD."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    total = torch.cuda.get_device_properties(idx).multi_processor_count
-    cus = max(8, min(cus, total))
-    words = (total + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for b in range(cus):
-        mask[b // 32] |= 1 << (b % 32)
-    h = ctypes.c_void_p()
-    with torch.cuda.device(idx):
-        if hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask) != 0:
-            raise RuntimeError("hipExtStreamCreateWithCUMask failed")
-    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", idx))
 
 
 class _FastEvent:
@@ -206,55 +182,41 @@ class MLMEngine:
         self._par = 0
         self._depth = max(2, int(os.environ.get("A3T_SIDE_DEPTH", "48")))   # scratch sets the main stream may run ahead by
         self._side_ev = [None] * self._depth
-        # (A3T_SIDE_DEFER=1, experiment: hand a sub-layer's weight gradients over at its END with one event record instead of one
-        #  per GEMM -- 47.1 ms per step against 45.4: the weight gradients have to start as early as they can)
-        self._side_defer = os.environ.get("A3T_SIDE_DEFER", "0") == "1"
-        self._side_pending = []
         # Linear weight gradients collected for one grouped launch (_lin_wgrad): 4 = one Conformer block's; needs the deep scratch ring
         self._wg_group = 4 if (self.bf16 and self.side is not None and self._depth >= 8 and
                                os.environ.get("A3T_WGRAD_GROUP", "1") != "0") else 1
         self._wg_pending = []
-        # (A3T_SIDE_LATE=1, experiment: 46.5 ms per step against 45.2 -- see _pre_ln)
-        self._side_late = os.environ.get("A3T_SIDE_LATE", "0") == "1"
         self._gm_ready = None
         self._arena = {k: dict(buf=None, used=0, slots={}, dtype=dt) for k, dt in
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
         self.colsum_slots = int(os.environ.get("A3T_COLSUM_SLOTS", "16"))   # spread of the attention bias-gradient atomics
         self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
         # A3T_FUSE_LN_FWD=1 (opt-in): the GEMM that closes a sub-layer (x + a * dropout(branch), N = d = 384: panel kernel, a
-        # workgroup owns whole rows) also writes the NEXT sub-layer's LayerNorm (a3t_gemm_desc::ln_*).  48 a3t_layernorm_fwd
-        # launches of 17 us fewer per step, but the two extra barriers and the second store pass in 224 exposed epilogues cost
-        # almost as much: 45.96 / 46.09 ms per step against 46.02 / 46.16 -- not worth a changed rounding order.
+        # workgroup owns whole rows) also writes the NEXT sub-layer's LayerNorm (a3t_gemm_desc::ln_*).  Neutral inside the step
+        #  and it rounds in a different order, so it stays off.
         self.fuse_ln_fwd = os.environ.get("A3T_FUSE_LN_FWD", "0") == "1"
         self._ln_pending = None
         # bf16 mode: the first postnet conv reads `before` (log-mel scale, |x| ~ 4: one bf16 ulp = 0.03) whose rounding the
         # five BatchNorm'ed postnet layers amplify.  Its forward therefore runs on (hi, lo) = (bf16(x), bf16(x - hi)): two
-        # K = 5*80 bf16 GEMMs carry `before` to ~2^-17 (max error of `after` 6.2e-2 -> 4.3e-2 of scale) for ~0.05 ms per step
-        # (the exact-fp32 MFMA for that layer and its two gradients cost 0.55 ms); gradients use hi only.
+        # K = 5*80 bf16 GEMMs carry `before` to ~2^-17 (max error of `after` 6.2e-2 -> 4.3e-2 of scale); gradients use hi only.
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
         self.sfc_f32 = os.environ.get("A3T_SFC_F32", "1") != "0"
         # the attention-dropout mask of the score gradients comes back from the counter RNG instead of being read off the dropped
-        # probabilities (round 3: 50.62 / 50.33 ms per step against 50.69 / 50.76); A3T_ATTN_REGEN_MASK=0 reads it.  (The head-major
-        # dBD layout with ONE batch-folded token reduction per head for the gradient of linear_pos lost inside the step in rounds
-        # 3-5 -- +0.7 / +0.2 ms -- and is tools/experiments/attn_dbd_head_major.patch.)
+        # probabilities (one T x T read less); A3T_ATTN_REGEN_MASK=0 reads it
         self.attn_regen = os.environ.get("A3T_ATTN_REGEN_MASK", "1") != "0"
         # dS / dBD straight from the saved probabilities in one launch (a3t_attn_bwd_ds) instead of the dprobs GEMM + softmax
-        # backward: dprobs is never stored.  Round 4: 177 us against 216 alone but +0.5 ms per step beside the 128x128 weight
-        # gradients (a persistent 79-KB-LDS kernel left them nothing).  Round 5, with the weight gradients on the 128x384-tile
-        # kernel: configs[1] (d_k = 192) 42.94 / 43.04 ms per step against 43.56 / 43.57 on one box -- default there.  configs[3]
-        # (d_k = 128, 2.6x the scores per layer for 2/3 of the product work per score): 68.70 against 67.51 -- the kernel is bound
-        # by score traffic, the GEMM it replaces shrinks with d_k: materialised pair there.  A3T_ATTN_BWD_DS=0 / 1: never / always.
+        # backward: dprobs is never stored.  Default where it wins inside the step: d_k >= 160 -- the kernel is bound by
+        # score traffic, the GEMM it replaces shrinks with d_k.  A3T_ATTN_BWD_DS=0 / 1: never / always.
         ds_env = os.environ.get("A3T_ATTN_BWD_DS", "auto")
         self.attn_bwd_ds = ds_env == "1" or (ds_env not in ("0", "1") and cfg.dk >= 160)
         # Fused legacy rel-pos attention forward (csrc/attn_fused.hip: scores, shifted position term, softmax, dropout and PV in one
         # launch, no logits in HBM).  A3T_FUSED_ATTN = auto (default) | fwd | 0:
-        #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; it beats the
-        #   materialised forward -- 291 vs 429 us per layer at the benchmark shape -- except below its 94-us latency floor, B <= 2);
+        #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; below that its
+        #   latency floor loses to the materialised forward);
         #   training steps under "auto" use a3t_attn_fwd_train, which also stores the un-normalised probabilities exp(s - m_ref), their
         #   dropped copy and 1 / row sum for the backward (A3T_FUSED_ATTN_TRAIN=0 switches that off, =2 lifts the 64-workgroup
         #   threshold so that the small-batch parity fixtures go through it).
-        # The backward reads the saved probabilities (a3t_attn_bwd_ds or the materialised pair above); the recomputing flash backward
-        # of round 2 (A3T_FUSED_ATTN=1: 10-11 score-sized products against 7) is tools/experiments/attn_flash_backward.patch.
+        # The backward reads the saved probabilities (a3t_attn_bwd_ds or the materialised pair above).
         fa = os.environ.get("A3T_FUSED_ATTN", "auto")
         if fa not in ("auto", "fwd", "0"):
             raise ValueError(f"A3T_FUSED_ATTN={fa!r}: expected auto, fwd or 0 (the flash backward behind '1' left the library in "
@@ -528,32 +490,16 @@ class MLMEngine:
 
     def _sub_end(self):
         if self.side is not None:
-            self._side_flush()
             ev = self._owned_event(("slot", self._par))
             ev.record(self.side)
             self._side_ev[self._par] = ev
 
-    def _side_flush(self):
-        """A3T_SIDE_DEFER=1 only: hand the sub-layer's deferred side work over with one event record on the main stream."""
-        if not self._side_pending:
-            return
-        ev = _new_event()
-        ev.record()
-        with torch.cuda.stream(self.side):
-            ev.wait_on(self.side)
-            for fn in self._side_pending:
-                fn()
-        self._side_pending = []
-
-    def _side(self, fn, want_event=False, urgent=False, late=False):
+    def _side(self, fn, want_event=False, urgent=False):
         """Run fn (work whose inputs are complete on the main stream NOW) on the side stream; with want_event the
         returned event marks its completion (for results the main stream consumes later).  urgent: the main stream joins
         this work before the sub-layer ends -- it goes to the second side stream, in front of no backlog."""
         if self.side is None:
             fn()
-            return None
-        if (self._side_defer or (late and self._side_late)) and not urgent and not want_event:
-            self._side_pending.append(fn)         # (its inputs stay valid until the sub-layer ends: scratch sets)
             return None
         ev = _new_event()
         ev.record()
@@ -567,7 +513,7 @@ class MLMEngine:
                 return done
         return None
 
-    def _lin_wgrad(self, dy, x, dW, late=False):
+    def _lin_wgrad(self, dy, x, dW):
         """Weight gradient of a Linear (dW += dy^T x), off the main stream.  bf16 path: the Linear weight gradients of a block
         (linear_out, linear_q/k/v, pointwise_conv2, pointwise_conv1 -- all reductions over the same tokens with 384 input
         channels) are collected and handed over as ONE grouped launch (ops.linear_bwd_weight_group): they feed nothing until the
@@ -578,7 +524,7 @@ class MLMEngine:
             if len(self._wg_pending) >= self._wg_group:
                 self._wg_flush()
             return
-        self._side(lambda: ops.linear_bwd_weight(dy, x, dW, compute=self.cmp), late=late)
+        self._side(lambda: ops.linear_bwd_weight(dy, x, dW, compute=self.cmp))
 
     def _wg_flush(self):
         items, self._wg_pending = self._wg_pending, []
@@ -593,7 +539,6 @@ class MLMEngine:
     def _side_join(self):
         self._wg_flush()
         if self.side is not None:
-            self._side_flush()
             torch.cuda.current_stream().wait_stream(self.side)
             if self.side2 is not self.side:
                 torch.cuda.current_stream().wait_stream(self.side2)
@@ -602,18 +547,9 @@ class MLMEngine:
     def _pre_ln(self, ga, g, g16):
         """The sub-layer's closing LayerNorm backward rewrites g / g16 in place: if the side-stream GEMMs read the
         gradient from there (no dropout copy), they must finish first."""
-        if self.side is not None and self._side_late:
-            # `late` weight gradients (their operand is produced in front of the sub-layer's last data-gradient GEMM) are handed
-            # over HERE: forked earlier they become eligible while that GEMM runs, take every CU the moment it ends, and the
-            # LayerNorm backward -- not eligible before the GEMM has completed -- waits a whole weight gradient for its slots
-            # (170 us instead of 53: tools/trace_analyse.py).  Eligible together, the high-priority main stream is served first.
-            # Measured: the LayerNorm backwards drop from 6.6 to 5.1 ms per step, but the late weight gradients then collide with
-            # the next sub-layer's first GEMMs (+2.8 ms): off by default.
-            self._side_flush()
         if ga is g or ga is g16:
             self._wg_flush()              # (collected Linear weight gradients read the gradient in place too)
         if self.side is not None and (ga is g or ga is g16):
-            self._side_flush()
             torch.cuda.current_stream().wait_stream(self.side)
 
     # ------------------------------------------------------------------ FFN (MultiLayeredConv1d)
@@ -659,7 +595,7 @@ class MLMEngine:
         else:
             ops.conv_bwd_data(ga, self.W(pre + ".w2"), dh, T, pad, S=h, alpha=a_dh,
                               compute=self.cmp, colsum=gr[pre + ".b1"] if self.bf16 else None)
-        self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp), late=True)
+        self._side(lambda: ops.conv_bwd_weight(dh, y, gr[pre + ".w1"], T, pad, compute=self.cmp))
         dy = self._act("tmp.dy", (M, c.adim))
         if self._ffn_plan(M)[1]:
             ops.conv_fwd(dh, self._wt["w1"][2][pre + ".w1"], dy, T, c.ff_kernel - 1 - pad, compute=self.cmp)
@@ -849,7 +785,7 @@ class MLMEngine:
             self._bias_grad(dqu, gr[pre + ".u"])
             self._bias_grad(dqv, gr[pre + ".v"])
             self._bias_grad(dqkv, gbq)
-        self._lin_wgrad(dqkv, y, gr[pre + ".wqkv"], late=True)
+        self._lin_wgrad(dqkv, y, gr[pre + ".wqkv"])
         dy = self._act("tmp.dy", (M, d))
         self._lin_dgrad(dqkv, pre + ".wqkv", dy)
         self._pre_ln(ga, g, g16)
@@ -914,7 +850,7 @@ class MLMEngine:
         dg = self._act(self._t("tmp.dg"), (M, 2 * d))
         ops.glu_dwconv_bwd(dz, g2, glu, p[pre + ".dw"], dg, gr[pre + ".dw"], gr[pre + ".db"], T,
                            dgsum=gr[pre + ".pb1"])
-        self._lin_wgrad(dg, y, gr[pre + ".pw1"], late=True)
+        self._lin_wgrad(dg, y, gr[pre + ".pw1"])
         dy = self._act("tmp.dy", (M, d))
         self._lin_dgrad(dg, pre + ".pw1", dy)
         self._pre_ln(ga, g, g16)
