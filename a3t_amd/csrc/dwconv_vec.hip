@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_vec_kernel(const u16* __re
             for (int tt = 0; tt < 4; ++tt) {
                 float acc = bias;
 #pragma unroll
-                for (int k = 0; k < KT; ++k) acc += w[k] * v[tt + k];
+                for (int k = 0; k < KT; ++k) acc = __builtin_fmaf(w[k], v[tt + k], acc);
                 zt[r0 + tt][tx] = acc;
             }
         }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 3) void glu_dwconv_bwd_vec_kernel(const float*
                     for (int tt = 0; tt < 4; ++tt) {
                         float a = 0.f;
 #pragma unroll
-                        for (int k = 0; k < KT; ++k) a += w[k] * u[tt + KT - 1 - k];
+                        for (int k = 0; k < KT; ++k) a = __builtin_fmaf(w[k], u[tt + KT - 1 - k], a);
                         acc[tt] = a;
                         dzt[tt] = u[tt + (KT - 1) / 2];
                     }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 3) void glu_dwconv_bwd_vec_kernel(const float*
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
-                        for (int k = 0; k < KT; ++k) dw[k] += dzt[tt] * q[tt + k];
+                        for (int k = 0; k < KT; ++k) dw[k] = __builtin_fmaf(dzt[tt], q[tt + k], dw[k]);
                         db += dzt[tt];
                     }
                 }
