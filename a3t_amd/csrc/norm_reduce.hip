@@ -281,6 +281,94 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
     }
 }
 
+// D % 128 == 0, second layout (round 5): a whole wave per row, NP float2 per lane (D = 128*NP).  Half the per-lane state of the
+// half-wave layout above (76 registers against 132 at D = 384): inside the training step this kernel runs beside the weight-gradient
+// GEMM of the other stream, whose two waves per SIMD leave 160 of the 512 registers -- one wave of the 132-register kernel, two of
+// this one (LayerNorm backward inside the step: 93 us with the half-wave layout, 54 us alone).  The column-sum partials of a
+// block's eight waves go through a 12-KiB LDS buffer one array at a time.
+template <int NP>
+__global__ __launch_bounds__(512) void ln_bwd_row64_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
+                                                           const float* __restrict__ g, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* dres, float* dx,
+                                                           unsigned short* __restrict__ dx16, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                                           float dxsum_scale, int M, int D, unsigned int drop_thr,
+                                                           float drop_inv, unsigned int drop_key) {
+    __shared__ float red[8][128 * NP];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float2 gam[NP], ag[NP], ab[NP], ax[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        gam[i] = *(const float2*)(g + (lane + 64 * i) * 2);
+        ag[i] = ab[i] = ax[i] = make_float2(0.f, 0.f);
+    }
+    const float invD = 1.f / (float)D;
+    const unsigned int t16 = drop_thr >> 16;
+    for (int row = blockIdx.x * 8 + wv; row < M; row += gridDim.x * 8) {
+        const float mu = mean[row], rs = rstd[row];
+        const int64_t ro = (int64_t)row * D;
+        float2 xh[NP], dg[NP], rr[NP];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {   // the residual gradient is requested with the row, not after the reduction
+            rr[i] = make_float2(0.f, 0.f);
+            if (dres) rr[i] = *(const float2*)(dres + ro + (lane + 64 * i) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int c = (lane + 64 * i) * 2;
+            float2 d;
+            if (dy_dt == A3T_BF16) {
+                const unsigned int t = *(const unsigned int*)((const unsigned short*)dy + ro + c);
+                d = make_float2(io_bf2f(t & 0xffff), io_bf2f(t >> 16));
+            } else {
+                d = *(const float2*)((const float*)dy + ro + c);
+            }
+            const float2 xv = *(const float2*)(x + ro + c);
+            xh[i] = make_float2((xv.x - mu) * rs, (xv.y - mu) * rs);
+            dg[i] = make_float2(d.x * gam[i].x, d.y * gam[i].y);
+            s1 += dg[i].x + dg[i].y;
+            s2 += dg[i].x * xh[i].x + dg[i].y * xh[i].y;
+            ag[i].x += d.x * xh[i].x, ag[i].y += d.y * xh[i].y;
+            ab[i].x += d.x, ab[i].y += d.y;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o, WAVE);
+            s2 += __shfl_xor(s2, o, WAVE);
+        }
+        s1 *= invD, s2 *= invD;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int c = (lane + 64 * i) * 2;
+            float2 o = make_float2(rs * (dg[i].x - s1 - xh[i].x * s2) + rr[i].x, rs * (dg[i].y - s1 - xh[i].y * s2) + rr[i].y);
+            *(float2*)(dx + ro + c) = o;
+            if (drop_inv > 0.f) {   // the consumer sub-layer's output dropout (same element pairs as rng_keep4)
+                const unsigned int h = rng_pair(drop_key, (unsigned int)(ro + c) >> 1);
+                o.x = (h & 0xffffu) >= t16 ? o.x * drop_inv : 0.f;
+                o.y = (h >> 16) >= t16 ? o.y * drop_inv : 0.f;
+            }
+            if (dx16) *(unsigned int*)(dx16 + ro + c) = io_pack2(o.x, o.y);
+            ax[i].x += o.x, ax[i].y += o.y;
+        }
+    }
+    // eight waves per block hold partial column sums of the same columns: one array at a time through LDS
+    for (int a = 0; a < 3; ++a) {
+        if (a == 2 && !dxsum) break;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NP; ++i) *(float2*)&red[wv][(lane + 64 * i) * 2] = a == 0 ? ag[i] : (a == 1 ? ab[i] : ax[i]);
+        __syncthreads();
+        for (int col = threadIdx.x; col < 128 * NP; col += 512) {
+            const float v = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
+            if (a == 0) atomicAdd(&dgamma[col], v);
+            else if (a == 1) atomicAdd(&dbeta[col], v);
+            else atomicAdd(&dxsum[col], dxsum_scale * v);
+        }
+    }
+}
+
 #define LN_DISPATCH(D, CALL)              \
     do {                                  \
         if ((D) <= 64) { CALL(1); }       \
@@ -334,6 +422,25 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
             vb_max = e ? atoi(e) : 512;
         }
         if (vb > vb_max) vb = vb_max;
+        static int row64 = -1;                 // A3T_LN_BWD_ROW64=0: the half-wave layout (A/B switch)
+        if (row64 < 0) {
+            const char* e = getenv("A3T_LN_BWD_ROW64");
+            row64 = e ? atoi(e) : 1;
+        }
+        if (row64) {
+            int rb = (M + 7) / 8;
+            if (rb > vb_max) rb = vb_max;
+#define RCALL(NP)                                                                                                      \
+    hipLaunchKernelGGL(ln_bwd_row64_kernel<NP>, dim3(rb), dim3(512), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
+                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D,          \
+                       drop_thr, drop_inv, drop_key)
+            if (D == 128) RCALL(1);
+            else if (D == 256) RCALL(2);
+            else if (D == 384) RCALL(3);
+            else RCALL(4);
+#undef RCALL
+            return (int)hipGetLastError();
+        }
 #define VCALL(NQ)                                                                                                   \
     hipLaunchKernelGGL(ln_bwd_vec_kernel<NQ>, dim3(vb), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
                        rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D,       \
