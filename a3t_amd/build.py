@@ -15,7 +15,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # The direct-to-LDS GEMM variants are tuned to a register budget (<= 128 VGPRs = 4 workgroups per CU); a harmless
 # looking edit can push one over the edge and cost 30-50 % on that GEMM class.  The build records what the compiler
 # allocated; tests/test_host_logic.py::test_gemm_register_budget checks it.
-RES_SOURCES = ("gemm_bf16.hip", "gemm_bf16_8p.hip", "gemm_bf16_pn.hip", "attn_fused.hip")
+RES_SOURCES = ("gemm_bf16.hip", "gemm_bf16_8p.hip", "gemm_bf16_pn.hip", "attn_fused.hip", "norm_reduce.hip")
 RES_FLAG = ["-Rpass-analysis=kernel-resource-usage"]
 
 

@@ -129,6 +129,22 @@ def test_host_index_logic_randomised_against_oracle():
         assert np.array_equal(m_g, m_r), (case, Ln)
 
 
+def test_row_kernels_that_run_beside_the_weight_gradient_gemm_keep_their_register_footprint():
+    """Inside the training step the LayerNorm backward (main stream) runs beside the weight-gradient GEMM of the side stream, whose two
+    176-register waves per SIMD leave 160 of the 512 registers: at <= 80 registers two of its waves fit, at 132 (the half-wave layout it
+    replaced at D = 384) one -- 93 against 80 us per launch inside the step, 63 launches (profiles/r05_ln_bwd_row64_ab.txt).  Held here
+    against the compiler's own report, like the GEMM budgets below."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "a3t_amd", "lib", "norm_reduce.resources.json")
+    if not os.path.exists(path):
+        pytest.skip("library not built by a3t_amd.build in this tree")
+    rows = json.load(open(path))
+    hit = {n: r for n, r in rows.items() if n.startswith("_Z19ln_bwd_row64_kernelILi3E")}
+    assert len(hit) == 1
+    for name, r in hit.items():
+        assert r["VGPRs"] <= 80 and r["ScratchSize [bytes/lane]"] == 0 and r["LDS Size [bytes/block]"] <= 16384, (name, r)
+
+
 def test_gemm_register_budget():
     """The direct-to-LDS GEMM variants are tuned to a register budget: <= 128 VGPRs (4 workgroups per CU) for the plain /
     fast-conv variants and the fused conv weight gradient, <= 168 (3 per CU) for the generic-conv and 192-column
