@@ -285,9 +285,11 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict_
 // half-wave layout above (76 registers against 132 at D = 384): inside the training step this kernel runs beside the weight-gradient
 // GEMM of the other stream, whose two waves per SIMD leave 160 of the 512 registers -- one wave of the 132-register kernel, two of
 // this one (LayerNorm backward inside the step: 93 us with the half-wave layout, 54 us alone).  The column-sum partials of a
-// block's eight waves go through a 12-KiB LDS buffer one array at a time.
-template <int NP>
-__global__ __launch_bounds__(512) void ln_bwd_row64_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
+// block's eight waves go through a 12-KiB LDS buffer one array at a time.  amdgpu_num_vgpr: at D = 384 the kernel needs 82 registers
+// without the hint and 80 with it -- the allocation granule is 8, and 88 would be one wave per SIMD beside the GEMM again
+// (tests/test_host_logic.py holds it to 80).
+template <int NP, bool DY16>
+__global__ __attribute__((amdgpu_num_vgpr(80))) __launch_bounds__(512) void ln_bwd_row64_kernel(const void* __restrict__ dy, int dy_dt, const float* __restrict__ x,
                                                            const float* __restrict__ g, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* dres, float* dx,
                                                            unsigned short* __restrict__ dx16, float* __restrict__ dgamma,
@@ -305,27 +307,41 @@ __global__ __launch_bounds__(512) void ln_bwd_row64_kernel(const void* __restric
     }
     const float invD = 1.f / (float)D;
     const unsigned int t16 = drop_thr >> 16;
-    for (int row = blockIdx.x * 8 + wv; row < M; row += gridDim.x * 8) {
+    // Software pipeline over the wave's rows: dy and x of the NEXT row are requested between the row reduction and the second pass of
+    // this one (into the registers the first pass has just emptied), the residual gradient of a row at its top -- a wave always has a
+    // row's worth of loads in flight while it computes, which is what two waves per SIMD need to keep HBM busy.
+    float2 xn[NP];
+    unsigned int dn16[DY16 ? NP : 1];
+    float2 dn32[DY16 ? 1 : NP];
+    auto request = [&](const int row) __attribute__((always_inline)) {
+        const int64_t ro = (int64_t)row * D;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int c = (lane + 64 * i) * 2;
+            if (DY16) dn16[i] = *(const unsigned int*)((const unsigned short*)dy + ro + c);
+            else dn32[i] = *(const float2*)((const float*)dy + ro + c);
+            xn[i] = *(const float2*)(x + ro + c);
+        }
+    };
+    int row = blockIdx.x * 8 + wv;
+    const int stride = gridDim.x * 8;
+    if (row < M) request(row);
+    for (; row < M; row += stride) {
         const float mu = mean[row], rs = rstd[row];
         const int64_t ro = (int64_t)row * D;
         float2 xh[NP], dg[NP], rr[NP];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {   // the residual gradient is requested with the row, not after the reduction
+        for (int i = 0; i < NP; ++i) {
             rr[i] = make_float2(0.f, 0.f);
             if (dres) rr[i] = *(const float2*)(dres + ro + (lane + 64 * i) * 2);
         }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int c = (lane + 64 * i) * 2;
             float2 d;
-            if (dy_dt == A3T_BF16) {
-                const unsigned int t = *(const unsigned int*)((const unsigned short*)dy + ro + c);
-                d = make_float2(io_bf2f(t & 0xffff), io_bf2f(t >> 16));
-            } else {
-                d = *(const float2*)((const float*)dy + ro + c);
-            }
-            const float2 xv = *(const float2*)(x + ro + c);
+            if (DY16) d = make_float2(io_bf2f(dn16[i] & 0xffff), io_bf2f(dn16[i] >> 16));
+            else d = dn32[i];
+            const float2 xv = xn[i];
             xh[i] = make_float2((xv.x - mu) * rs, (xv.y - mu) * rs);
             dg[i] = make_float2(d.x * gam[i].x, d.y * gam[i].y);
             s1 += dg[i].x + dg[i].y;
@@ -339,6 +355,7 @@ __global__ __launch_bounds__(512) void ln_bwd_row64_kernel(const void* __restric
             s2 += __shfl_xor(s2, o, WAVE);
         }
         s1 *= invD, s2 *= invD;
+        if (row + stride < M) request(row + stride);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int c = (lane + 64 * i) * 2;
@@ -430,10 +447,17 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
         if (row64) {
             int rb = (M + 7) / 8;
             if (rb > vb_max) rb = vb_max;
-#define RCALL(NP)                                                                                                      \
-    hipLaunchKernelGGL(ln_bwd_row64_kernel<NP>, dim3(rb), dim3(512), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
-                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D,          \
-                       drop_thr, drop_inv, drop_key)
+#define RCALL(NP)                                                                                                        \
+    do {                                                                                                                 \
+        if (dy_dtype == A3T_BF16)                                                                                        \
+            hipLaunchKernelGGL((ln_bwd_row64_kernel<NP, true>), dim3(rb), dim3(512), 0, (hipStream_t)stream, dy, dy_dtype, x, \
+                               gamma, mean, rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum,         \
+                               dx_colsum_scale, M, D, drop_thr, drop_inv, drop_key);                                     \
+        else                                                                                                             \
+            hipLaunchKernelGGL((ln_bwd_row64_kernel<NP, false>), dim3(rb), dim3(512), 0, (hipStream_t)stream, dy, dy_dtype, x, \
+                               gamma, mean, rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum,         \
+                               dx_colsum_scale, M, D, drop_thr, drop_inv, drop_key);                                     \
+    } while (0)
             if (D == 128) RCALL(1);
             else if (D == 256) RCALL(2);
             else if (D == 384) RCALL(3);

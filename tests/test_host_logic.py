@@ -140,7 +140,7 @@ def test_row_kernels_that_run_beside_the_weight_gradient_gemm_keep_their_registe
         pytest.skip("library not built by a3t_amd.build in this tree")
     rows = json.load(open(path))
     hit = {n: r for n, r in rows.items() if n.startswith("_Z19ln_bwd_row64_kernelILi3E")}
-    assert len(hit) == 1
+    assert len(hit) == 2            # bf16 / fp32 incoming gradient
     for name, r in hit.items():
         assert r["VGPRs"] <= 80 and r["ScratchSize [bytes/lane]"] == 0 and r["LDS Size [bytes/block]"] <= 16384, (name, r)
 
