@@ -105,6 +105,7 @@ _SIGS = {
     "a3t_gemm_tn3_mode": [c_int],
     "a3t_gemm_tn3_group": [_P, c_int, _P],
     "a3t_attn_split_mode": [c_int],
+    "a3t_release_workspaces": [],
     "a3t_gemm_pn_supported": [c_int, c_int, c_int, c_int, c_int],
     "a3t_dropout_bwd_cast": [_P, _P, c_int, _P, c_float, c_int, c_int, c_float, ctypes.c_uint32, _P],
 }

@@ -112,7 +112,7 @@ static void* g_attn_timing_buf = nullptr;      // a3t_attn_timing_buf(): where t
 __device__ __forceinline__ unsigned lds_base(const void* smem0) { return (unsigned)(uintptr_t)LDS_AS(smem0); }
 __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff) {
     const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(r) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(r) : "memory", "m0");
 }
 __device__ __forceinline__ bf16x8 ld_frag_g(const u16* p, bool ok) {
     const u16* src = ok ? p : (const u16*)attn_zero_page;
@@ -1340,9 +1340,23 @@ static inline bool al16(const void* q) { return ((uintptr_t)q & 15) == 0; }
 
 // workspace of the key-split launch, one per device, allocated at the first use (<= 256 (block, part) pairs of 128 rows):
 // like the overflow flags it serves ONE attention launch at a time per device (the engine issues them on one stream)
+static float* attn_ws_ptr[64];
+static size_t attn_ws_cap[64];
+void attn_release_split_ws() {      // a3t_release_workspaces (gemm_bf16_8p.hip); the caller has drained the attention stream
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int dev = 0; dev < 64; ++dev)
+        if (attn_ws_ptr[dev]) {
+            (void)hipSetDevice(dev);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(attn_ws_ptr[dev]);
+            attn_ws_ptr[dev] = nullptr, attn_ws_cap[dev] = 0;
+        }
+    (void)hipSetDevice(cur);
+}
 static float* attn_split_ws(size_t floats) {
-    static float* ws[64];
-    static size_t cap[64];
+    float** ws = attn_ws_ptr;
+    size_t* cap = attn_ws_cap;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (cap[dev] < floats) {

@@ -57,7 +57,7 @@ typedef unsigned short u16;
 // kernels wait for it themselves (counted vmcnt + s_barrier, as written).  M0 is set in the same statement that uses it.
 __device__ __forceinline__ unsigned g8_lds_base(const void* smem0) { return (unsigned)(uintptr_t)LDS_AS(smem0); }
 __device__ __forceinline__ void g8_dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
 }
 
 #ifdef G8_TIMING
@@ -1065,26 +1065,74 @@ __global__ __launch_bounds__(256) void gemm_8p_tn_fold_kernel(GP p) {
 }
 
 // Split-K partial workspace: one per (device, stream) -- a launch and its fold are ordered on their stream, launches on
-// different streams must not share slabs.  Grow-only (hipMalloc on first use / growth; a few launches during warm-up).
+// different streams must not share slabs.  Grow-only per stream (hipMalloc on first use / growth; a few launches during warm-up);
+// the device is the STREAM's (a launch on another device's stream gets its slab there), at most G8_MAX_SLABS live at a time (the
+// least recently used one is drained and freed), and a3t_release_workspaces() frees them all.
 #include <map>
 #include <mutex>
+#define G8_MAX_SLABS 16
+struct G8Slab {
+    float* p;
+    size_t bytes;
+    unsigned long long used;
+};
+static std::mutex g8_slab_mu;
+static std::map<std::pair<int, hipStream_t>, G8Slab> g8_slabs;
+static unsigned long long g8_slab_clock = 0;
 static float* g8_slab(hipStream_t stream, size_t bytes) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> ws;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    auto& e = ws[{dev, stream}];
-    if (e.second < bytes) {
-        if (e.first) {
-            (void)hipStreamSynchronize(stream);
-            (void)hipFree(e.first);
-        }
-        e.first = nullptr, e.second = 0;
-        if (hipMalloc((void**)&e.first, bytes) != hipSuccess) return nullptr;
-        e.second = bytes;
+    if (stream) {
+        hipDevice_t sd = 0;
+        if (hipStreamGetDevice(stream, &sd) == hipSuccess) dev = (int)sd;
     }
-    return e.first;
+    std::lock_guard<std::mutex> lk(g8_slab_mu);
+    const std::pair<int, hipStream_t> key(dev, stream);
+    if (!g8_slabs.count(key) && g8_slabs.size() >= G8_MAX_SLABS) {
+        auto lru = g8_slabs.begin();
+        for (auto it = g8_slabs.begin(); it != g8_slabs.end(); ++it)
+            if (it->second.used < lru->second.used) lru = it;
+        if (lru->second.p) {
+            (void)hipStreamSynchronize(lru->first.second);      // (a destroyed stream: the error is ignored, the memory is idle)
+            (void)hipFree(lru->second.p);
+        }
+        g8_slabs.erase(lru);
+    }
+    G8Slab& e = g8_slabs[key];
+    e.used = ++g8_slab_clock;
+    if (e.bytes < bytes) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        if (e.p) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(e.p);
+        }
+        e.p = nullptr, e.bytes = 0;
+        const hipError_t r = hipMalloc((void**)&e.p, bytes);
+        if (cur != dev) (void)hipSetDevice(cur);
+        if (r != hipSuccess) {
+            e.p = nullptr;
+            return nullptr;
+        }
+        e.bytes = bytes;
+    }
+    return e.p;
+}
+// frees every split-K slab (after draining the stream it belongs to) and the attention key-split workspace; the next launch that
+// needs one allocates again
+void attn_release_split_ws();      // attn_fused.hip
+extern "C" int a3t_release_workspaces(void) {
+    attn_release_split_ws();
+    std::lock_guard<std::mutex> lk(g8_slab_mu);
+    for (auto& kv : g8_slabs)
+        if (kv.second.p) {
+            (void)hipStreamSynchronize(kv.first.second);
+            (void)hipFree(kv.second.p);
+        }
+    g8_slabs.clear();
+    (void)hipGetLastError();
+    return 0;
 }
 
 static int g8_cus() {          // per device (a process may drive several GPUs)
@@ -1263,6 +1311,14 @@ extern "C" int a3t_gemm_tn3_group(const a3t_gemm_desc* d, int n, void* stream_) 
         q.tile0 = (int)tiles, q.tiles_n = (e.N + 383) / 384;
         tiles += (long)((e.M + 127) / 128) * q.tiles_n;
     }
+    // A3T_ACC_SOLE members are folded with plain read-modify-writes: two members that write overlapping ranges of one gradient (a
+    // tied weight) would race inside the one fold launch -> the caller launches them one by one (ordered on the stream)
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const char* ci = (const char*)d[i].C, *cj = (const char*)d[j].C;
+            const char* ei = ci + ((int64_t)(d[i].M - 1) * d[i].c_rs + d[i].N) * 4, *ej = cj + ((int64_t)(d[j].M - 1) * d[j].c_rs + d[j].N) * 4;
+            if (ci < ej && cj < ei) return -1;
+        }
     if (tn3_mode() == 2) {       // partly empty 384-column tiles (input widths that are no multiple of 384) lose to the single launches
         double out = 0.0;
         for (int i = 0; i < n; ++i) out += (double)d[i].M * d[i].N;
@@ -1334,12 +1390,9 @@ static int gemm_8p_tn(const GP& p, int batch, hipStream_t stream) {
     pv.tiles_n = (int)tn, pv.ntiles = (int)tiles, pv.splitk = splits;
     pv.a_bytes = (unsigned)a_bytes, pv.b_bytes = (unsigned)b_bytes;
     pv.slab = nullptr;
-    static int slab_on = -1;
-    if (slab_on < 0) {
-        const char* e = getenv("A3T_GEMM_8P_TN_SLAB");       // 0: fp32 atomics straight from the accumulators (rounds 3-4)
-        slab_on = e ? atoi(e) : 1;
-    }
-    if (splits > 1 && slab_on) {
+    // K splits always leave through the slab + fold (the fp32-atomic epilogue of rounds 3-4 lost by 21 us per launch and left in
+    // round 6; a single split writes C directly in the mode the descriptor asks for)
+    if (splits > 1) {
         pv.slab = g8_slab(stream, (size_t)tiles * splits * 65536 * sizeof(float));
         if (!pv.slab) return (int)hipErrorOutOfMemory;
     }

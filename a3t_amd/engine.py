@@ -186,6 +186,7 @@ class MLMEngine:
         self._wg_group = 4 if (self.bf16 and self.side is not None and self._depth >= 8 and
                                os.environ.get("A3T_WGRAD_GROUP", "1") != "0") else 1
         self._wg_pending = []
+        self._wg_slots = set()
         self._gm_ready = None
         self._arena = {k: dict(buf=None, used=0, slots={}, dtype=dt) for k, dt in
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
@@ -521,6 +522,7 @@ class MLMEngine:
         alone has 16-20 K-tiles per workgroup.  A3T_WGRAD_GROUP=0: one launch each."""
         if self._wg_group > 1:
             self._wg_pending.append((dy, x, dW, 1.0))
+            self._wg_slots.add(self._par)       # the scratch set its operands may live in (tmp.gm / tmp.dg / tmp.dqkv of this sub-layer)
             if len(self._wg_pending) >= self._wg_group:
                 self._wg_flush()
             return
@@ -528,9 +530,18 @@ class MLMEngine:
 
     def _wg_flush(self):
         items, self._wg_pending = self._wg_pending, []
+        slots, self._wg_slots = self._wg_slots, set()
         if items:
             cmp = self.cmp
             self._side(lambda: ops.linear_bwd_weight_group(items, compute=cmp))
+            # A collected gradient may be handed over AFTER its sub-layer ended: the slot event _sub_end recorded then does
+            # not cover this launch.  Re-record the event of every scratch set the group reads, behind the group (ADVICE r5:
+            # with A3T_SIDE_DEPTH=8 the main stream could otherwise reuse tmp.gm.{slot} under the group kernel).
+            if self.side is not None:
+                for sl in slots:
+                    ev = self._owned_event(("slot", sl))
+                    ev.record(self.side)
+                    self._side_ev[sl] = ev
 
     def join_side(self):
         """Make the current stream wait for every weight gradient issued so far (for on_group_done hooks that read gradients)."""

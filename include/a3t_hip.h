@@ -392,6 +392,10 @@ int a3t_gemm_tn3_group(const a3t_gemm_desc* d, int n, void* stream);
  * folds (attention.py:64-96 is associative in the keys once every range uses the block's one reference maximum); 0 = one
  * workgroup per block always; -1 = re-read A3T_ATTN_SPLIT.  Returns the previous mode. */
 int a3t_attn_split_mode(int mode);
+/* The library's grow-only device workspaces (the split-K slabs of the weight-gradient kernels, one per (device, stream), at most
+ * 16 cached; the key-split workspace of the fused attention forward, one per device) are drained and freed; the next launch that
+ * needs one allocates it again.  For a host that destroys streams or wants the memory back between jobs.  Returns 0. */
+int a3t_release_workspaces(void);
 
 #ifdef __cplusplus
 }

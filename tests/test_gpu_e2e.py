@@ -338,6 +338,42 @@ def test_bf16_schedule_side_stream_and_fused_dropout_match_serial_schedule():
         assert float(torch.nn.functional.cosine_similarity(g, ref, dim=0)) > 0.999999
 
 
+def test_grouped_weight_gradients_on_a_shallow_scratch_ring_match_single_launches(monkeypatch):
+    """ADVICE r5 (engine.py:516): collected Linear weight gradients are handed over after their sub-layer ended; with the
+    shallowest ring that still groups (A3T_SIDE_DEPTH=8) the main stream reuses a scratch set 8 sub-layers later and must
+    wait for the GROUP launch that reads it, not only for the work issued inside the sub-layer.  16 blocks = 80 sub-layers:
+    ten laps of the ring; dropout on so that the operands live in tmp.gm / tmp.dg.  Equal to one launch per gradient."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.init import xavier_init_
+    from a3t_amd.params import ParamStore
+    from a3t_amd.collate import synthetic_batch
+    c = A3TConfig(adim=384, heads=2, ff=768, enc_blocks=8, dec_blocks=8, postnet_layers=3, postnet_chans=64, vocab=40,
+                  dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
+    store = ParamStore(c, DEV)
+    xavier_init_(store, seed=3, bn_gamma=1.0)
+    batch = synthetic_batch(c, 8, 512, 64, seed=7, device=DEV)
+    grads = []
+    for depth, group in (("8", "1"), ("48", "0"), ("8", "1")):
+        monkeypatch.setenv("A3T_SIDE_DEPTH", depth)
+        monkeypatch.setenv("A3T_WGRAD_GROUP", group)
+        eng = MLMEngine(c, store, compute="bf16", training=True, dropout=True)
+        assert eng._wg_group == (4 if group == "1" else 1) and eng._depth == int(depth)
+        eng.step_seed = 9
+        store.zero_grad()
+        loss = float(eng.forward(batch)["loss"])
+        eng.backward()
+        torch.cuda.synchronize()
+        grads.append((loss, store.grad.clone()))
+        del eng
+    assert grads[0][0] == grads[1][0]
+    ref = grads[1][1]
+    for loss, g in (grads[0], grads[2]):
+        err = float((g - ref).abs().max() / ref.abs().max())
+        assert err < 2e-4, err
+        assert float(torch.nn.functional.cosine_similarity(g, ref, dim=0)) > 0.999999
+
+
 def test_trainer_overlapped_allreduce_plumbing_single_rank_rccl():
     """The data-parallel step on real RCCL with a 1-rank group: bucketed all-reduce on its own stream, fired from
     the backward hooks after the engine's side stream has drained.  A 1-rank SUM is the identity, so the reduced
