@@ -60,13 +60,12 @@ _SIGS = {
     "a3t_relpos_softmax_bwd": [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P,
                                c_float, c_int64, c_int64, ctypes.c_uint32, _P, _P],
     "a3t_attn_fwd_train": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
-                           c_int64, c_float, c_float, ctypes.c_uint32, _P],
+                           c_int64, c_float, c_float, ctypes.c_uint32, _P, _P, _P],
     "a3t_attn_scale_rows": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_attn_bwd_ds": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_float,
                         c_float, ctypes.c_uint32, _P],
     "a3t_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
-                     c_float, c_float, ctypes.c_uint32, _P],
-    "a3t_attn_delta": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int64, _P],
+                     c_float, c_float, ctypes.c_uint32, _P, _P, _P],
     "a3t_pwg_block": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_mask_fill": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
     "a3t_embed_finish_fwd": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_float, ctypes.c_uint32,

@@ -44,23 +44,17 @@ typedef unsigned short u16;
 struct AttnArgs {
     const u16* qu;        // (q + pos_bias_u)  [B*T][ldq], head h at column h*dk
     const u16* qv;        // (q + pos_bias_v)
+    const float* bu;      // optional pos_bias_u / pos_bias_v [H*dk] (fp32): qu / qv then hold q itself and the kernel forms
+    const float* bv;      // bf16(q + bias) as it loads its query fragments (= what a3t_add_pos_bias would have stored)
     const u16* k;         // keys   [B*T][ldkv]
     const u16* v;         // values [B*T][ldkv]
     const u16* pos;       // linear_pos(pos_emb) [T][ldp]
     const uint8_t* keymask;   // [B][T], 1 = valid key
     u16* ctx;             // out [B*T][ldo]
     float* lse;           // out [B][H][T]: log sum exp of the scaled scores (+inf for a fully masked row)
-    // backward only
-    const u16* dctx;      // [B*T][ldo]
-    const float* delta;   // [B][H][T]: sum_d dctx * ctx
-    u16* dqu;             // [B*T][ldq]
-    u16* dqvl;            // gradient of (q+v)[i] through the x < T half of the band
-    u16* dqvu;            // gradient of (q+v)[i+1] through the x > T half, written AT row i+1
-    u16* dbd;             // compact dBD [B][H][T][T] (input of the d linear_pos GEMM)
-    u16* dk;              // [B*T][lddkv]
-    u16* dv;
+    u16* dbd;             // (A3T_ATTN_TIMING builds: where the per-stage cycle stamps go)
     int B, H, T;
-    int64_t ldq, ldkv, ldp, ldo, lddkv;
+    int64_t ldq, ldkv, ldp, ldo;
     float scale;
     unsigned int drop_thr, drop_key;
     float drop_inv;
@@ -110,13 +104,31 @@ static void* g_attn_timing_buf = nullptr;      // a3t_attn_timing_buf(): where t
 //  from the generic address space makes the compiler emit a null check against src_shared_base that some instantiations
 //  fail to select -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base".)
 __device__ __forceinline__ unsigned lds_base(const void* smem0) { return (unsigned)(uintptr_t)LDS_AS(smem0); }
+// (M0 is written and consumed inside the one statement.  It cannot be declared as a clobber -- hipcc: "inline asm clobber list
+//  contains reserved registers: m0 ... may lead to undefined behaviour" -- so the kernels that call this use no other M0 consumer:
+//  no LDS-DMA builtin, s_movrel, sendmsg or GWS; the gfx950 compiler does not keep values in M0 across statements on its own.)
 __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff) {
     const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(r) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(r) : "memory");
 }
 __device__ __forceinline__ bf16x8 ld_frag_g(const u16* p, bool ok) {
     const u16* src = ok ? p : (const u16*)attn_zero_page;
     return *(const bf16x8*)src;
+}
+// query fragment with the positional bias added on the fly (attention.py:190-194: q + pos_bias_u / pos_bias_v): the bf16 q
+// values plus 8 consecutive fp32 biases, rounded to bf16 exactly as a3t_add_pos_bias rounds; rows outside the utterance stay zero
+__device__ __forceinline__ bf16x8 ld_frag_qb(const u16* p, bool ok, const float* bias8) {
+    const bf16x8 f = ld_frag_g(p, ok);
+    if (!bias8) return f;                               // (wave-uniform)
+    const uint4 u = __builtin_bit_cast(uint4, f);
+    const float4 b0 = *(const float4*)bias8, b1 = *(const float4*)(bias8 + 4);
+    uint4 o;
+    o.x = io_pack2(io_bf2f(u.x & 0xffff) + b0.x, io_bf2f(u.x >> 16) + b0.y);
+    o.y = io_pack2(io_bf2f(u.y & 0xffff) + b0.z, io_bf2f(u.y >> 16) + b0.w);
+    o.z = io_pack2(io_bf2f(u.z & 0xffff) + b1.x, io_bf2f(u.z >> 16) + b1.y);
+    o.w = io_pack2(io_bf2f(u.w & 0xffff) + b1.z, io_bf2f(u.w >> 16) + b1.w);
+    if (!ok) o = make_uint4(0, 0, 0, 0);
+    return __builtin_bit_cast(bf16x8, o);
 }
 // row-major [row][k] tile image with padded rows: this lane's 8 consecutive k of row `row`
 template <int RSB>
@@ -290,8 +302,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int off = 32 * kk + 8 * PI;
-        fqu[kk] = ld_frag_g(quB + (int64_t)i * p.ldq + off, i < T);
-        fqv[kk] = ld_frag_g(qvB + (int64_t)i * p.ldq + off, i < T);
+        fqu[kk] = ld_frag_qb(quB + (int64_t)i * p.ldq + off, i < T, p.bu ? p.bu + h * DK + off : nullptr);
+        fqv[kk] = ld_frag_qb(qvB + (int64_t)i * p.ldq + off, i < T, p.bv ? p.bv + h * DK + off : nullptr);
     }
     for (int sb = w; sb < NS; sb += 8) {
         const int jl = 32 * sb + (lane & 31);
@@ -306,7 +318,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
         if (16 * n >= Q0 + 128 && !upper) {
             upper = true;
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) fqv[kk] = ld_frag_g(qvB + (int64_t)(i + 1) * p.ldq + 32 * kk + 8 * PI, i + 1 < T);
+            for (int kk = 0; kk < KS; ++kk)
+                fqv[kk] = ld_frag_qb(qvB + (int64_t)(i + 1) * p.ldq + 32 * kk + 8 * PI, i + 1 < T,
+                                     p.bv ? p.bv + h * DK + 32 * kk + 8 * PI : nullptr);
         }
     };
     auto band_block = [&](int n) -> f32x4 {
@@ -630,9 +644,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int off = 16 * kk + 8 * lh;
-        fqu[kk] = ld_frag_g(quB + (int64_t)i * p.ldq + off, i < T);
-        fqvL[kk] = ld_frag_g(qvB + (int64_t)i * p.ldq + off, i < T);
-        fqvU[kk] = ld_frag_g(qvB + (int64_t)(i + 1) * p.ldq + off, i + 1 < T);
+        const float* bu8 = p.bu ? p.bu + h * DK + off : nullptr;
+        const float* bv8 = p.bv ? p.bv + h * DK + off : nullptr;
+        fqu[kk] = ld_frag_qb(quB + (int64_t)i * p.ldq + off, i < T, bu8);
+        fqvL[kk] = ld_frag_qb(qvB + (int64_t)i * p.ldq + off, i < T, bv8);
+        fqvU[kk] = ld_frag_qb(qvB + (int64_t)(i + 1) * p.ldq + off, i + 1 < T, bv8);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA (invisible to the compiler) and the fragment loads
     __syncthreads();
@@ -985,7 +1001,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 // =====================================================================================================================
 // Score gradients of the training path that keeps the forward's probabilities (a3t_attn_fwd_train):
 //   dP = dctx V^T on the matrix cores, dS = p (keep/(1-p_drop) dP - delta) scale with p = probs * rowscale and
-//   delta_i = dctx_i . ctx_i (a3t_attn_delta), written twice: row-major (operand of dK = dS^T (q+u) and d(q+u) = dS K) and
+//   delta_i = dctx_i . ctx_i (formed in the kernel when a query block's dctx / ctx fragments arrive), written twice: row-major (operand of dK = dS^T (q+u) and d(q+u) = dS K) and
 //   through the inverse legacy skew (attention.py:145-165) into the compact dBD matrix (operand of d(q+v) and d linear_pos).
 // It replaces the dprobs GEMM (a T x T write) and a3t_relpos_softmax_bwd (a T x T read): 480 MB per launch at configs[1] instead
 // of 800.  No state is carried along the keys (delta is known up front), so the unit of work is a strip of 128 queries x
@@ -995,7 +1011,7 @@ struct DsArgs {
     const u16* v;         // [B*T][ldkv], head h at column h*dk
     const u16* probs;     // [B][H][T][T] exp(s - m_ref)
     const float* rowscale;   // [B][H][T]
-    const float* delta;      // [B][H][T]
+    const u16* ctx;       // [B*T][ldo]: the forward's output; delta_i = dctx_i . ctx_i is formed in the kernel
     u16* ds;              // [B][H][T][T]
     u16* dbd;             // compact dBD, block (b, h) at b*dbd_bsb + h*dbd_bsh
     int B, H, T;
@@ -1073,23 +1089,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
     // chunks), dctx fragments, row factors.  (A macro, not a lambda: arrays handed to a lambda by reference end up in scratch.)
     static_assert(KT == 5, "ten named strip registers below");
     uint4 pr0, pr1, pr2, pr3, pr4, pr5, pr6, pr7, pr8, pr9;      // (named: an array that lives across the task loop stays in scratch)
-    bf16x8 in_fd[KS];
-    float in_rsc, in_dl;
+    bf16x8 in_fd[KS], in_fc[KS];
+    float in_rsc, in_dl = 0.f;
 #define A3T_DS_FETCH(P)                                                                                             \
     do {                                                                                                            \
         const int i_ = P##q0 + lr, cpr_ = 4 * P##nt, np_ = 32 * cpr_;                                               \
         const u16* prB_ = p.probs + (int64_t)P##bh * T * T;                                                         \
         const u16* dcB_ = p.dctx + ((int64_t)P##b * T) * p.ldo + P##h * DK;                                         \
+        const u16* cxB_ = p.ctx + ((int64_t)P##b * T) * p.ldo + P##h * DK;                                          \
         pr0 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, lane), pr1 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 64 + lane);         \
         pr2 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 128 + lane), pr3 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 192 + lane);  \
         pr4 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 256 + lane), pr5 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 320 + lane);  \
         pr6 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 384 + lane), pr7 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 448 + lane);  \
         pr8 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 512 + lane), pr9 = ds_ld_chunk(prB_, T, P##q0, P##J0, cpr_, np_, 576 + lane);  \
         if (fetch_rows) {       /* (wave-uniform: a new query block) */                                            \
-            _Pragma("unroll") for (int kk = 0; kk < KS; ++kk)                                                       \
+            _Pragma("unroll") for (int kk = 0; kk < KS; ++kk) {                                                     \
                 in_fd[kk] = ld_frag_g(dcB_ + (int64_t)i_ * p.ldo + 16 * kk + 8 * lh, i_ < T);                       \
+                in_fc[kk] = ld_frag_g(cxB_ + (int64_t)i_ * p.ldo + 16 * kk + 8 * lh, i_ < T);                       \
+            }                                                                                                       \
             in_rsc = i_ < T ? p.rowscale[(int64_t)P##bh * T + i_] * p.scale : 0.f;                                  \
-            in_dl = i_ < T ? p.delta[(int64_t)P##bh * T + i_] : 0.f;                                                \
         }                                                                                                           \
     } while (0)
 #define A3T_DS_PUT(u_, v_)                                                          \
@@ -1100,8 +1118,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
 
     // a workgroup walks a CONTIGUOUS range of tasks = the key strips of one query block after the other: the dctx fragments and
     // row factors are requested once per query block, not once per strip (193 MB less through the CU's address path per launch)
+    // XCD-contiguous: workgroup ids are dealt round-robin over the 8 XCDs, each with an L2 of its own; the workgroups of ONE XCD
+    // take neighbouring task ranges = the query blocks of the same few (b, h) and share their V tiles there.  (Round 6 measured
+    // what that is worth: FETCH_SIZE 514 MB against 538 MB per launch with workgroup id = range index, 182 against 184 us --
+    // profiles/r06_ds_map_ab.txt.  The V tiles were never the kernel's problem; the mapping stays because it costs nothing.)
+    int vb = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = vb & 7;
+        vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    }
     const int64_t tper = (ntasks + gridDim.x - 1) / gridDim.x;
-    int64_t task = (int64_t)blockIdx.x * tper;
+    int64_t task = (int64_t)vb * tper;
     const int64_t tend = task + tper < ntasks ? task + tper : ntasks;
     if (task >= tend) return;
 #ifdef A3T_DS_TIMING
@@ -1132,6 +1159,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         bf16x8 fd[KS];
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) fd[kk] = in_fd[kk];
+        if (fetch_rows) {       // a new query block: delta_i = dctx_i . ctx_i, the row term of the softmax backward (a lane holds
+            float sdl = 0.f;    // half of the row's d_k columns, its partner lane ^ 32 the other half)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const uint4 a4 = __builtin_bit_cast(uint4, in_fd[kk]), c4 = __builtin_bit_cast(uint4, in_fc[kk]);
+                sdl = __builtin_fmaf(io_bf2f(a4.x & 0xffff), io_bf2f(c4.x & 0xffff), sdl), sdl = __builtin_fmaf(io_bf2f(a4.x >> 16), io_bf2f(c4.x >> 16), sdl);
+                sdl = __builtin_fmaf(io_bf2f(a4.y & 0xffff), io_bf2f(c4.y & 0xffff), sdl), sdl = __builtin_fmaf(io_bf2f(a4.y >> 16), io_bf2f(c4.y >> 16), sdl);
+                sdl = __builtin_fmaf(io_bf2f(a4.z & 0xffff), io_bf2f(c4.z & 0xffff), sdl), sdl = __builtin_fmaf(io_bf2f(a4.z >> 16), io_bf2f(c4.z >> 16), sdl);
+                sdl = __builtin_fmaf(io_bf2f(a4.w & 0xffff), io_bf2f(c4.w & 0xffff), sdl), sdl = __builtin_fmaf(io_bf2f(a4.w >> 16), io_bf2f(c4.w >> 16), sdl);
+            }
+            in_dl = sdl + __shfl_xor(sdl, 32, 64);
+        }
         const float rsc = in_rsc, dl = in_dl;
         const unsigned int ibase = (unsigned int)(((int64_t)c_bh * T + i) * T);
         u16* dsB = p.ds + (int64_t)c_bh * T * T;
@@ -1248,7 +1287,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
     }
 #ifdef A3T_DS_TIMING
     if (lane == 0 && p.timing) {
-        unsigned long long* o = p.timing + ((int64_t)blockIdx.x * 4 + w) * 8;
+        unsigned long long* o = p.timing + ((int64_t)vb * 4 + w) * 8;
         for (int e = 0; e < 8; ++e) o[e] = tacc[e];
     }
 #endif
@@ -1270,29 +1309,6 @@ __device__ __forceinline__ void st4_bf16(u16* dst, float a, float b, float c, fl
     uint2 v2;
     v2.x = io_pack2(a, b), v2.y = io_pack2(c, d);
     *(uint2*)dst = v2;
-}
-
-// delta[b][h][i] = sum_d dctx[b*T+i][h*dk+d] * ctx[...]: one 64-lane wave per (row, head) pair group
-__global__ __launch_bounds__(256) void attn_delta_kernel(const u16* __restrict__ dctx, const u16* __restrict__ ctx,
-                                                         float* __restrict__ delta, int B, int H, int T, int dk,
-                                                         int64_t ldo) {
-    const int lane = threadIdx.x & 63;
-    const int64_t id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (b*T + i)*H + h
-    if (id >= (int64_t)B * T * H) return;
-    const int h = (int)(id % H);
-    const int64_t row = id / H;
-    const int b = (int)(row / T), i = (int)(row - (int64_t)b * T);
-    const u16* a = dctx + row * ldo + h * dk;
-    const u16* c = ctx + row * ldo + h * dk;
-    float s = 0.f;
-    for (int d0 = lane * 4; d0 < dk; d0 += 256) {
-        const uint2 x = *(const uint2*)(a + d0), y = *(const uint2*)(c + d0);
-        s += io_bf2f(x.x & 0xffff) * io_bf2f(y.x & 0xffff) + io_bf2f(x.x >> 16) * io_bf2f(y.x >> 16) +
-             io_bf2f(x.y & 0xffff) * io_bf2f(y.y & 0xffff) + io_bf2f(x.y >> 16) * io_bf2f(y.y >> 16);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) delta[((int64_t)b * H + h) * T + i] = s;
 }
 
 // Fold of the key-split tail blocks (launch_fwd16): O = sum of the parts' un-normalised sums, l likewise, both relative to
@@ -1477,17 +1493,18 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
 
 static bool attn_shape_ok(int dk, int T) { return dk % 32 == 0 && dk <= 192 && dk != 160 && T % 8 == 0 && T >= 8 && T <= 4096; }
 
-extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* probs, const float* rowscale, const float* delta,
+extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v, const void* probs, const float* rowscale,
                                void* ds, void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb,
                                int64_t dbd_bsh, float scale, float drop_p, uint32_t drop_key, void* stream) {
-    if (!attn_shape_ok(dk, T) || drop_p < 0.f || drop_p >= 1.f || !dctx || !v || !probs || !rowscale || !delta || !ds || !dbd)
+    if (!attn_shape_ok(dk, T) || drop_p < 0.f || drop_p >= 1.f || !dctx || !ctx || !v || !probs || !rowscale || !ds || !dbd)
         return A3T_EINVAL;
-    if (!al16(dctx) || !al16(v) || !al16(probs) || !al16(ds) || !al16(dbd) || ldo % 8 || ldkv % 8 || dbd_bsb % 8 || dbd_bsh % 8)
+    if (!al16(dctx) || !al16(ctx) || !al16(v) || !al16(probs) || !al16(ds) || !al16(dbd) || ldo % 8 || ldkv % 8 || dbd_bsb % 8 ||
+        dbd_bsh % 8)
         return A3T_EINVAL;
     if ((int64_t)B * H * T * T >= (1ll << 32)) return A3T_EINVAL;       // (the dropout counter is 32 bits, as in the forward)
     if (dbd_bsb == 0 && dbd_bsh == 0) dbd_bsb = (int64_t)H * T * T, dbd_bsh = (int64_t)T * T;
     DsArgs a = {};
-    a.dctx = (const u16*)dctx, a.v = (const u16*)v, a.probs = (const u16*)probs, a.rowscale = rowscale, a.delta = delta;
+    a.dctx = (const u16*)dctx, a.ctx = (const u16*)ctx, a.v = (const u16*)v, a.probs = (const u16*)probs, a.rowscale = rowscale;
     a.ds = (u16*)ds, a.dbd = (u16*)dbd, a.B = B, a.H = H, a.T = T, a.ldo = ldo, a.ldkv = ldkv, a.dbd_bsb = dbd_bsb, a.dbd_bsh = dbd_bsh;
     a.scale = scale;
     a.drop_thr = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u, a.drop_key = drop_key, a.drop_inv = 1.f / (1.f - drop_p);
@@ -1523,15 +1540,6 @@ extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* prob
     return (int)hipGetLastError();
 }
 
-extern "C" int a3t_attn_delta(const void* dctx, const void* ctx, float* delta, int B, int H, int T, int dk, int64_t ldo,
-                              void* stream) {
-    if (dk % 4 || ldo % 4) return A3T_EINVAL;
-    const int64_t n = (int64_t)B * T * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const u16*)dctx,
-                       (const u16*)ctx, delta, B, H, T, dk, ldo);
-    return (int)hipGetLastError();
-}
-
 #if defined(A3T_ATTN_TIMING) || defined(A3T_DS_TIMING)
 extern "C" void a3t_attn_timing_buf(void* ptr) { g_attn_timing_buf = ptr; }
 #endif
@@ -1559,14 +1567,15 @@ extern "C" int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y
 static int attn_fwd_impl(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
                          const uint8_t* keymask, void* ctx, float* lse, void* probs, void* probs_drop, float* rowscale, int B,
                          int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo, float scale, float drop_p,
-                         uint32_t drop_key, void* stream) {
+                         uint32_t drop_key, const float* bias_u, const float* bias_v, void* stream) {
     if (!attn_shape_ok(dk, T)) return A3T_EINVAL;
+    if ((bias_u == nullptr) != (bias_v == nullptr) || !al16(bias_u) || !al16(bias_v)) return A3T_EINVAL;
     if (!(al16(qu) && al16(qv) && al16(k) && al16(v) && al16(pos) && al16(ctx))) return A3T_EINVAL;
     if ((ldq % 8) || (ldkv % 8) || (ldp % 8) || (ldo % 4)) return A3T_EINVAL;
     if (drop_p < 0.f || drop_p >= 1.f) return A3T_EINVAL;
     AttnArgs a = {};
     a.qu = (const u16*)qu, a.qv = (const u16*)qv, a.k = (const u16*)k, a.v = (const u16*)v, a.pos = (const u16*)pos;
-    a.keymask = keymask, a.ctx = (u16*)ctx, a.lse = lse;
+    a.keymask = keymask, a.ctx = (u16*)ctx, a.lse = lse, a.bu = bias_u, a.bv = bias_v;
     a.probs = (u16*)probs, a.pdrop = (u16*)probs_drop, a.rowscale = rowscale;
 #ifdef A3T_ATTN_TIMING
     a.dbd = (u16*)g_attn_timing_buf;
@@ -1588,17 +1597,18 @@ static int attn_fwd_impl(const void* qu, const void* qv, const void* k, const vo
 extern "C" int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
                             const uint8_t* keymask, void* ctx, float* lse, int B, int H, int T, int dk, int64_t ldq,
                             int64_t ldkv, int64_t ldp, int64_t ldo, float scale, float drop_p, uint32_t drop_key,
-                            void* stream) {
+                            const float* bias_u, const float* bias_v, void* stream) {
     return attn_fwd_impl(qu, qv, k, v, pos, keymask, ctx, lse, nullptr, nullptr, nullptr, B, H, T, dk, ldq, ldkv, ldp, ldo, scale,
-                         drop_p, drop_key, stream);
+                         drop_p, drop_key, bias_u, bias_v, stream);
 }
 
 extern "C" int a3t_attn_fwd_train(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
                                   const uint8_t* keymask, void* ctx, float* lse, void* probs, void* probs_drop,
                                   float* rowscale, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp,
-                                  int64_t ldo, float scale, float drop_p, uint32_t drop_key, void* stream) {
+                                  int64_t ldo, float scale, float drop_p, uint32_t drop_key, const float* bias_u,
+                                  const float* bias_v, void* stream) {
     if (!probs || !rowscale || (drop_p > 0.f && !probs_drop) || (T % 8)) return A3T_EINVAL;
     if (((uintptr_t)probs & 7) || ((uintptr_t)probs_drop & 7)) return A3T_EINVAL;
     return attn_fwd_impl(qu, qv, k, v, pos, keymask, ctx, lse, probs, drop_p > 0.f ? probs_drop : nullptr, rowscale, B, H, T, dk, ldq,
-                         ldkv, ldp, ldo, scale, drop_p, drop_key, stream);
+                         ldkv, ldp, ldo, scale, drop_p, drop_key, bias_u, bias_v, stream);
 }

@@ -476,7 +476,8 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         return A3T_EINVAL;
     const bool keep = p.keep_out || p.keep_in;
     if (keep && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16)) return A3T_EINVAL;
-    if (p.c_dtype == A3T_BF16 && p.accumulate != A3T_ACC_STORE) return A3T_EINVAL;
+    // bf16 C accumulates only by plain read-modify-write (A3T_ACC_ADD, one launch per element at a time): no bf16 atomics
+    if (p.c_dtype == A3T_BF16 && p.accumulate != A3T_ACC_STORE && (p.accumulate != A3T_ACC_ADD || p.splitk > 1)) return A3T_EINVAL;
     const bool AK = (d->a_cs == 1), BKC = (d->b_cs == 1);
     if (!AK && d->a_rs != 1) return A3T_EINVAL;
     if (!BKC && d->b_rs != 1) return A3T_EINVAL;

@@ -54,10 +54,11 @@ typedef unsigned short u16;
 // not alias the tiles in flight): one full drain of the DMA queue at the top of every phase -- the counted waits of the schedule
 // never got to wait for anything (found in round 5 in the .s of both TN kernels: 7 "s_waitcnt vmcnt(0)" in the K loop; the
 // k-contiguous kernels, whose fragments are plain ds_read_b128, have none).  An asm DMA is invisible to that bookkeeping; the
-// kernels wait for it themselves (counted vmcnt + s_barrier, as written).  M0 is set in the same statement that uses it.
+// kernels wait for it themselves (counted vmcnt + s_barrier, as written).  M0 is set in the same statement that uses it; it cannot
+// be listed as a clobber (hipcc rejects reserved registers there), so the token-reduction kernels use no other M0 consumer.
 __device__ __forceinline__ unsigned g8_lds_base(const void* smem0) { return (unsigned)(uintptr_t)LDS_AS(smem0); }
 __device__ __forceinline__ void g8_dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
 #ifdef G8_TIMING

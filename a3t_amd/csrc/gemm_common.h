@@ -111,8 +111,9 @@ __device__ __forceinline__ void epilogue_store(const GP& p, int64_t zoff, int ro
     if (p.drop_inv > 0.f) v = rng_keep(p.drop_key, (unsigned int)idx, p.drop_thr) ? v * p.drop_inv : 0.f;
     v *= p.alpha;
     if (p.R && ks == 0) v += p.R[idx];
-    if (p.c_dtype == A3T_BF16) {
-        ((unsigned short*)p.C)[idx] = f2bf(v);
+    if (p.c_dtype == A3T_BF16) {     // (bf16 C: STORE or ADD -- one writer per element, read-modify-write in fp32)
+        unsigned short* c = (unsigned short*)p.C + idx;
+        *c = f2bf(p.accumulate == A3T_ACC_STORE ? v : v + bf2f(*c));
         return;
     }
     float* C = (float*)p.C;
@@ -163,10 +164,15 @@ __device__ __forceinline__ void epilogue_vec4(const GP& p, float4 v, int64_t idx
     }
     cs.x += v.x, cs.y += v.y, cs.z += v.z, cs.w += v.w;
     if (p.c_dtype == A3T_BF16) {
+        uint2* c = (uint2*)((unsigned short*)p.C + idx);
+        if (p.accumulate != A3T_ACC_STORE) {     // A3T_ACC_ADD on a bf16 tensor: the sum is formed in fp32 and rounded once
+            const uint2 t = *c;                  // (`cs`, the fused column sum, has taken the increment alone above)
+            v.x += bf2f(t.x & 0xffff), v.y += bf2f(t.x >> 16), v.z += bf2f(t.y & 0xffff), v.w += bf2f(t.y >> 16);
+        }
         uint2 o;
         o.x = io_pack2(v.x, v.y);
         o.y = io_pack2(v.z, v.w);
-        *(uint2*)((unsigned short*)p.C + idx) = o;
+        *c = o;
     } else {
         float* C = (float*)p.C + idx;
         if (p.accumulate == A3T_ACC_STORE) {

@@ -22,7 +22,7 @@ from typing import Dict
 import torch
 
 from . import ops
-from ._lib import ACC_ATOMIC, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
+from ._lib import ACC_ADD, ACC_ATOMIC, ACC_STORE, ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, BF16, F32
 from .config import A3TConfig
 from .params import ParamStore
 
@@ -628,9 +628,16 @@ class MLMEngine:
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
         qkv = self._act(tag + ".qkv", (M, 3 * d))
         ops.linear_fwd(y, self.W(pre + ".wqkv"), qkv, bias=p[pre + ".bqkv"], compute=cmp)
-        qu = self._act(tag + ".qu", (M, d))
-        qv = self._act(tag + ".qv", (M, d))
-        ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
+        # q + pos_bias_u / q + pos_bias_v (attention.py:190-194): the fused kernels add the biases as they load their query
+        # fragments (bit for bit what a3t_add_pos_bias stores); the two [M][d] tensors only exist for the materialised forward and,
+        # in the backward, as operands of the dK / d linear_pos products (made there, off the main stream)
+        fused = (self._fused_now or self._fused_train_now) and ops.attn_fused_supported(dk, T)
+        pbias = (p[pre + ".u"], p[pre + ".v"])
+        qu = qv = None
+        if not fused:
+            qu = self._act(tag + ".qu", (M, d))
+            qv = self._act(tag + ".qv", (M, d))
+            ops.add_pos_bias(qkv, pbias[0], pbias[1], qu, qv)
         P = getattr(self, "_P_ahead", {}).get(tag)
         if P is not None:       # projected ahead on the side stream (forward())
             ev = self._pos_ev.get(tag[:3]) if self._pos_ev else None
@@ -644,7 +651,8 @@ class MLMEngine:
             adr = self._drop(c.attention_dropout_rate, tag + ".att")
             ctx = self._act(tag + ".ctx", (M, d))
             lse = self.ws.get(tag + ".lse", (B, H, T))
-            ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=adr or (0.0, 0))
+            ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=adr or (0.0, 0),
+                         pos_bias=pbias if qu is None else None)
             xo = self.ws.get(tag + ".xo", (M, d))
             ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
                            drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, d))
@@ -662,7 +670,7 @@ class MLMEngine:
             lse = self.ws.get(tag + ".lse", (B, H, T))
             rs = self.ws.get(tag + ".rs", (B, H, T))
             ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk),
-                               drop=adr or (0.0, 0))
+                               drop=adr or (0.0, 0), pos_bias=pbias if qu is None else None)
             xo = self.ws.get(tag + ".xo", (M, d))
             ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
                            drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, d))
@@ -743,14 +751,20 @@ class MLMEngine:
         # (independent of the dprobs -> softmax-backward chain: runs beside it on the side stream)
         if rs is not None and not self._attn_small_side:
             ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
+        make_q = qu is None        # fused forward: (q+u), (q+v) were never stored -- the dK product (second side stream, below) and
+        if make_q:                 # the gradient of linear_pos (first side stream) read them: made on the second side stream
+            qu = self._act("tmp.qu", (M, d))                  # (read on that stream only, in order)
+            qv = self._act(self._t("tmp.qv"), (M, d))         # (read by the other side stream, whenever it gets there)
 
         def dv_gemm():
+            if make_q:
+                ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
             if rs is not None and self._attn_small_side:
                 ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
             ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                      batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
                      compute=cmp, colsum=sl[3 * d:] if fz else None, **csk)
-        self._side(dv_gemm, urgent=True)
+        qv_ready = self._side(dv_gemm, want_event=make_q, urgent=True)
         zbd = zb
         if self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
@@ -759,13 +773,13 @@ class MLMEngine:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
         if ds_fused:
-            delta = self.ws.get("tmp.attn.delta", (B, H, T))
-            ops.attn_delta(dctx, ctx, delta, B, H, T)
-            ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0))
+            ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0))
         else:
             ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
                                    drop_p=adr[0] if adr else 0.0, drop_key=adr[1] if regen else 0, rowscale=rs)
         def pos_weight_grad():   # dP_h += sum_b dbd^T (q+v) -> d W_pos; only the side stream touches tmp.dP*
+            if qv_ready is not None and self.side is not None:
+                qv_ready.wait_on(self.side)
             dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
             ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
                      c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
@@ -775,18 +789,24 @@ class MLMEngine:
                 dP = dP16
             ops.linear_bwd_weight(dP, pos, gr[pre + ".wpos"], compute=cmp)
         self._side(pos_weight_grad)
-        dqu = self._act("tmp.dqu", (M, d))
-        dqv = self._act("tmp.dqv", (M, d))
+        # bf16 path: dq = d(q+u) + d(q+v) goes straight into the q third of dqkv -- the first product stores, the second adds (sum
+        # in fp32, one rounding); pos_bias_u / pos_bias_v / linear_q.bias take their gradients from the products' own column sums.
+        # fp32 path: both products are kept (their plain column sums are the bias gradients) and added by a3t_add_pos_bias_bwd.
+        dq_acc = fz
+        dqu = dqkv if dq_acc else self._act("tmp.dqu", (M, d))
+        dqv = dqkv if dq_acc else self._act("tmp.dqv", (M, d))
+        ldq, cbq = (3 * d, (T * 3 * d, dk)) if dq_acc else (d, (T * d, dk))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
-        ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, d, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp, colsum=sl if fz else None, **csk)
+        ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zb,
+                 b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl if fz else None, **csk)
         dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
                                               a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
                                               colsum=sl[2 * d:] if fz else None, **csk), want_event=True, urgent=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
-        ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
-                 c_bs=(T * d, dk), compute=cmp, colsum=sl[d:] if fz else None, **csk)
-        ops.add_pos_bias_bwd(dqu, dqv, dqkv)      # (the dq slice only)
+        ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, ldq, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
+                 c_bs=cbq, acc=ACC_ADD if dq_acc else ACC_STORE, compute=cmp, colsum=sl[d:] if fz else None, **csk)
+        if not dq_acc:
+            ops.add_pos_bias_bwd(dqu, dqv, dqkv)      # (the dq slice only)
         if dk_done is not None:      # the dV / dK slices of dqkv and their column sums come from the side stream
             dk_done.wait_on(torch.cuda.current_stream())
         if fz:   # d u, d v, d b_q = d u + d v, d b_k, d b_v from the slot sums (all four GEMMs have drained here); feeds nothing

@@ -333,31 +333,43 @@ def attn_fused_supported(dk, T):
     return dk % 32 == 0 and dk <= 192 and dk != 160 and T % 8 == 0 and 8 <= T <= 4096
 
 
-def attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=(0.0, 0)):
+def _attn_q_operands(qu, qv, qkv, pos_bias):
+    """(qu pointer, qv pointer, ldq, bias_u pointer, bias_v pointer): with pos_bias = (pos_bias_u, pos_bias_v) the kernel reads q
+    itself (first d columns of qkv) and adds the biases as it loads its query fragments; qu / qv are then not needed."""
+    d = qkv.shape[1] // 3
+    if pos_bias is None:
+        return _ptr(qu), _ptr(qv), d, None, None
+    return _ptr(qkv), _ptr(qkv), 3 * d, _ptr(pos_bias[0]), _ptr(pos_bias[1])
+
+
+def attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=(0.0, 0), pos_bias=None):
     """Fused legacy rel-pos attention forward: ctx[b, :, h, :] = dropout(softmax(((q+u) k^T + shift((q+v) P^T)) * scale)) v.
-    qu / qv / ctx [B*T][d], qkv [B*T][3d] (q | k | v), P [T][d], all bf16; lse [B][H][T] fp32."""
-    d = qu.shape[1]
+    qu / qv / ctx [B*T][d], qkv [B*T][3d] (q | k | v), P [T][d], all bf16; lse [B][H][T] fp32.
+    pos_bias=(u, v) (fp32 [d]): qu / qv may be None, q + u / q + v are formed inside the kernel."""
+    d = qkv.shape[1] // 3
     dk = d // H
     kk = qkv.view(-1)[d:]
     vv = qkv.view(-1)[2 * d:]
-    L.check(L.load().a3t_attn_fwd(_ptr(qu), _ptr(qv), _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(ctx), _ptr(lse),
-                                  B, H, T, dk, d, 3 * d, d, d, scale, drop[0], drop[1], _stream()), "attn_fwd")
+    pqu, pqv, ldq, pbu, pbv = _attn_q_operands(qu, qv, qkv, pos_bias)
+    L.check(L.load().a3t_attn_fwd(pqu, pqv, _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(ctx), _ptr(lse),
+                                  B, H, T, dk, ldq, 3 * d, d, d, scale, drop[0], drop[1], pbu, pbv, _stream()), "attn_fwd")
 
 
-def attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, probs_drop, rowscale, B, H, T, scale, drop=(0.0, 0)):
+def attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, probs_drop, rowscale, B, H, T, scale, drop=(0.0, 0), pos_bias=None):
     """a3t_attn_fwd for training steps: also stores un-normalised probabilities (probs, probs_drop [B][H][T][T] bf16) and
     rowscale [B][H][T] = 1 / row sum for the materialised backward."""
-    d = qu.shape[1]
+    d = qkv.shape[1] // 3
     dk = d // H
     kk = qkv.view(-1)[d:]
     vv = qkv.view(-1)[2 * d:]
+    pqu, pqv, ldq, pbu, pbv = _attn_q_operands(qu, qv, qkv, pos_bias)
     e0 = None
     if PROFILE is not None:      # bench.py: the fused attention forward sits in the per-kernel table next to the GEMMs
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(L.load().a3t_attn_fwd_train(_ptr(qu), _ptr(qv), _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(ctx), _ptr(lse),
-                                        _ptr(probs), _ptr(probs_drop), _ptr(rowscale), B, H, T, dk, d, 3 * d, d, d, scale,
-                                        drop[0], drop[1], _stream()), "attn_fwd_train")
+    L.check(L.load().a3t_attn_fwd_train(pqu, pqv, _ptr(kk), _ptr(vv), _ptr(P), _ptr(keymask), _ptr(ctx), _ptr(lse),
+                                        _ptr(probs), _ptr(probs_drop), _ptr(rowscale), B, H, T, dk, ldq, 3 * d, d, d, scale,
+                                        drop[0], drop[1], pbu, pbv, _stream()), "attn_fwd_train")
     if e0 is not None:
         e1.record()
         PROFILE.append((f"attn_fwd32_kernel<{dk // 32}, {'true' if drop[0] > 0 else 'false'}, true>", 3 * 2.0 * B * H * T * T * dk, e0, e1,
@@ -369,19 +381,15 @@ def attn_scale_rows(x, rowscale, y, B, H, T):
     L.check(L.load().a3t_attn_scale_rows(_ptr(x), _ptr(rowscale), _ptr(y), B, H, T, d // H, _stream()), "attn_scale_rows")
 
 
-def attn_bwd_ds(dctx, qkv, probs, rowscale, delta, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=False):
-    """dS and the compact dBD from the saved un-normalised probabilities of attn_fwd_train (dP = dctx V^T is never stored):
-    replaces the dprobs GEMM + relpos_softmax_bwd.  qkv: [B*T, 3d], V in columns 2d..3d."""
+def attn_bwd_ds(dctx, ctx, qkv, probs, rowscale, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=False):
+    """dS and the compact dBD from the saved un-normalised probabilities of attn_fwd_train (dP = dctx V^T is never stored; the row
+    term delta = dctx . ctx is formed in the kernel): replaces the dprobs GEMM + relpos_softmax_bwd.  qkv: [B*T, 3d], V in
+    columns 2d..3d; ctx: the forward's output [B*T, d]."""
     d = dctx.shape[1]
     v = qkv.view(-1)[2 * d:]
     bsb, bsh = ((T * T, B * T * T) if dbd_head_major else (0, 0))
-    L.check(L.load().a3t_attn_bwd_ds(_ptr(dctx), _ptr(v), _ptr(probs), _ptr(rowscale), _ptr(delta), _ptr(ds), _ptr(dbd), B, H, T,
+    L.check(L.load().a3t_attn_bwd_ds(_ptr(dctx), _ptr(ctx), _ptr(v), _ptr(probs), _ptr(rowscale), _ptr(ds), _ptr(dbd), B, H, T,
                                      d // H, d, 3 * d, bsb, bsh, scale, drop[0], drop[1], _stream()), "attn_bwd_ds")
-
-
-def attn_delta(dctx, ctx, delta, B, H, T):
-    d = ctx.shape[1]
-    L.check(L.load().a3t_attn_delta(_ptr(dctx), _ptr(ctx), _ptr(delta), B, H, T, d // H, d, _stream()), "attn_delta")
 
 
 def mask_fill(speech, masked, mask_feature, out):

@@ -220,6 +220,9 @@ int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprob
  *   lse out [B][H][T] fp32: log sum_j exp(scaled score) per query (+inf for a fully masked row), kept for backward.
  * drop_p / drop_key: attention dropout with the same counter RNG and element index ((b*H+h)*T+i)*T+j as
  * a3t_relpos_softmax_fwd's probs_drop.  dk in {32, 64, 96, 128, 192}, T % 8 == 0; A3T_EINVAL otherwise.
+ * bias_u / bias_v (both or neither; fp32 [H*dk], 16-byte aligned): qu and qv then both point at q itself (e.g. the first d
+ * columns of the fused q|k|v projection, ldq = 3d) and the kernel forms bf16(q + pos_bias_u) / bf16(q + pos_bias_v) as it loads
+ * its query fragments -- bit for bit what a3t_add_pos_bias stores, without the two [B*T][d] tensors (attention.py:190-194).
  * STREAM CONTRACT (a3t_attn_fwd, a3t_attn_fwd_train, a3t_attn_split_mode): the overflow ("redo") flags and the key-split
  * partial-sum workspace are ONE set per device, and the workspace is (re)allocated with hipMalloc when a launch needs more
  * than any launch before it.  All fused-attention forward launches on a device must therefore be issued on one stream, or
@@ -227,7 +230,7 @@ int a3t_relpos_softmax_bwd(const void* probs, int probs_dtype, const void* dprob
  * DEVICES are independent.  Every other entry point of this header keeps no state between calls. */
 int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, const void* pos, const uint8_t* keymask,
                  void* ctx, float* lse, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo,
-                 float scale, float drop_p, uint32_t drop_key, void* stream);
+                 float scale, float drop_p, uint32_t drop_key, const float* bias_u, const float* bias_v, void* stream);
 
 /* The same forward for TRAINING steps whose backward runs on materialised probabilities (a3t_relpos_softmax_bwd + the
  * batched GEMMs): besides ctx / lse it stores, per score, probs = exp(s - m_ref) (bf16, UN-normalised: the reference
@@ -238,23 +241,21 @@ int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, c
 int a3t_attn_fwd_train(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
                        const uint8_t* keymask, void* ctx, float* lse, void* probs, void* probs_drop, float* rowscale,
                        int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo, float scale,
-                       float drop_p, uint32_t drop_key, void* stream);
+                       float drop_p, uint32_t drop_key, const float* bias_u, const float* bias_v, void* stream);
 /* y[r][h*dk + c] = x[r][h*dk + c] * rowscale[(b*H + h)*T + i], r = b*T + i: folds the row normalisation of
  * a3t_attn_fwd_train's probabilities into the dctx operand of dV = probs_drop^T dctx (attention.py:96 backward). */
 int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y, int B, int H, int T, int dk, void* stream);
 /* Score gradients from a3t_attn_fwd_train's saved probabilities in ONE launch (the backward of attention.py:64-96, 145-209
  * between dctx and the two T x T operands of the remaining GEMMs): dP = dctx V^T is formed tile by tile on the matrix cores and
  * never stored;  ds[b][h][i][j] = probs * rowscale[i] * (keep_ij / (1 - drop_p) * dP_ij - delta[i]) * scale  (keep from the counter
- * RNG with the forward's key and index; delta from a3t_attn_delta);  dbd = the same values in the compact dBD layout of
+ * RNG with the forward's key and index; delta[i] = dctx_i . ctx_i = sum_j dP_ij P_ij, the row term of the softmax backward,
+ * attention.py:86, formed in the kernel from the forward's output ctx, row stride ldo);  dbd = the same values in the compact dBD layout of
  * a3t_relpos_softmax_bwd (block (b, h) at b*dbd_bsb + h*dbd_bsh elements, both 0 = [B][H][T][T]; every entry is written).
  * Replaces the dprobs GEMM + a3t_relpos_softmax_bwd of the materialised backward.  dctx row stride ldo, v row stride ldkv
  * (head h at column h*dk), dk % 32 == 0 (<= 192, not 160), T % 8 == 0. */
-int a3t_attn_bwd_ds(const void* dctx, const void* v, const void* probs, const float* rowscale, const float* delta, void* ds,
+int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v, const void* probs, const float* rowscale, void* ds,
                     void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb, int64_t dbd_bsh,
                     float scale, float drop_p, uint32_t drop_key, void* stream);
-/* delta[b][h][i] = sum_d dctx * ctx (= sum_j dP_ij P_ij, with or without dropout): the row term of the softmax backward
- * (attention.py:86 backward) that a3t_attn_bwd_ds subtracts.  dctx / ctx row stride ldo, head h at column h*dk. */
-int a3t_attn_delta(const void* dctx, const void* ctx, float* delta, int B, int H, int T, int dk, int64_t ldo, void* stream);
 
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
 int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,

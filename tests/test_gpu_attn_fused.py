@@ -440,12 +440,11 @@ def test_score_gradients_from_saved_probabilities_in_one_launch(B, H, T, dk, len
     ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, scale, drop=drop)
     g = torch.Generator(device="cpu").manual_seed(T + dk)
     dctx = torch.randn(B * T, d, generator=g).to(DEV).bfloat16()
-    delta = torch.zeros(B, H, T, device=DEV)
-    ops.attn_delta(dctx, ctx, delta, B, H, T)
+    delta = (dctx.double() * ctx.double()).view(B, T, H, dk).sum(-1).transpose(1, 2)      # the row term the kernel forms itself
     ds = torch.full((B, H, T, T), 3.0, device=DEV, dtype=torch.bfloat16)
     dshape = (H, B, T, T) if hm else (B, H, T, T)
     dbd = torch.full(dshape, 3.0, device=DEV, dtype=torch.bfloat16)
-    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=hm)
+    ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=hm)
     torch.cuda.synchronize()
     # definition in fp64
     v = qkv[:, 2 * d:].double().view(B, T, H, dk).transpose(1, 2)
@@ -455,7 +454,7 @@ def test_score_gradients_from_saved_probabilities_in_one_launch(B, H, T, dk, len
         keep = ((pdrop.float() != 0) | (probs.float() == 0)).double()
         dP = dP * keep / (1.0 - drop_p)
     pn = probs.double() * rs.double()[..., None]
-    want = pn * (dP - delta.double()[..., None]) * scale
+    want = pn * (dP - delta[..., None]) * scale
     got = ds.double()
     sc = max(1e-6, float(want.abs().max()))
     err = float((got - want).abs().max()) / sc
@@ -506,13 +505,11 @@ def test_score_gradient_kernel_is_deterministic_at_full_size(B, H, T, dk):
     ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, scale, drop=drop)
     del pdrop
     dctx = torch.randn(B * T, d, device=DEV).bfloat16()
-    delta = torch.zeros(B, H, T, device=DEV)
-    ops.attn_delta(dctx, ctx, delta, B, H, T)
     outs = []
     for _ in range(5):
         ds = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
         dbd = torch.zeros(H, B, T, T, device=DEV, dtype=torch.bfloat16)
-        ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
+        ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
         torch.cuda.synchronize()
         outs.append((ds, dbd))
     for ds, dbd in outs[1:]:

@@ -37,6 +37,8 @@ unit = 2.0 * B * H * T * T * dk
 res = {}
 res["fwd_fused_us"] = timeit(lambda: ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=DROP))
 res["fwd_materialised_us"] = timeit(lambda: _materialised(qkv, qu, qv, P, keymask, B, H, T, dk, DROP))
-res["bwd_delta_us"] = timeit(lambda: ops.attn_delta(dctx, ctx, delta, B, H, T))
+zu, zv = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+res["fwd_fused_bias_in_kernel_us"] = timeit(lambda: ops.attn_fwd(None, None, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=DROP, pos_bias=(zu, zv)))
+res["add_pos_bias_us"] = timeit(lambda: ops.add_pos_bias(qkv, zu, zv, qu, qv))
 res["fwd_tflops"] = 3 * unit / res["fwd_fused_us"] / 1e6
 print({k: round(v, 1) for k, v in res.items()})

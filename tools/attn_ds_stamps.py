@@ -25,7 +25,6 @@ rs = torch.zeros(B, H, T, device="cuda")
 ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, scale, drop=drop)
 dctx = torch.randn(M, d, device="cuda").bfloat16()
 delta = torch.zeros(B, H, T, device="cuda")
-ops.attn_delta(dctx, ctx, delta, B, H, T)
 ds = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
 dbd = torch.zeros(H, B, T, T, device="cuda", dtype=torch.bfloat16)
 lib = _lib.load()
@@ -34,7 +33,7 @@ lib.a3t_attn_timing_buf.restype = None
 buf = torch.zeros(512 * 4 * 8, dtype=torch.int64, device="cuda")
 lib.a3t_attn_timing_buf(buf.data_ptr())
 for _ in range(3):
-    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
+    ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
 torch.cuda.synchronize()
 t = buf.view(512 * 4, 8).double().cpu()
 tot = t.sum(1)

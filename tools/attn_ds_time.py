@@ -1,4 +1,4 @@
-"""Time a3t_attn_bwd_ds (+ a3t_attn_delta) against the two kernels it replaces (dprobs GEMM + a3t_relpos_softmax_bwd) at
+"""Time a3t_attn_bwd_ds against the two kernels it replaces (dprobs GEMM + a3t_relpos_softmax_bwd) at
 the benchmark shape.  usage: python tools/attn_ds_time.py [B H T dk]"""
 import math
 import os
@@ -32,8 +32,7 @@ zb = (H * T * T, T * T)
 
 
 def new():
-    ops.attn_delta(dctx, ctx, delta, B, H, T)
-    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
+    ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
 
 
 def old():
@@ -46,16 +45,12 @@ def old():
 x = torch.randn(4096, 4096, device="cuda")
 for _ in range(20):
     x @ x
-def delta_only():
-    ops.attn_delta(dctx, ctx, delta, B, H, T)
-
-
 def ds_only():
-    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
+    ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
 
 
 def ds_nodrop():
-    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=True)
+    ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=True)
 
 
 def gemm_only():
@@ -63,7 +58,7 @@ def gemm_only():
              c_bs=zb, compute=BF16)
 
 
-for name, fn in (("new", new), ("old", old), ("delta", delta_only), ("ds", ds_only), ("ds_nodrop", ds_nodrop), ("dprobs_gemm", gemm_only)):
+for name, fn in (("new", new), ("old", old), ("ds", ds_only), ("ds_nodrop", ds_nodrop), ("dprobs_gemm", gemm_only)):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

@@ -28,6 +28,5 @@ delta = torch.zeros(B, H, T, device="cuda")
 ds = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
 dbd = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
-    ops.attn_delta(dctx, ctx, delta, B, H, T)
-    ops.attn_bwd_ds(dctx, qkv, probs, rs, delta, ds, dbd, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
+    ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
 torch.cuda.synchronize()
