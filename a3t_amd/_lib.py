@@ -35,8 +35,6 @@ class GemmDesc(ctypes.Structure):
         ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("drop_key", ctypes.c_uint32),
         ("drop_p", c_float), ("colsum_ss", c_int32),
         ("keep_out", c_void_p), ("keep_in", c_void_p),
-        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_y", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
-        ("ln_eps", c_float), ("ln_y_dtype", c_int32),
     ]
 
 

@@ -1409,17 +1409,6 @@ extern "C" int a3t_attn_split_mode(int mode) {
     return old;
 }
 
-// A3T_ATTN_FWD=16: the rescaling 16-query kernel alone (round 2); default: the 32-query one-wave-per-SIMD kernel + the
-// 16-query kernel as its overflow fixup
-static int attn_fwd_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("A3T_ATTN_FWD");
-        mode = (e && !strcmp(e, "16")) ? 0 : 2;
-    }
-    return mode;
-}
-
 template <int NDB>
 static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     constexpr int TB = DT16<NDB>::BYTES;
@@ -1428,12 +1417,11 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     //  its second device without the raised LDS limit)
     const int nqb = (a.T + 127) / 128;
     const unsigned grid = (unsigned)(a.B * a.H * nqb);
-    const int mode = attn_fwd_mode();
     AttnArgs a16 = a;
-    // only the fixed-reference kernel can save probabilities: the training forward always takes it (A3T_ATTN_FWD=16 selects the
-    // kernel of forward-only passes)
+    // The 32-query one-wave-per-SIMD kernel with the rescaling 16-query kernel as its overflow fixup; beyond 2^16
+    // blocks (the overflow flags) the 16-query kernel alone.  Only the fixed-reference kernel can save probabilities.
     if (a.probs && grid > (1u << 16)) return A3T_EINVAL;
-    if ((mode == 2 || a.probs) && grid <= (1u << 16)) {
+    if (grid <= (1u << 16)) {
         constexpr int TB32 = DT32<NDB>::BYTES;
         constexpr int lds32 = 9 * TB32 + 4 * 32 * SC_LD * 4 + 136 * 4 + 4 * 2 * 2048;
         // One workgroup per CU and equal workgroups: the launch runs in ceil(grid / CUs) rounds and the last one may be mostly

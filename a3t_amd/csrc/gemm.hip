@@ -469,11 +469,6 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.keep_out = (unsigned char*)d->keep_out, p.keep_in = (const unsigned char*)d->keep_in;
     p.a_bytes = p.b_bytes = 0;
     p.slab = nullptr;
-    p.ln_g = d->ln_gamma, p.ln_b = d->ln_beta, p.ln_y = d->ln_y, p.ln_mean = d->ln_mean, p.ln_rstd = d->ln_rstd;
-    p.ln_eps = d->ln_eps, p.ln_y_dtype = d->ln_y_dtype;
-    if (p.ln_y && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16 || !p.ln_g || !p.ln_b || !p.ln_mean ||
-                   !p.ln_rstd || (p.ln_y_dtype != A3T_BF16 && p.ln_y_dtype != A3T_F32)))
-        return A3T_EINVAL;
     const bool keep = p.keep_out || p.keep_in;
     if (keep && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16)) return A3T_EINVAL;
     // bf16 C accumulates only by plain read-modify-write (A3T_ACC_ADD, one launch per element at a time): no bf16 atomics
@@ -526,7 +521,6 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         if (rc >= 0) return rc;                                   // -1: alignment contract not met
     }
     if (keep) return A3T_EINVAL;        // keep-bit images only exist in the 8-phase kernel
-    if (p.ln_y) return A3T_EINVAL;      // the fused LayerNorm only exists in the panel kernel
     if (d->colsum) return A3T_EINVAL;   // fused column sums live in the direct-to-LDS kernel's epilogue
     {
         const int ea = d->a_dtype == A3T_BF16 ? 2 : 4, eb = d->b_dtype == A3T_BF16 ? 2 : 4;

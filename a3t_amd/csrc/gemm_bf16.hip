@@ -499,7 +499,6 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
         const int rc = a3t_gemm_bf16_pn(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }
-    if (pv.ln_y) return A3T_EINVAL;       // the fused LayerNorm exists in the panel kernel only
     {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
         const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;

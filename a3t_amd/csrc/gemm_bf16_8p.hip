@@ -1301,7 +1301,7 @@ extern "C" int a3t_gemm_tn3_group(const a3t_gemm_desc* d, int n, void* stream_) 
         if (!e.A || !e.B || !e.C || e.M <= 0 || e.N <= 0 || e.K != K) return A3T_EINVAL;
         if (e.compute != A3T_BF16 || e.a_dtype != A3T_BF16 || e.b_dtype != A3T_BF16 || e.c_dtype != A3T_F32) return -1;
         if (e.a_rs != 1 || e.b_rs != 1 || e.taps > 1 || e.batch > 1 || e.Tseq > 0 || e.kshift) return -1;
-        if (e.bias || e.R || e.S || e.colsum || e.act != A3T_ACT_NONE || e.drop_p > 0.f || e.keep_in || e.keep_out || e.ln_y) return -1;
+        if (e.bias || e.R || e.S || e.colsum || e.act != A3T_ACT_NONE || e.drop_p > 0.f || e.keep_in || e.keep_out) return -1;
         if (e.M % 8 || e.N % 8 || e.a_cs % 8 || e.b_cs % 8 || (((uintptr_t)e.A | (uintptr_t)e.B | (uintptr_t)e.C) & 15)) return -1;
         const int64_t ab = (int64_t)K * e.a_cs * 2, bb = (int64_t)K * e.b_cs * 2;
         if (ab >= (1ll << 31) || bb >= (1ll << 31)) return -1;

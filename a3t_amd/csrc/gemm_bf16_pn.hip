@@ -60,8 +60,6 @@ constexpr int PN_ROWS = 160, PN_COLS = 384;
 constexpr int A_BYTES = PN_ROWS * 128, BH_BYTES = 192 * 128, BUF_BYTES = A_BYTES + 2 * BH_BYTES;   // 20 + 24 + 24 KiB
 constexpr int LDS_CSUM = 2 * BUF_BYTES;        // 384 fp32 column sums of the tile in flight
 constexpr int LDS_TOTAL = LDS_CSUM + PN_COLS * 4;                                                   // 140 800 B
-constexpr int LDS_LN = LDS_TOTAL;              // LN variant: [2][160 rows][4 wave columns] fp32 row partials
-constexpr int LDS_TOTAL_LN = LDS_LN + 2 * PN_ROWS * 4 * 4;                                          // 145 920 B
 constexpr unsigned OOB = 0x80000000u;         // voffset beyond every descriptor (host contract: operands < 2 GiB)
 
 __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes of a DPP row, result in every lane
@@ -73,7 +71,7 @@ __device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes
 }
 }   // namespace
 
-template <bool CONV, bool LN = false>
+template <bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, lane_ = lane;
@@ -119,7 +117,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
             if (tid < PN_COLS) cs_l[tid] = 0.f;
             __syncthreads();
         }
-        float rsum[5] = {0.f, 0.f, 0.f, 0.f, 0.f};       // LN: this lane's share (24 columns) of the five row sums
 #pragma unroll
         for (int jl = 0; jl < 3; ++jl) {
             const int nloc = wc * 96 + jl * 32 + g * 8, ncol = chunk * PN_COLS + nloc;
@@ -178,10 +175,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cs[e] += v[e];
-                    if (LN) {       // the finished row values stay in the accumulators for the LayerNorm below
-                        acc[i][jl] = f32x4{v[0], v[1], v[2], v[3]}, acc[i][3 + jl] = f32x4{v[4], v[5], v[6], v[7]};
-                        rsum[i] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-                    }
                     if (q->c_dtype == A3T_BF16) {
                         uint4 o;
                         o.x = io_pack2(v[0], v[1]), o.y = io_pack2(v[2], v[3]), o.z = io_pack2(v[4], v[5]), o.w = io_pack2(v[6], v[7]);
@@ -205,74 +198,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
         if (q->colsum) {
             __syncthreads();
             if (tid < PN_COLS && chunk * PN_COLS + tid < q->N) atomicAdd(q->colsum + chunk * PN_COLS + tid, q->colsum_scale * cs_l[tid]);
-        }
-        if (LN) {
-            // LayerNorm of the 160 finished rows (N == 384: the workgroup owns them whole; layer_norm.py:28-42, the two-pass
-            // mean / centred variance of a3t_layernorm_fwd).  A row lives in 4 lane groups x 4 wave columns: lanes fold over g,
-            // waves through LDS.
-            float* red = (float*)(smem + LDS_LN);
-            float mu[5], rstd[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                float t = rsum[i];
-                t += __shfl_xor(t, 16, 64);
-                t += __shfl_xor(t, 32, 64);
-                if (g == 0) red[(wr * 80 + i * 16 + fr) * 4 + wc] = t;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const float4 t = *(const float4*)(red + (wr * 80 + i * 16 + fr) * 4);
-                mu[i] = ((t.x + t.y) + (t.z + t.w)) * (1.0f / (float)PN_COLS);
-                float qs = 0.f;
-#pragma unroll
-                for (int j = 0; j < 6; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float dlt = acc[i][j][e] - mu[i];
-                        qs += dlt * dlt;
-                    }
-                qs += __shfl_xor(qs, 16, 64);
-                qs += __shfl_xor(qs, 32, 64);
-                if (g == 0) red[PN_ROWS * 4 + (wr * 80 + i * 16 + fr) * 4 + wc] = qs;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const float4 t = *(const float4*)(red + PN_ROWS * 4 + (wr * 80 + i * 16 + fr) * 4);
-                rstd[i] = 1.0f / sqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / (float)PN_COLS) + q->ln_eps);
-                const int m = tile * PN_ROWS + wr * 80 + i * 16 + fr;
-                if (wc == 0 && g == 0 && m < q->M) q->ln_mean[m] = mu[i], q->ln_rstd[m] = rstd[i];
-            }
-#pragma unroll
-            for (int jl = 0; jl < 3; ++jl) {
-                const int ncol = wc * 96 + jl * 32 + g * 8;
-                const float4 g0 = *(const float4*)(q->ln_g + ncol), g1 = *(const float4*)(q->ln_g + ncol + 4);
-                const float4 b0 = *(const float4*)(q->ln_b + ncol), b1 = *(const float4*)(q->ln_b + ncol + 4);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) {
-                    const int m = tile * PN_ROWS + wr * 80 + i * 16 + fr;
-                    const f32x4 lo = acc[i][jl], hi = acc[i][3 + jl];
-                    acc[i][jl] = f32x4{0.f, 0.f, 0.f, 0.f}, acc[i][3 + jl] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const float y0 = (lo[0] - mu[i]) * rstd[i] * g0.x + b0.x, y1 = (lo[1] - mu[i]) * rstd[i] * g0.y + b0.y;
-                    const float y2 = (lo[2] - mu[i]) * rstd[i] * g0.z + b0.z, y3 = (lo[3] - mu[i]) * rstd[i] * g0.w + b0.w;
-                    const float y4 = (hi[0] - mu[i]) * rstd[i] * g1.x + b1.x, y5 = (hi[1] - mu[i]) * rstd[i] * g1.y + b1.y;
-                    const float y6 = (hi[2] - mu[i]) * rstd[i] * g1.z + b1.z, y7 = (hi[3] - mu[i]) * rstd[i] * g1.w + b1.w;
-                    if (m < q->M) {
-                        const int64_t idx = (int64_t)m * PN_COLS + ncol;
-                        if (q->ln_y_dtype == A3T_BF16) {
-                            uint4 o;
-                            o.x = io_pack2(y0, y1), o.y = io_pack2(y2, y3), o.z = io_pack2(y4, y5), o.w = io_pack2(y6, y7);
-                            *(uint4*)((u16*)q->ln_y + idx) = o;
-                        } else {
-                            float* c = (float*)q->ln_y + idx;
-                            *(float4*)c = make_float4(y0, y1, y2, y3);
-                            *(float4*)(c + 4) = make_float4(y4, y5, y6, y7);
-                        }
-                    }
-                }
-            }
-            __syncthreads();        // `red` is free again before the next tile's epilogue
         }
     };
 
@@ -449,10 +374,6 @@ static bool pn_applicable(const GP& p, int batch, int ly) {
     if (p.bias && ((uintptr_t)p.bias & 15)) return false;
     const int64_t a_bytes = ((int64_t)p.M * p.a_rs) * 2, b_bytes = ((int64_t)p.N * p.b_rs) * 2;
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31) || (int64_t)p.M * p.c_rs >= (1ll << 32)) return false;
-    if (p.ln_y) {        // fused LayerNorm: whole rows in one workgroup, contiguous ln_y, aligned vectors
-        if (p.N != PN_COLS || (((uintptr_t)p.ln_y | (uintptr_t)p.ln_g | (uintptr_t)p.ln_b) & 15)) return false;
-        return true;
-    }
     if (mode == 3 && p.N != PN_COLS) return false;
     if (mode >= 2) {
         // Cost model fitted on MI355X (tools/probes/gemm_pn.hip, profiles/r03_pn_check.txt): a tile (panel x 384-column chunk) costs ~1.55 us per
@@ -493,15 +414,14 @@ extern "C" int a3t_gemm_pn_supported(int M, int N, int K, int taps, int flags) {
     if (flags & 8) p.keep_in = (const unsigned char*)dummy;
     if (flags & 32) p.colsum = dummy;
     if (flags & 64) p.S = dummy, p.s_dtype = A3T_BF16;
-    if (flags & 128) p.ln_y = dummy, p.ln_g = dummy, p.ln_b = dummy, p.ln_mean = dummy, p.ln_rstd = dummy, p.ln_y_dtype = A3T_BF16;
     return pn_applicable(p, 1, 0) ? 1 : 0;
 }
 
-template <bool CV, bool LN = false>
+template <bool CV>
 static void launch_pn(const GP& pv, int grid, hipStream_t stream) {
-    constexpr int lds = LN ? LDS_TOTAL_LN : LDS_TOTAL;
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_pn_kernel<CV, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((gemm_bf16_pn_kernel<CV, LN>), dim3(grid), dim3(512), lds, stream, pv);
+    constexpr int lds = LDS_TOTAL;
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_pn_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((gemm_bf16_pn_kernel<CV>), dim3(grid), dim3(512), lds, stream, pv);
 }
 
 // Called by a3t_gemm_bf16_glds after the alignment contract has been checked.  Returns -1 when not applicable.
@@ -515,18 +435,10 @@ int a3t_gemm_bf16_pn(const GP& p, int batch, int ly, hipStream_t stream) {
     pv.b_bytes = (unsigned)(((int64_t)p.N * p.b_rs) * 2);
     const int grid = panels < pn_cus() ? panels : pn_cus();
     const bool conv = p.taps > 1;
-    if (p.ln_y) {
-        if (conv)
-            launch_pn<true, true>(pv, grid, stream);
-        else
-            launch_pn<false, true>(pv, grid, stream);
-        a3t_note_kernel("gemm_bf16_pn_kernel<%s, true>", conv ? "true" : "false");
-        return (int)hipGetLastError();
-    }
     if (conv)
         launch_pn<true>(pv, grid, stream);
     else
         launch_pn<false>(pv, grid, stream);
-    a3t_note_kernel("gemm_bf16_pn_kernel<%s, false>", conv ? "true" : "false");
+    a3t_note_kernel("gemm_bf16_pn_kernel<%s>", conv ? "true" : "false");
     return (int)hipGetLastError();
 }

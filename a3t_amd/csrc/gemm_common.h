@@ -37,14 +37,6 @@ struct GP {
     unsigned int a_bytes, b_bytes;  // operand extents for the buffer descriptors
     float* slab;                    // token-reduction variant: split-K partial tiles (plain stores) for the deterministic fold
     int sole_writer;                // A3T_ACC_SOLE: the fold may add with plain read-modify-writes
-    // panel kernel (gemm_bf16_pn.hip), N == 384: LayerNorm of the finished output rows in the epilogue
-    const float* ln_g;
-    const float* ln_b;
-    void* ln_y;                     // [M][N] bf16 | fp32 (ln_y_dtype)
-    float* ln_mean;
-    float* ln_rstd;
-    float ln_eps;
-    int ln_y_dtype;
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return io_f2bf(f); }   // hardware RNE conversion

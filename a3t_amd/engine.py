@@ -192,11 +192,6 @@ class MLMEngine:
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
         self.colsum_slots = int(os.environ.get("A3T_COLSUM_SLOTS", "16"))   # spread of the attention bias-gradient atomics
         self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
-        # A3T_FUSE_LN_FWD=1 (opt-in): the GEMM that closes a sub-layer (x + a * dropout(branch), N = d = 384: panel kernel, a
-        # workgroup owns whole rows) also writes the NEXT sub-layer's LayerNorm (a3t_gemm_desc::ln_*).  Neutral inside the step
-        #  and it rounds in a different order, so it stays off.
-        self.fuse_ln_fwd = os.environ.get("A3T_FUSE_LN_FWD", "0") == "1"
-        self._ln_pending = None
         # bf16 mode: the first postnet conv reads `before` (log-mel scale, |x| ~ 4: one bf16 ulp = 0.03) whose rounding the
         # five BatchNorm'ed postnet layers amplify.  Its forward therefore runs on (hi, lo) = (bf16(x), bf16(x - hi)): two
         # K = 5*80 bf16 GEMMs carry `before` to ~2^-17 (max error of `after` 6.2e-2 -> 4.3e-2 of scale); gradients use hi only.
@@ -377,31 +372,9 @@ class MLMEngine:
     def _act(self, name, shape):
         return self.ws.get(name, shape, self.adt)
 
-    def _ln_fuse(self, ln_next, xo, K, taps=1, eps=1e-12):
-        """ln = (gamma, beta, y, mean, rstd, eps) for the GEMM that writes the residual stream xo, when that GEMM can also write
-        the LayerNorm the next sub-layer opens with (ln_next = (tag, parameter prefix, output dtype)); None otherwise."""
-        self._ln_pending = None
-        if ln_next is None or not (self.fuse_ln_fwd and self.bf16):
-            return None
-        tag, pre, odt = ln_next
-        p = self.store.p
-        M, D = xo.shape
-        g, b = p[pre + ".g"], p[pre + ".b"]
-        if D != 384 or (g.data_ptr() | b.data_ptr()) % 16 or not ops.gemm_pn_supported(M, D, K, taps, ops.PN_LN):
-            return None
-        y = self.ws.get(tag + ".y", (M, D), odt or self.adt)
-        mean = self.ws.get(tag + ".mean", (M,))
-        rstd = self.ws.get(tag + ".rstd", (M,))
-        self._ln_pending = (tag, xo, y, mean, rstd)
-        return (g, b, y, mean, rstd, eps)
-
     def _ln_fwd(self, tag, x, pre, eps=1e-12, out_dtype=None):
         p = self.store.p
         M, D = x.shape
-        pend, self._ln_pending = self._ln_pending, None
-        if pend is not None and pend[0] == tag and pend[1] is x:       # written by the GEMM that produced x
-            self.sv[tag] = (x, pend[2], pend[3], pend[4])
-            return pend[2]
         y = self.ws.get(tag + ".y", (M, D), out_dtype or self.adt)
         mean = self.ws.get(tag + ".mean", (M,))
         rstd = self.ws.get(tag + ".rstd", (M,))
@@ -564,7 +537,7 @@ class MLMEngine:
             torch.cuda.current_stream().wait_stream(self.side)
 
     # ------------------------------------------------------------------ FFN (MultiLayeredConv1d)
-    def _ffn_fwd(self, tag, pre, x, T, ln_next=None):
+    def _ffn_fwd(self, tag, pre, x, T):
         p, c = self.store.p, self.c
         M = x.shape[0]
         pad = (c.ff_kernel - 1) // 2
@@ -577,7 +550,7 @@ class MLMEngine:
                      drop=self._drop(c.dropout_rate, tag + ".h"), keep_out=keep)
         xo = self.ws.get(tag + ".xo", (M, c.adim))
         ops.conv_fwd(h, self.W(pre + ".w2"), xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=self.cmp,
-                     drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, c.ff_kernel * c.ff, c.ff_kernel))
+                     drop=self._drop(c.dropout_rate, tag + ".o"))
         self.sv[tag] = (y, h, keep)
         return xo
 
@@ -620,7 +593,7 @@ class MLMEngine:
         return g
 
     # ------------------------------------------------------------------ rel-pos self-attention
-    def _mha_fwd(self, tag, pre, x, pos, keymask, B, T, ln_next=None):
+    def _mha_fwd(self, tag, pre, x, pos, keymask, B, T):
         p, c = self.store.p, self.c
         d, H, dk = c.adim, c.heads, c.dk
         M = B * T
@@ -655,7 +628,7 @@ class MLMEngine:
                          pos_bias=pbias if qu is None else None)
             xo = self.ws.get(tag + ".xo", (M, d))
             ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
-                           drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, d))
+                           drop=self._drop(c.dropout_rate, tag + ".o"))
             self.sv[tag] = None          # forward-only pass: nothing is kept for a backward
             self.sv[tag + ".fused"] = True
             return xo
@@ -673,7 +646,7 @@ class MLMEngine:
                                drop=adr or (0.0, 0), pos_bias=pbias if qu is None else None)
             xo = self.ws.get(tag + ".xo", (M, d))
             ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
-                           drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, d))
+                           drop=self._drop(c.dropout_rate, tag + ".o"))
             self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos, pdrop)
             self.sv[tag + ".rs"] = rs
             return xo
@@ -699,7 +672,7 @@ class MLMEngine:
                  a_bs=(H * T * T, T * T), b_bs=(T * 3 * d, dk), c_bs=(T * d, dk), compute=cmp)
         xo = self.ws.get(tag + ".xo", (M, d))
         ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
-                       drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, d))
+                       drop=self._drop(c.dropout_rate, tag + ".o"))
         self.sv[tag] = (y, qkv, qu, qv, P, probs, ctx, pos, pdrop)
         return xo
 
@@ -847,7 +820,7 @@ class MLMEngine:
         ops.bn_act_bwd(dy, z, mean, rstd, p[pre + ".g"], p[pre + ".b"], sums, dz, gr[pre + ".g"], gr[pre + ".b"],
                        self.training, act, zero=False)
 
-    def _conv_fwd(self, tag, pre, x, T, ln_next=None):
+    def _conv_fwd(self, tag, pre, x, T):
         p, c = self.store.p, self.c
         M, d = x.shape
         cmp = self.cmp
@@ -861,7 +834,7 @@ class MLMEngine:
         self._bn_fwd(tag, z, pre + ".bn", pre + ".bn", ACT_SWISH, s)
         xo = self.ws.get(tag + ".xo", (M, d))
         ops.linear_fwd(s, self.W(pre + ".pw2"), xo, bias=p[pre + ".pb2"], R=x, compute=cmp,
-                       drop=self._drop(c.dropout_rate, tag + ".o"), ln=self._ln_fuse(ln_next, xo, d))
+                       drop=self._drop(c.dropout_rate, tag + ".o"))
         self.sv[tag] = (y, g2, glu, s)
         return xo
 
@@ -891,11 +864,11 @@ class MLMEngine:
 
     # ------------------------------------------------------------------ one Conformer block
     def block_fwd(self, pre, x, pos, keymask, B, T):
-        # (each sub-layer's closing GEMM writes the LayerNorm the next one opens with: encoder_layer.py:117-181)
-        x = self._ffn_fwd(pre + ".ffm", pre + ".ffm", x, T, ln_next=(pre + ".mha.ln", pre + ".mha.ln", None))
-        x = self._mha_fwd(pre + ".mha", pre + ".mha", x, pos, keymask, B, T, ln_next=(pre + ".cnv.ln", pre + ".cnv.ln", None))
-        x = self._conv_fwd(pre + ".cnv", pre + ".cnv", x, T, ln_next=(pre + ".ff.ln", pre + ".ff.ln", None))
-        x = self._ffn_fwd(pre + ".ff", pre + ".ff", x, T, ln_next=(pre + ".fin", pre + ".fin.ln", torch.float32))
+        # (encoder_layer.py:117-181)
+        x = self._ffn_fwd(pre + ".ffm", pre + ".ffm", x, T)
+        x = self._mha_fwd(pre + ".mha", pre + ".mha", x, pos, keymask, B, T)
+        x = self._conv_fwd(pre + ".cnv", pre + ".cnv", x, T)
+        x = self._ffn_fwd(pre + ".ff", pre + ".ff", x, T)
         return self._ln_fwd(pre + ".fin", x, pre + ".fin.ln", out_dtype=torch.float32)
 
     def block_bwd(self, pre, g, B, T):

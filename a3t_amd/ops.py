@@ -38,9 +38,8 @@ def _dt(t):
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
          act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
-         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, ln=None):
-    """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h.
-    ln = (gamma, beta, y, mean, rstd, eps): LayerNorm of the finished rows in the same epilogue (panel kernel, N == 384)."""
+         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None):
+    """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
@@ -63,9 +62,6 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.drop_p, d.drop_key = (drop if drop is not None else (0.0, 0))
     d.keep_out = keep_out.data_ptr() if keep_out is not None else None
     d.keep_in = keep_in.data_ptr() if keep_in is not None else None
-    if ln is not None:
-        d.ln_gamma, d.ln_beta, d.ln_y = ln[0].data_ptr(), ln[1].data_ptr(), ln[2].data_ptr()
-        d.ln_mean, d.ln_rstd, d.ln_eps, d.ln_y_dtype = ln[3].data_ptr(), ln[4].data_ptr(), ln[5], _dt(ln[2])
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -92,10 +88,10 @@ def _splitk_for(n_tiles, K, ktile=64):
 
 
 # ---- y = x W^T (+bias): torch.nn.Linear / 1x1 Conv1d -----------------------------------------
-def linear_fwd(x, W, out, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None, ln=None):
+def linear_fwd(x, W, out, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None):
     M, K = x.shape
     N = W.shape[0]
-    gemm(x, W, out, M, N, K, K, 1, K, 1, N, bias=bias, R=R, alpha=alpha, act=act, compute=compute, drop=drop, ln=ln)
+    gemm(x, W, out, M, N, K, K, 1, K, 1, N, bias=bias, R=R, alpha=alpha, act=act, compute=compute, drop=drop)
 
 
 def linear_bwd_data(dy, W, dx, S=None, alpha=1.0, acc=ACC_STORE, compute=F32, colsum=None):
@@ -153,15 +149,15 @@ def linear_bwd_weight_group(items, compute=F32):
 
 # ---- Conv1d over time as implicit-im2col GEMM; weights kept as Wk[N][taps][Cin] --------------
 def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None,
-             keep_out=None, keep_in=None, colsum=None, S=None, ln=None):
+             keep_out=None, keep_in=None, colsum=None, S=None):
     M, Cin = x.shape
     N, taps, _ = Wk.shape
     gemm(x, Wk, out, M, N, taps * Cin, Cin, 1, taps * Cin, 1, N, b_ts=Cin, bias=bias, R=R, taps=taps, pad=pad,
          dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute, drop=drop, keep_out=keep_out, keep_in=keep_in,
-         colsum=colsum, S=S, ln=ln)
+         colsum=colsum, S=S)
 
 
-G8_BIAS_ACT, G8_DROP, G8_KEEP_OUT, G8_KEEP_IN, G8_F32_OR_RES, G8_COLSUM, G8_SMASK, PN_LN = 1, 2, 4, 8, 16, 32, 64, 128
+G8_BIAS_ACT, G8_DROP, G8_KEEP_OUT, G8_KEEP_IN, G8_F32_OR_RES, G8_COLSUM, G8_SMASK = 1, 2, 4, 8, 16, 32, 64
 
 
 def gemm_8p_supported(M, N, K, taps=1, flags=0):

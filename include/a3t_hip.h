@@ -101,19 +101,6 @@ typedef struct a3t_gemm_desc {
                                             multi_layer_conv.py:52-63's hidden layer on its way back).  a3t_gemm fails with
                                             A3T_EINVAL when either is set and the 8-phase kernel does not take the problem:
                                             ask a3t_gemm_8p_supported first. */
-    /* Optional (panel kernel only, N == 384 = one workgroup owns whole output rows): LayerNorm of the finished rows of C
-     * (after bias / activation / dropout / alpha / residual) in the same epilogue -- the "x = x + sublayer(..)" GEMM of a
-     * Conformer block followed by the next sub-layer's norm (encoder_layer.py:117-181, layer_norm.py:28-42):
-     *   ln_y[m][n] = (C[m][n] - mean_m) * rstd_m * ln_gamma[n] + ln_beta[n],  ln_mean[m], ln_rstd[m] as a3t_layernorm_fwd writes them.
-     * a3t_gemm fails with A3T_EINVAL when ln_y is set and the panel kernel does not take the problem: ask
-     * a3t_gemm_pn_supported(.., flags | 128) first. */
-    const float* ln_gamma;
-    const float* ln_beta;
-    void* ln_y;
-    float* ln_mean;
-    float* ln_rstd;
-    float ln_eps;
-    int32_t ln_y_dtype;                /* A3T_BF16 | A3T_F32 */
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);

@@ -37,6 +37,10 @@ BF16_LOSS_RTOL = 1e-2
 # RMS error of the bf16 mel outputs, of the output scale.  north_star's 1e-2 holds on configs[1] (measured: before 5.1e-3, after
 # 9.7e-3) and on `before` of configs[3] (5.4e-3); `after` of the d=512 model is 1.2e-2 -- its five BatchNorm'ed postnet layers
 # amplify `before`'s error, and the oracle under bf16 autocast loses 1.6e-2 there.  Stated, not waived: the bound is 1.3e-2.
+# Round 6 (tools/postnet_floor.py, profiles/r06_postnet_floor.txt): the engine's bf16 `before` pushed through the ORACLE's exact fp32
+# postnet gives `after` rms 1.198e-2 against the engine's own 1.201e-2 (c4; c2 at B = 8: 1.124e-2 / 1.127e-2), while the postnet's
+# bf16 arithmetic on an exact `before` costs 1.2e-3: no postnet precision brings `after` under 1e-2 -- it is `before`'s 5.4e-3 times
+# the gain (~2.2) of five BatchNorm'ed layers, i.e. the bf16 operands of the twelve Conformer blocks.
 BF16_MEL_RMS = {"c2": dict(before=1e-2, after=1e-2), "c4": dict(before=1e-2, after=1.3e-2)}
 # ONE rule for every gradient tensor, full vector against the oracle's fp32 gradient (measured worst: cosine 0.9985 / 0.9966,
 # relative L2 5.5e-2 / 8.6e-2 on c2 / c4 -- both pos_bias_v of an early encoder block; nothing below 0.99, no exception list)
@@ -75,10 +79,14 @@ def _host_ram_gb():
 
 # The oracle's forward + backward at configs[1]'s full batch keeps ~42 GB of autograd state (measured: 25 s on 32 host threads of
 # the MI355X box, which has 3 TB); on a host with less than 128 GB the c2 case falls back to B = 8 (same T, same code paths except
-# the 224-panel launch count) and says so.
+# the 224-panel launch count).  Every pass / fail line names the B it ran; A3T_REQUIRE_FULL_B=1 turns the fallback into a failure.
+_C2_FULL_B = 32
+_C2_B = _C2_FULL_B if _host_ram_gb() >= 128 else 8
+if _C2_B != _C2_FULL_B and os.environ.get("A3T_REQUIRE_FULL_B") == "1":
+    raise RuntimeError(f"A3T_REQUIRE_FULL_B=1: the host has {_host_ram_gb():.0f} GB, the configs[1] oracle needs 128 GB for B = {_C2_FULL_B}")
 _CASES = {
     # tag: (oracle config, B, T_mel, T_phn)
-    "c2": (dict(enc_blocks=6, dec_blocks=6), 32 if _host_ram_gb() >= 128 else 8, 1000, 120),
+    "c2": (dict(enc_blocks=6, dec_blocks=6), _C2_B, 1000, 120),
     "c4": (dict(adim=512, heads=4, ff=2048, enc_blocks=6, dec_blocks=6), 4, 1600, 200),
 }
 _ORACLE = {}
@@ -111,16 +119,19 @@ def _oracle(tag):
 
 @pytest.mark.parametrize("tag", ["c2", "c4"])
 def test_full_size_forward_fp32_and_bf16_against_oracle(tag):
+    B = _CASES[tag][1]
+    if tag == "c2" and B != _C2_FULL_B:
+        print(f"[c2] REDUCED BATCH: B = {B} instead of {_C2_FULL_B} (host RAM {_host_ram_gb():.0f} GB < 128 GB)")
     oc, seed, batch, rl, rb, ra, _, yard = _oracle(tag)
     dev_batch = _to_dev(batch)
     eng, store = _engine(oc, seed, compute="f32")
     out = eng.forward(dev_batch, need_grad=False)
     l32 = float(out["loss"])
-    assert abs(l32 - rl) < FP32_LOSS_RTOL * abs(rl), (l32, rl)
+    assert abs(l32 - rl) < FP32_LOSS_RTOL * abs(rl), (f"B={B}", l32, rl)
     for name, ref in (("before", rb), ("after", ra)):
         mx, rms = _mel_err(out[name].float().cpu().numpy(), ref)
-        print(f"[{tag}] full size fp32 {name}: max {mx:.2e} rms {rms:.2e} of scale (loss {l32:.6f} vs oracle {rl:.6f})")
-        assert mx < FP32_MEL_TOL, (name, mx)
+        print(f"[{tag}] B={B} full size fp32 {name}: max {mx:.2e} rms {rms:.2e} of scale (loss {l32:.6f} vs oracle {rl:.6f})")
+        assert mx < FP32_MEL_TOL, (f"B={B}", name, mx)
     del eng, out
     torch.cuda.empty_cache()
     # production compute mode, TRAINING forward (fused attention forward that saves the probabilities, panel / 8-phase GEMMs)
@@ -129,13 +140,13 @@ def test_full_size_forward_fp32_and_bf16_against_oracle(tag):
     if tag == "c2":      # 576 attention workgroups: every layer takes the fused training forward, its last round key-split
         assert sum(k.endswith(".rs") for k in eng16.sv) == oc.enc_blocks + oc.dec_blocks
     l16 = float(out["loss"])
-    assert abs(l16 - rl) < BF16_LOSS_RTOL * abs(rl), (l16, rl)
+    assert abs(l16 - rl) < BF16_LOSS_RTOL * abs(rl), (f"B={B}", l16, rl)
     for name, ref in (("before", rb), ("after", ra)):
         mx, rms = _mel_err(out[name].float().cpu().numpy(), ref)
         ymx, yrms = yard[name]
-        print(f"[{tag}] full size bf16 {name}: max {mx:.2e} rms {rms:.2e} of scale "
+        print(f"[{tag}] B={B} full size bf16 {name}: max {mx:.2e} rms {rms:.2e} of scale "
               f"(oracle under bf16 autocast on the same batch: max {ymx:.2e} rms {yrms:.2e})")
-        assert rms <= BF16_MEL_RMS[tag][name] and mx <= ymx and rms <= yrms, (name, mx, ymx, rms, yrms)
+        assert rms <= BF16_MEL_RMS[tag][name] and mx <= ymx and rms <= yrms, (f"B={B}", name, mx, ymx, rms, yrms)
 
 
 @pytest.mark.parametrize("tag", ["c2", "c4"])
@@ -151,7 +162,7 @@ def test_full_size_gradients_fp32_and_bf16_against_oracle_backward(tag):
         torch.cuda.synchronize()
         grads = store.state_dict(grads=True)
         lo = float(out["loss"])
-        assert abs(lo - rl) < (FP32_LOSS_RTOL if compute == "f32" else BF16_LOSS_RTOL) * abs(rl), (compute, lo, rl)
+        assert abs(lo - rl) < (FP32_LOSS_RTOL if compute == "f32" else BF16_LOSS_RTOL) * abs(rl), (f"B={B}", compute, lo, rl)
         worst_l2, worst_cos, bad = (0.0, ""), (1.0, ""), []
         n = 0
         for name, ref in rg.items():
@@ -171,6 +182,6 @@ def test_full_size_gradients_fp32_and_bf16_against_oracle_backward(tag):
                     bad.append((name, round(cos, 4), round(ratio, 4)))
         print(f"[{tag}] B={B} {compute} gradients vs oracle backward, {n} tensors (full vectors): worst relative L2 "
               f"{worst_l2[0]:.2e} ({worst_l2[1]}), worst cosine {worst_cos[0]:.4f} ({worst_cos[1]})")
-        assert n > 300 and not bad, bad[:10]
+        assert n > 300 and not bad, (f"B={B}", bad[:10])
         del eng, store, grads, out
         torch.cuda.empty_cache()

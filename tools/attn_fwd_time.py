@@ -34,4 +34,4 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
-print(f"TRAIN={os.environ.get('TRAIN', '0')} EXP={os.environ.get('A3T_ATTN_EXP', '0')} MODE={os.environ.get('A3T_ATTN_FWD', '32')} fwd {us:.1f} us  {3 * 2.0 * B * H * T * T * dk / us / 1e6:.0f} TFLOP/s")
+print(f"TRAIN={os.environ.get('TRAIN', '0')} EXP={os.environ.get('A3T_ATTN_EXP', '0')} fwd {us:.1f} us  {3 * 2.0 * B * H * T * T * dk / us / 1e6:.0f} TFLOP/s")
