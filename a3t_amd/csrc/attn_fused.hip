@@ -117,11 +117,16 @@ __device__ __forceinline__ bf16x8 ld_frag_g(const u16* p, bool ok) {
 }
 // query fragment with the positional bias added on the fly (attention.py:190-194: q + pos_bias_u / pos_bias_v): the bf16 q
 // values plus 8 consecutive fp32 biases, rounded to bf16 exactly as a3t_add_pos_bias rounds; rows outside the utterance stay zero
-__device__ __forceinline__ bf16x8 ld_frag_qb(const u16* p, bool ok, const float* bias8) {
+// (bias8: this lane's 8 biases in LDS -- the workgroup stages its head's 2 x d_k biases there once: read from global memory
+//  per fragment, the 36 dependent load pairs of a wave's prologue cost the 14 us per launch that a3t_add_pos_bias took.)
+typedef const __attribute__((address_space(3))) float* lds_cfp;
+__device__ __forceinline__ bf16x8 ld_frag_qb(const u16* p, bool ok, lds_cfp bias8, bool biased) {
     const bf16x8 f = ld_frag_g(p, ok);
-    if (!bias8) return f;                               // (wave-uniform)
+    if (!biased) return f;                              // (wave-uniform)
     const uint4 u = __builtin_bit_cast(uint4, f);
-    const float4 b0 = *(const float4*)bias8, b1 = *(const float4*)(bias8 + 4);
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ b0 = *(const __attribute__((address_space(3))) v4f_*)bias8;
+    const v4f_ b1 = *(const __attribute__((address_space(3))) v4f_*)(bias8 + 4);
     uint4 o;
     o.x = io_pack2(io_bf2f(u.x & 0xffff) + b0.x, io_bf2f(u.x >> 16) + b0.y);
     o.y = io_pack2(io_bf2f(u.y & 0xffff) + b0.z, io_bf2f(u.y >> 16) + b0.w);
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
     unsigned char* Pr = smem + 4 * TB;                   // 6 ring slots of 32-row Pext tiles
     float* sc = (float*)(smem + 10 * TB);                // [8 waves][16][SC16_LD]: ring of four 16-column band blocks
     unsigned int* kmw = (unsigned int*)(sc + 8 * 16 * SC16_LD);
+    float* pbl = (float*)(kmw + 128);                    // [2][DK]: this head's pos_bias_u | pos_bias_v (when the kernel adds them)
 
     const int tid = threadIdx.x, lane = tid & 63, lq = lane & 15, lg = lane >> 4;
     const int PI = ((lg & 1) << 1) | (lg >> 1);          // k-chunk of this lane group inside a 32-deep MFMA step
@@ -297,13 +303,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
     D::issue(Vb, vB, p.ldkv, w, lane, [&](int r) { return krow(0, r); });
 #pragma unroll
     for (int u = 0; u < 5; ++u) D::issue(Pr + u * TB, pB, p.ldp, w, lane, [&](int r) { return prow(u, r); });
+    const bool biased = p.bu != nullptr;
+    if (biased) {
+        if (tid < DK) pbl[tid] = p.bu[h * DK + tid], pbl[DK + tid] = p.bv[h * DK + tid];
+        __syncthreads();
+    }
+    const lds_cfp pbu = (lds_cfp)LDS_AS(pbl), pbv = (lds_cfp)LDS_AS(pbl + DK);
     bf16x8 fqu[KS], fqv[KS];
     bool upper = false;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int off = 32 * kk + 8 * PI;
-        fqu[kk] = ld_frag_qb(quB + (int64_t)i * p.ldq + off, i < T, p.bu ? p.bu + h * DK + off : nullptr);
-        fqv[kk] = ld_frag_qb(qvB + (int64_t)i * p.ldq + off, i < T, p.bv ? p.bv + h * DK + off : nullptr);
+        fqu[kk] = ld_frag_qb(quB + (int64_t)i * p.ldq + off, i < T, pbu + off, biased);
+        fqv[kk] = ld_frag_qb(qvB + (int64_t)i * p.ldq + off, i < T, pbv + off, biased);
     }
     for (int sb = w; sb < NS; sb += 8) {
         const int jl = 32 * sb + (lane & 31);
@@ -319,8 +331,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd16_kernel(AttnArgs p) {
             upper = true;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
-                fqv[kk] = ld_frag_qb(qvB + (int64_t)(i + 1) * p.ldq + 32 * kk + 8 * PI, i + 1 < T,
-                                     p.bv ? p.bv + h * DK + 32 * kk + 8 * PI : nullptr);
+                fqv[kk] = ld_frag_qb(qvB + (int64_t)(i + 1) * p.ldq + 32 * kk + 8 * PI, i + 1 < T, pbv + 32 * kk + 8 * PI, biased);
         }
     };
     auto band_block = [&](int n) -> f32x4 {
@@ -551,6 +562,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     const uint8_t* mkB = p.keymask + (int64_t)b * T;
     float* scw = sc + w * 32 * SC_LD;
 
+    // this head's pos_bias_u | pos_bias_v (when the kernel adds them) in the staging area of the probability stores, which is
+    // idle until the key loop; the barrier below publishes them
+    const bool biased = p.bu != nullptr;
+    float* pbl = (float*)stg;
+    if (biased && tid < DK) pbl[tid] = p.bu[h * DK + tid], pbl[DK + tid] = p.bv[h * DK + tid];
     // ---- key-mask words; the first tile with a valid key (the same for every query: the mask is per key) ----------------
     for (int sb = w; sb <= NS; sb += 4) {
         const int jl = 32 * sb + lr;
@@ -644,11 +660,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const int off = 16 * kk + 8 * lh;
-        const float* bu8 = p.bu ? p.bu + h * DK + off : nullptr;
-        const float* bv8 = p.bv ? p.bv + h * DK + off : nullptr;
-        fqu[kk] = ld_frag_qb(quB + (int64_t)i * p.ldq + off, i < T, bu8);
-        fqvL[kk] = ld_frag_qb(qvB + (int64_t)i * p.ldq + off, i < T, bv8);
-        fqvU[kk] = ld_frag_qb(qvB + (int64_t)(i + 1) * p.ldq + off, i + 1 < T, bv8);
+        const lds_cfp bu8 = (lds_cfp)LDS_AS(pbl + off), bv8 = (lds_cfp)LDS_AS(pbl + DK + off);
+        fqu[kk] = ld_frag_qb(quB + (int64_t)i * p.ldq + off, i < T, bu8, biased);
+        fqvL[kk] = ld_frag_qb(qvB + (int64_t)i * p.ldq + off, i < T, bv8, biased);
+        fqvU[kk] = ld_frag_qb(qvB + (int64_t)(i + 1) * p.ldq + off, i + 1 < T, bv8, biased);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA (invisible to the compiler) and the fragment loads
     __syncthreads();
@@ -1412,7 +1427,7 @@ extern "C" int a3t_attn_split_mode(int mode) {
 template <int NDB>
 static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
     constexpr int TB = DT16<NDB>::BYTES;
-    constexpr int lds = 10 * TB + 8 * 16 * SC16_LD * 4 + 4 * 128;
+    constexpr int lds = 10 * TB + 8 * 16 * SC16_LD * 4 + 4 * 128 + 2 * 32 * NDB * 4;
     // (the attribute is per device: set it on every launch -- a process that drives several GPUs would otherwise launch on
     //  its second device without the raised LDS limit)
     const int nqb = (a.T + 127) / 128;
