@@ -243,41 +243,31 @@ def _collate_finish_on_device(self, ds, feats, flen, text, tlen, a_s, a_e, alen,
 
 
 def _collate_device_pipeline(self, ds, slen):
-    """device_out with raw waveforms: utterances are padded straight into a pinned staging buffer in chunks, each chunk goes
-    to the device asynchronously and through STFT -> mel -> log10 while the host pads the next one (the host-side memcpy of
-    4 B / sample is the longest stage; PCIe and the GPU hide behind it)."""
+    """device_out with raw waveforms: the utterances are padded straight into a pinned staging buffer, go to the device in ONE
+    asynchronous copy and through STFT -> mel -> log10 there.  (Chunked copies that overlap the host-side padding with PCIe and
+    the GPU were measured in round 4 -- 1 chunk 6.1 ms, 2: 6.6, 4: 6.9, 8: 8.4 per batch: the padding memcpy is 1.3 ms, a chunk's
+    launches cost more than they hide.)"""
     fe_x = self.feats_extract
     dev = torch.device(fe_x.device)
     B, N = len(ds), int(slen.max())
-    # pinned staging buffer: flat and grow-only (a hipHostMalloc per batch shape would cost more than the copy it serves);
-    # the (B, N) view of its head is contiguous, so every chunk is one plain async H2D copy
+    # pinned staging buffer: flat and grow-only (a hipHostMalloc per batch shape would cost more than the copy it serves)
     if getattr(self, "_pin", None) is None or self._pin.numel() < B * N:
         self._pin = torch.empty(max(B * N, int(1.25 * getattr(self, "_pin_cap", 0))), dtype=torch.float32).pin_memory()
         self._pin_cap = self._pin.numel()
     pin = self._pin[:B * N].view(B, N)
     pnp = pin.numpy()
-    nchunk = int(os.environ.get("A3T_COLLATE_CHUNKS", "1"))   # measured (tools/collate_time.py): 1 chunk 6.1 ms, 2: 6.6, 4: 6.9, 8: 8.4 -- the memcpy is 1.3 ms
-    chunk = max(1, (B + nchunk - 1) // nchunk)
     ev = getattr(self, "_pin_ev", None)
     if ev is not None:
-        ev.synchronize()          # the previous call's copies out of the staging buffer are done
-    feats, flens = [], []
-    for c0 in range(0, B, chunk):
-        c1 = min(B, c0 + chunk)
-        for i in range(c0, c1):
-            n = int(slen[i])
-            pnp[i, :n] = ds[i]["speech"]
-            if n < N:
-                pnp[i, n:] = self.float_pad_value
-        xd = pin[c0:c1].to(dev, non_blocking=True)
-        f, fl = fe_x(xd, torch.from_numpy(slen[c0:c1]))
-        feats.append(f)
-        flens.append(fl)
+        ev.synchronize()          # the previous call's copy out of the staging buffer is done
+    for i in range(B):
+        n = int(slen[i])
+        pnp[i, :n] = ds[i]["speech"]
+        if n < N:
+            pnp[i, n:] = self.float_pad_value
+    xd = pin.to(dev, non_blocking=True)
+    feats, flen = fe_x(xd, torch.from_numpy(slen))
     self._pin_ev = torch.cuda.Event()
     self._pin_ev.record()
-    # (every chunk is padded to the batch-wide N above, so all chunks have the same frame width)
-    feats = torch.cat(feats, 0) if len(feats) > 1 else feats[0]
-    flen = torch.cat(flens, 0)
     text = pad_list([d["text"] for d in ds], self.int_pad_value)
     tlen = np.array([d["text"].shape[0] for d in ds], dtype=np.int64)
     a_s = pad_list([d["align_start"] for d in ds], self.float_pad_value)

@@ -77,14 +77,7 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
         wi = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wi >> 3);
     }
     const int bid = wi % p.ntiles, zy = wi / p.ntiles;
-    int tn = bid % p.tiles_n, tm = bid / p.tiles_n;
-    if (p.cgroup > 0) {   // L2 blocking: the co-resident tiles of an XCD cover few column tiles (a small slab of B) and many rows
-        const int tiles_m = p.ntiles / p.tiles_n, per = tiles_m * p.cgroup;
-        const int cg = bid / per, rem = bid - cg * per;
-        const int gw = min(p.cgroup, p.tiles_n - cg * p.cgroup);
-        tm = rem / gw;
-        tn = cg * p.cgroup + (rem - tm * gw);
-    }
+    const int tn = bid % p.tiles_n, tm = bid / p.tiles_n;      // (an L2-blocked tile order -- column groups -- was ruled out in round 3)
     const int ks = zy % p.splitk, bz = zy / p.splitk;
     const int z0 = bz / p.batch_inner, z1 = bz % p.batch_inner;
     const u16* A = (const u16*)p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
@@ -530,14 +523,6 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     const long tiles = (long)pv.tiles_n * tiles_m * batch * p.splitk;
     const int stages = forced_st ? forced_st : (tiles >= (wn3 ? 512 : 768) ? 1 : 2);
     pv.ntiles = pv.tiles_n * tiles_m;
-    {
-        static int cg = -1;
-        if (cg < 0) {
-            const char* e = getenv("A3T_GEMM_COLGROUP");
-            cg = e ? atoi(e) : 0;
-        }
-        pv.cgroup = (cg > 0 && pv.tiles_n > cg && tiles_m >= 64) ? cg : 0;
-    }
     dim3 grid((unsigned)((long)pv.ntiles * batch * p.splitk));
     if (wn3) {
 #define V3(LY, ST)                                             \

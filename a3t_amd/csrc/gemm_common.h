@@ -24,7 +24,6 @@ struct GP {
     float alpha;
     int act, accumulate, splitk, c_dtype, tiles_n, s_dtype, epi_vec;
     int ntiles;   // output tiles per (batch element, K split): 1-D grids of the direct-to-LDS kernels
-    int cgroup;   // > 0: tiles are ordered (column group of `cgroup` tiles, row tile, column in group) -- L2 blocking
     float* colsum;
     int64_t colsum_bs1;
     float colsum_scale;

@@ -178,111 +178,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
-// D % 128 == 0 fast path: half a wave (32 lanes) per row, NQ float4 per lane (D = 128*NQ), so every
-// global access is 16 bytes (8 for bf16) and a wave streams two rows at once.
-template <int NQ>
-__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict__ dy, int dy_dt,
-                                                         const float* __restrict__ x, const float* __restrict__ g,
-                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* dres, float* dx, unsigned short* __restrict__ dx16,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         float* __restrict__ dxsum, float dxsum_scale, int M, int D,
-                                                         unsigned int drop_thr, float drop_inv, unsigned int drop_key) {
-    __shared__ float red[3][8][32 * 4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, hl = lane & 31, half = lane >> 5;
-    float4 gam[NQ], ag[NQ], ab[NQ], ax[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        gam[i] = *(const float4*)(g + (hl + 32 * i) * 4);
-        ag[i] = ab[i] = ax[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const float invD = 1.f / (float)D;
-    for (int row = (blockIdx.x * 4 + wv) * 2 + half; row < M; row += gridDim.x * 8) {
-        const float mu = mean[row], rs = rstd[row];
-        const int64_t ro = (int64_t)row * D;
-        float4 xh[NQ], dg[NQ], rr[NQ];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {   // the residual gradient is requested with the row, not after the reduction
-            rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (dres) rr[i] = *(const float4*)(dres + ro + (hl + 32 * i) * 4);
-        }
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int c = (hl + 32 * i) * 4;
-            float4 d;
-            if (dy_dt == A3T_BF16) {
-                uint2 t = *(const uint2*)((const unsigned short*)dy + ro + c);
-                d = make_float4(io_bf2f(t.x & 0xffff), io_bf2f(t.x >> 16), io_bf2f(t.y & 0xffff), io_bf2f(t.y >> 16));
-            } else {
-                d = *(const float4*)((const float*)dy + ro + c);
-            }
-            float4 xv = *(const float4*)(x + ro + c);
-            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-            dg[i] = make_float4(d.x * gam[i].x, d.y * gam[i].y, d.z * gam[i].z, d.w * gam[i].w);
-            s1 += dg[i].x + dg[i].y + dg[i].z + dg[i].w;
-            s2 += dg[i].x * xh[i].x + dg[i].y * xh[i].y + dg[i].z * xh[i].z + dg[i].w * xh[i].w;
-            ag[i].x += d.x * xh[i].x, ag[i].y += d.y * xh[i].y, ag[i].z += d.z * xh[i].z, ag[i].w += d.w * xh[i].w;
-            ab[i].x += d.x, ab[i].y += d.y, ab[i].z += d.z, ab[i].w += d.w;
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {   // reduce inside each 32-lane half
-            s1 += __shfl_xor(s1, o, WAVE);
-            s2 += __shfl_xor(s2, o, WAVE);
-        }
-        s1 *= invD, s2 *= invD;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int c = (hl + 32 * i) * 4;
-            float4 o = make_float4(rs * (dg[i].x - s1 - xh[i].x * s2), rs * (dg[i].y - s1 - xh[i].y * s2),
-                                   rs * (dg[i].z - s1 - xh[i].z * s2), rs * (dg[i].w - s1 - xh[i].w * s2));
-            o.x += rr[i].x, o.y += rr[i].y, o.z += rr[i].z, o.w += rr[i].w;
-            *(float4*)(dx + ro + c) = o;
-            if (drop_inv > 0.f) {   // the consumer sub-layer's output dropout: its GEMM operand / bias gradient see the masked dx
-                const unsigned int i0 = (unsigned int)(ro + c);
-                bool kp[4];
-                rng_keep4(drop_key, i0, drop_thr, kp);
-                o.x = kp[0] ? o.x * drop_inv : 0.f, o.y = kp[1] ? o.y * drop_inv : 0.f;
-                o.z = kp[2] ? o.z * drop_inv : 0.f, o.w = kp[3] ? o.w * drop_inv : 0.f;
-            }
-            if (dx16) {
-                uint2 h;
-                h.x = io_pack2(o.x, o.y);
-                h.y = io_pack2(o.z, o.w);
-                *(uint2*)(dx16 + ro + c) = h;
-            }
-            ax[i].x += o.x, ax[i].y += o.y, ax[i].z += o.z, ax[i].w += o.w;
-        }
-    }
-    // 8 half-waves per block hold partial column sums for the same columns
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const int slot = wv * 2 + half;
-        *(float4*)&red[0][slot][hl * 4] = ag[i];
-        *(float4*)&red[1][slot][hl * 4] = ab[i];
-        *(float4*)&red[2][slot][hl * 4] = ax[i];
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const int cc = threadIdx.x;                // column inside this 128-wide group
-            float a = 0.f, b2 = 0.f, c2 = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                a += red[0][s][cc];
-                b2 += red[1][s][cc];
-                c2 += red[2][s][cc];
-            }
-            // lane hl owns columns (hl + 32*i)*4 .. +3  ->  global column = 128*i + cc
-            const int col = 128 * i + cc;
-            atomicAdd(&dgamma[col], a);
-            atomicAdd(&dbeta[col], b2);
-            if (dxsum) atomicAdd(&dxsum[col], dxsum_scale * c2);
-        }
-        __syncthreads();
-    }
-}
 
-// D % 128 == 0, second layout (round 5): a whole wave per row, NP float2 per lane (D = 128*NP).  Half the per-lane state of the
-// half-wave layout above (76 registers against 132 at D = 384): inside the training step this kernel runs beside the weight-gradient
+// D % 128 == 0 (round 5): a whole wave per row, NP float2 per lane (D = 128*NP).  Half the per-lane state of the half-wave-per-row
+// layout it replaced (76 registers against 132 at D = 384; that kernel left the library in round 6): inside the training step this kernel runs beside the weight-gradient
 // GEMM of the other stream, whose two waves per SIMD leave 160 of the 512 registers -- one wave of the 132-register kernel, two of
 // this one (LayerNorm backward inside the step: 93 us with the half-wave layout, 54 us alone).  The column-sum partials of a
 // block's eight waves go through a 12-KiB LDS buffer one array at a time.  amdgpu_num_vgpr: at D = 384 the kernel needs 82 registers
@@ -429,24 +327,13 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
     const float drop_inv = drop_p > 0.f ? 1.f / (1.f - drop_p) : 0.f;
     if (D % 128 == 0 && D <= 512 && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dx % 16 == 0) &&
         (!dres || (uintptr_t)dres % 16 == 0) && ((uintptr_t)gamma % 16 == 0)) {
-        int vb = (M + 7) / 8;
-        static int vb_max = 0;
-        if (!vb_max) {
-            const char* e = getenv("A3T_LN_BLOCKS");
-            // 2 workgroups per CU: every workgroup ends with 3*D same-address atomics (dgamma, dbeta, dx column sums),
-            // and with 2048 workgroups that serialised tail cost more than the row streaming itself (66 -> 45 us at
-            // M = 35840, D = 384: tools/ln_bench.py)
-            vb_max = e ? atoi(e) : 512;
-        }
-        if (vb > vb_max) vb = vb_max;
-        static int row64 = -1;                 // A3T_LN_BWD_ROW64=0: the half-wave layout (A/B switch)
-        if (row64 < 0) {
-            const char* e = getenv("A3T_LN_BWD_ROW64");
-            row64 = e ? atoi(e) : 1;
-        }
-        if (row64) {
-            int rb = (M + 7) / 8;
-            if (rb > vb_max) rb = vb_max;
+        // 2 workgroups per CU: every workgroup ends with 3*D same-address atomics (dgamma, dbeta, dx column sums), and with
+        // 2048 workgroups that serialised tail cost more than the row streaming itself (66 -> 45 us at M = 35840, D = 384)
+        const int vb_max = 512;
+        // a whole wave per row, rows software-pipelined (round 5; the half-wave-per-row layout it replaced, +0.4 ms per step, left
+        // the library in round 6)
+        int rb = (M + 7) / 8;
+        if (rb > vb_max) rb = vb_max;
 #define RCALL(NP)                                                                                                        \
     do {                                                                                                                 \
         if (dy_dtype == A3T_BF16)                                                                                        \
@@ -458,22 +345,11 @@ extern "C" int a3t_layernorm_bwd(const void* dy, int dy_dtype, const float* x, c
                                gamma, mean, rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum,         \
                                dx_colsum_scale, M, D, drop_thr, drop_inv, drop_key);                                     \
     } while (0)
-            if (D == 128) RCALL(1);
-            else if (D == 256) RCALL(2);
-            else if (D == 384) RCALL(3);
-            else RCALL(4);
+        if (D == 128) RCALL(1);
+        else if (D == 256) RCALL(2);
+        else if (D == 384) RCALL(3);
+        else RCALL(4);
 #undef RCALL
-            return (int)hipGetLastError();
-        }
-#define VCALL(NQ)                                                                                                   \
-    hipLaunchKernelGGL(ln_bwd_vec_kernel<NQ>, dim3(vb), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, x, gamma, mean, \
-                       rstd, dres, dx, (unsigned short*)dx_bf16, dgamma, dbeta, dx_colsum, dx_colsum_scale, M, D,       \
-                       drop_thr, drop_inv, drop_key)
-        if (D == 128) VCALL(1);
-        else if (D == 256) VCALL(2);
-        else if (D == 384) VCALL(3);
-        else VCALL(4);
-#undef VCALL
         return (int)hipGetLastError();
     }
     if (drop_p > 0.f) return A3T_EINVAL;   // the fused consumer-dropout output lives in the D % 128 == 0 kernel only

@@ -59,7 +59,7 @@ class _FastEvent:
     """Cross-stream hand-over event created with hipEventDisableTiming | hipEventDisableSystemFence: the marker packet of
     a default-flag event costs the queue it is recorded on ~7.3 us between two kernels, this one ~5.2 (tools/event_cost.py,
     rocprofv3 kernel trace); the engine records ~110 of them per step on the main stream.  Same interface as the two methods
-    of torch.cuda.Event the engine uses.  A3T_FAST_EVENTS=0: torch events."""
+    of torch.cuda.Event the engine uses (torch's own events are the fallback when libamdhip64.so cannot be loaded by that name)."""
     _hip = None
     _pools = {}        # device -> [events, next]: an event belongs to the device that was current when it was created
 
@@ -122,7 +122,7 @@ def _new_event(owned=False):
     return _TorchEvent()
 
 
-_FAST_EVENTS = os.environ.get("A3T_FAST_EVENTS", "1") != "0"
+_FAST_EVENTS = True
 
 
 class Workspace:
@@ -190,16 +190,16 @@ class MLMEngine:
         self._gm_ready = None
         self._arena = {k: dict(buf=None, used=0, slots={}, dtype=dt) for k, dt in
                        (("fwd64", torch.float64), ("bwd64", torch.float64), ("bwd32", torch.float32))}
-        self.colsum_slots = int(os.environ.get("A3T_COLSUM_SLOTS", "16"))   # spread of the attention bias-gradient atomics
+        self.colsum_slots = 16          # spread of the attention bias-gradient atomics (1 and 64 measured: slower / equal)
         self.fuse_ln_dropout = True      # LayerNorm backward emits the next sub-layer's masked gradient (bf16, d % 128 == 0)
         # bf16 mode: the first postnet conv reads `before` (log-mel scale, |x| ~ 4: one bf16 ulp = 0.03) whose rounding the
         # five BatchNorm'ed postnet layers amplify.  Its forward therefore runs on (hi, lo) = (bf16(x), bf16(x - hi)): two
         # K = 5*80 bf16 GEMMs carry `before` to ~2^-17 (max error of `after` 6.2e-2 -> 4.3e-2 of scale); gradients use hi only.
         self.post_f32_first = os.environ.get("A3T_POST_F32_FIRST", "1") != "0"
-        self.sfc_f32 = os.environ.get("A3T_SFC_F32", "1") != "0"
+        self.sfc_f32 = True
         # the attention-dropout mask of the score gradients comes back from the counter RNG instead of being read off the dropped
-        # probabilities (one T x T read less); A3T_ATTN_REGEN_MASK=0 reads it
-        self.attn_regen = os.environ.get("A3T_ATTN_REGEN_MASK", "1") != "0"
+        # probabilities (one T x T read less)
+        self.attn_regen = True
         # dS / dBD straight from the saved probabilities in one launch (a3t_attn_bwd_ds) instead of the dprobs GEMM + softmax
         # backward: dprobs is never stored.  Default where it wins inside the step: d_k >= 160 -- the kernel is bound by
         # score traffic, the GEMM it replaces shrinks with d_k.  A3T_ATTN_BWD_DS=0 / 1: never / always.
@@ -235,10 +235,9 @@ class MLMEngine:
         self._ffn_plans = {}
         self._lin_plans = {}
         self._wt = {}        # transposed FFN weight shadows (8-phase data gradients), built on demand
-        self._late_cast = os.environ.get("A3T_LATE_CAST", "1") != "0"
-        self._pos_ahead = os.environ.get("A3T_POS_AHEAD", "1") != "0"
-        self._head_side = os.environ.get("A3T_HEAD_WGRAD_SIDE", "1") != "0"     # postnet / feat_out weight gradients on the side stream
-        self._attn_small_side = os.environ.get("A3T_ATTN_SMALL_SIDE", "1") != "0"   # attn_scale_rows / attn_bias_fold off the main stream
+        # (settled by the A/Bs of rounds 4-5; the switches left in round 6) weights cast late on the side stream, the
+        # positional projections made ahead on it, the head's weight gradients and the attention's small kernels on the side streams
+        self._late_cast = self._pos_ahead = True
         self._P_ahead, self._pos_ev = {}, None
         self._cast_ev = self._wt_ev = None
         dec = [o for k, (o, _) in store.offsets.items() if k.startswith("dec.")]
@@ -337,8 +336,8 @@ class MLMEngine:
                     ops.gemm_8p_supported(M, c.ff, k * c.adim, k, ops.G8_KEEP_IN | ops.G8_COLSUM)
                 d1 = ops.gemm_8p_supported(M, c.adim, k * c.ff, k, 0) or ops.gemm_pn_supported(M, c.adim, k * c.ff, k, 0)
                 # (no keep bits: the panel GEMM runs the data gradient of conv 2 on the transposed w_2 with the saved hidden
-                #  activation as its ReLU' mask, A3T_FFN_D2T=0 turns that off)
-                d2 = (not keep) and os.environ.get("A3T_FFN_D2T", "1") != "0" and \
+                #  activation as its ReLU' mask, 
+                d2 = (not keep) and \
                     ops.gemm_pn_supported(M, c.ff, k * c.adim, k, ops.G8_SMASK | ops.G8_COLSUM)
                 if (keep or d2) and "w2" not in self._wt:
                     self._setup_wt("w2", (c.adim, k, c.ff))
@@ -722,8 +721,6 @@ class MLMEngine:
         sl = self._arena_slot("bwd32", tag + ".bsl", S * 4 * d) if fz else None
         csk = dict(colsum_bs1=dk, colsum_slots=S, colsum_ss=4 * d)
         # (independent of the dprobs -> softmax-backward chain: runs beside it on the side stream)
-        if rs is not None and not self._attn_small_side:
-            ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
         make_q = qu is None        # fused forward: (q+u), (q+v) were never stored -- the dK product (second side stream, below) and
         if make_q:                 # the gradient of linear_pos (first side stream) read them: made on the second side stream
             qu = self._act("tmp.qu", (M, d))                  # (read on that stream only, in order)
@@ -732,7 +729,7 @@ class MLMEngine:
         def dv_gemm():
             if make_q:
                 ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
-            if rs is not None and self._attn_small_side:
+            if rs is not None:
                 ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
             ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                      batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
@@ -783,7 +780,7 @@ class MLMEngine:
         if dk_done is not None:      # the dV / dK slices of dqkv and their column sums come from the side stream
             dk_done.wait_on(torch.cuda.current_stream())
         if fz:   # d u, d v, d b_q = d u + d v, d b_k, d b_v from the slot sums (all four GEMMs have drained here); feeds nothing
-            (self._side if self._attn_small_side else (lambda f: f()))(
+            self._side(
                 lambda: ops.attn_bias_fold(sl, S, d, gr[pre + ".u"], gr[pre + ".v"], gbq))       # but the optimizer
         else:
             self._bias_grad(dqu, gr[pre + ".u"])
@@ -1079,7 +1076,7 @@ class MLMEngine:
                 yin = self.sv[f"post.{l}"]
                 ic = yin.shape[1]
                 # (weight gradients of the head: the side stream is idle at the start of the backward)
-                (self._side if self._head_side else (lambda f: f()))(
+                self._side(
                     lambda dz=dz, yin=yin, l=l: ops.conv_bwd_weight(dz, yin, gr[f"post.{l}.w"], Tm, pad, compute=cmp))
                 gi = ws.get(f"tmp.post.g{l % 2}.{ic}", (B * Tm, ic))
                 ops.conv_bwd_data(dz, W, gi, Tm, pad, compute=cmp)
@@ -1092,7 +1089,7 @@ class MLMEngine:
             ops.cast_bf16(db, dba)
         dhs = ws.get("tmp.dhs", (B * Tm, d))
         ops.linear_bwd_data(dba, self.W("sfc.w"), dhs, compute=cmp)
-        (self._side if self._head_side else (lambda f: f()))(lambda: ops.linear_bwd_weight(dba, hs, gr["sfc.w"], compute=cmp))
+        self._side(lambda: ops.linear_bwd_weight(dba, hs, gr["sfc.w"], compute=cmp))
         self._bias_grad(db, gr["sfc.b"])
         done("sfc.w")
         g = ws.get("grad.x", (B * T, d), zero=True)

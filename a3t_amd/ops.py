@@ -73,7 +73,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
 
 
-_SPLITK_TARGET = int(os.environ.get("A3T_SPLITK_TARGET", "1000"))   # A/B knob (tools/step_ab.sh)
+_SPLITK_TARGET = 1000      # workgroups of a split-K grid on the 128x128 kernel (500 / 700 / 1500 / 2000 measured in round 3: slower)
 
 
 def _splitk_for(n_tiles, K, ktile=64):

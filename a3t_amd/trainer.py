@@ -165,7 +165,7 @@ class A3TTrainer:
         self.lr, self.warmup, self.clip, self.betas, self.eps = lr, warmup_steps, grad_clip, betas, eps
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self._main = None
-        if dev.type == "cuda" and os.environ.get("A3T_MAIN_PRIORITY", "1") != "0":
+        if dev.type == "cuda":
             from .engine import shared_stream
             self._main = shared_stream(dev, "main", high=True)
         self.reducer = None
@@ -187,7 +187,7 @@ class A3TTrainer:
         """One iteration of the trainer loop body (see _step).  On a GPU the whole schedule runs on a HIGH-priority stream
         owned by the trainer: the data-gradient chain and its row kernels are the critical path, the weight gradients on
         the engine's (default-priority) side stream are not, and the dispatcher should hand free CUs to the former first
-        (round 2, A/B with the knob: 51.0 -> 50.6 ms per step; A3T_MAIN_PRIORITY=0 runs on the caller's stream)."""
+        (round 2, A/B: 51.0 -> 50.6 ms per step; on a CPU device the schedule runs on the caller's stream)."""
         if self._main is None:
             return self._step(batch, total_weight, accum_grad, accum_index)
         cur = torch.cuda.current_stream(self.store.device)

@@ -25,7 +25,7 @@ import torch.distributed as dist  # noqa: E402
 
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # TFLOP/s dense, MI355X_MICROARCH.md
 HBM_PEAK = 8000.0                            # GB/s
-TRAFFIC_FILE = "r05_hbm_traffic_per_kernel.json"   # this round's PMC summary (tools/r05_profiles.sh)
+TRAFFIC_FILE = "r06_hbm_traffic_per_kernel.json"   # this round's PMC summary (tools/r06_profiles.sh)
 
 
 def fwd_flops_per_step(c, B, Tm, Tp):
@@ -525,7 +525,7 @@ def main():
         name, (fl, tt, n) = max(agg.items(), key=lambda kv: kv[1][1])
         achieved = fl / tt / 1e12
         peak = MFMA_PEAK["bf16" if "bf16" in name else "f32"]
-        # HBM traffic of that kernel: ONLY from THIS round's PMC passes of this command (tools/r05_profiles.sh -> separate
+        # HBM traffic of that kernel: ONLY from THIS round's PMC passes of this command (tools/r06_profiles.sh -> separate
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x2 for gfx950); no silent fall-back to an older round's file
         traffic, traffic_source = None, None
         tfp = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
@@ -536,7 +536,7 @@ def main():
                     traffic_source = ("profiles/" + TRAFFIC_FILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "command, FETCH_SIZE x2 for gfx950; a tracked file, not measured in this run)")
         if traffic is None:
-            traffic_source = (f"MISSING: profiles/{TRAFFIC_FILE} has no entry for {name} -- run tools/r05_profiles.sh on the GPU box and "
+            traffic_source = (f"MISSING: profiles/{TRAFFIC_FILE} has no entry for {name} -- run tools/r06_profiles.sh on the GPU box and "
                               "commit its output; traffic is null, not borrowed from an older round")
             print("[bench] WARNING: " + traffic_source, file=sys.stderr, flush=True)
             if a.strict_traffic:

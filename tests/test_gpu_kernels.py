@@ -893,3 +893,63 @@ def test_grouped_linear_weight_gradients_equal_the_single_launches():
     finally:
         lib.a3t_gemm_8p_mode(old8)
         lib.a3t_gemm_tn3_mode(old3)
+
+
+def test_bf16_output_accumulates_in_fp32_with_one_rounding_and_keeps_its_own_column_sum():
+    """Round 6: A3T_ACC_ADD on a bf16 C (the second attention product adds d(q+v) onto d(q+u) in the q third of dqkv): the sum is
+    formed in fp32 from the stored bf16 value and rounded once; the fused column sum takes the INCREMENT alone (the bias gradient
+    of pos_bias_v is the column sum of d(q+v), not of the total); bf16 atomics / split-K accumulation are refused."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import ACC_ADD, ACC_ATOMIC, BF16
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    B, H, T, dk = 3, 2, 264, 192
+    d = H * dk
+    A1, A2 = rn(B, H, T, T).bfloat16(), rn(B, H, T, T).bfloat16()
+    kk, P = rn(B * T, d).bfloat16(), rn(T, d).bfloat16()
+    out = torch.zeros(B * T, 3 * d, device=DEV, dtype=torch.bfloat16)          # q third of a q | k | v row
+    cs = torch.zeros(2 * d, device=DEV)
+    zb = (H * T * T, T * T)
+    ops.gemm(A1, kk, out, T, dk, T, T, 1, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
+             compute=BF16, colsum=cs[:d], colsum_bs1=dk)
+    first = out[:, :d].clone()
+    ops.gemm(A2, P, out, T, dk, T, T, 1, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk), c_bs=(T * 3 * d, dk),
+             acc=ACC_ADD, compute=BF16, colsum=cs[d:], colsum_bs1=dk)
+    torch.cuda.synchronize()
+    r1 = torch.einsum("bhij,bjhc->bihc", A1.float(), kk.float().view(B, T, H, dk)).reshape(B * T, d)
+    r2 = torch.einsum("bhij,jhc->bihc", A2.float(), P.float().view(T, H, dk)).reshape(B * T, d)
+    assert torch.equal(first, r1.bfloat16()) or float((first.float() - r1).abs().max()) < 2e-2 * float(r1.abs().max())
+    want = (first.float() + r2).bfloat16()                                    # one rounding of (stored bf16 + fp32 increment)
+    diff = (out[:, :d].float() - want.float()).abs()
+    assert float(diff.max()) <= 2.0 ** -7 * float(want.float().abs().max()), float(diff.max())      # <= 1 bf16 ulp (fp32 sum order)
+    assert float((out[:, d:].float()).abs().max()) == 0.0                     # the k | v thirds are not touched
+    sc = float(r2.abs().sum(0).max())
+    assert float((cs[d:] - r2.sum(0)).abs().max()) < 2e-3 * sc and float((cs[:d] - r1.sum(0)).abs().max()) < 2e-3 * float(r1.abs().sum(0).max())
+    with pytest.raises(_lib.A3TLibraryError if hasattr(_lib, "A3TLibraryError") else RuntimeError):
+        ops.gemm(A2, P, out, T, dk, T, T, 1, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk), c_bs=(T * 3 * d, dk),
+                 acc=ACC_ATOMIC, compute=BF16)
+
+
+def test_release_workspaces_frees_the_split_k_slabs_and_the_next_launch_allocates_again():
+    """a3t_release_workspaces (round 6): the grow-only slabs of the weight-gradient kernels and the attention key-split
+    workspace are freed; the next weight gradient allocates again and gives the same bits."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import BF16
+    ops = _ops()
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(8)
+    dy, x = torch.randn(5 * 1120, 1536, device=DEV, generator=g).bfloat16(), torch.randn(5 * 1120, 384, device=DEV, generator=g).bfloat16()
+
+    def run():
+        dW = torch.zeros(1536, 3, 384, device=DEV)
+        ops.conv_bwd_weight(dy, x, dW, 1120, 1, compute=BF16)
+        torch.cuda.synchronize()
+        return dW
+    a = run()
+    free0 = torch.cuda.mem_get_info()[0]
+    assert lib.a3t_release_workspaces() == 0
+    free1 = torch.cuda.mem_get_info()[0]
+    b = run()
+    assert free1 >= free0 and torch.equal(a, b)
+    assert lib.a3t_release_workspaces() == 0 and lib.a3t_release_workspaces() == 0        # idempotent

@@ -1,4 +1,4 @@
-"""Where the on-device collate spends its time (bench.py's collate leg, A3T_COLLATE_CHUNKS variants)."""
+"""Where the on-device collate spends its time (bench.py's collate leg)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,8 +16,7 @@ for i in range(B):
     data.append((f"u{i}", dict(speech=(0.1 * rs.standard_normal(n)).astype(np.float32), text=rs.randint(2, 70, size=Tp).astype(np.int64),
                                align_start=st.astype(np.float32), align_end=en.astype(np.float32))))
 fe = LogMelFbank(fs=fs, n_fft=2048, win_length=1200, hop_length=hop, n_mels=80, fmin=80, fmax=7600, device="cuda")
-for nch in (1, 2, 4, 8, 16):
-    os.environ["A3T_COLLATE_CHUNKS"] = str(nch)
+for nch in (1,):
     coll = MLMCollateFn(fe, mlm_prob=0.8, mean_phn_span=8, sega_emb=True, device_out=True)
     np.random.seed(1)
     coll(data); coll(data)

@@ -1,18 +1,18 @@
 # SQ counters of the FFN GEMM classes (workload: tools/gemm_pmc_workload.py = configs[1] on the 128x128 and panel kernels, configs[3]
-# on the 8-phase kernel) -> gpurun_out/${A3T_ROUND:-r05}_gemm_mfma_busy.json; part of the per-round evidence set (tools/r05_profiles.sh calls it)
+# on the 8-phase kernel) -> gpurun_out/${A3T_ROUND:-r05}_gemm_mfma_busy.json; part of the per-round evidence set (tools/r06_profiles.sh calls it)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   i=$((i+1))
-  rm -rf /tmp/r04_pmcg_$i
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/r04_pmcg_$i -- python $R/tools/gemm_pmc_workload.py > /tmp/r04_pmcg_$i.log 2>&1
+  rm -rf /tmp/pmcg_$i
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmcg_$i -- python $R/tools/gemm_pmc_workload.py > /tmp/pmcg_$i.log 2>&1
 done
 cd $R
 python - <<'PY'
 import collections, csv, glob, json
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
-for f in glob.glob("/tmp/r04_pmcg_*/*/*counter_collection.csv"):
+for f in glob.glob("/tmp/pmcg_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "gemm" not in k:

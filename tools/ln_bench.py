@@ -1,4 +1,4 @@
-"""Micro-benchmark of the LayerNorm kernels at the C2 shape (A3T_LN_BLOCKS caps the backward grid)."""
+"""Micro-benchmark of the LayerNorm kernels at the C2 shape."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -21,4 +21,4 @@ dy = torch.randn(M, D, device=dev).bfloat16(); dres = torch.randn(M, D, device=d
 dx = torch.empty(M, D, device=dev); dx16 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
 dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev); dxs = torch.zeros(D, device=dev)
 t = timeit(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, dx16=dx16, dxsum=dxs, dxsum_scale=0.5))
-print(f"ln bwd {t:6.1f} us  {(M*D*16)/t/1e6:5.2f} TB/s (blocks cap {os.environ.get('A3T_LN_BLOCKS', '2048')})")
+print(f"ln bwd {t:6.1f} us  {(M*D*16)/t/1e6:5.2f} TB/s")
