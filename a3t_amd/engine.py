@@ -201,10 +201,10 @@ class MLMEngine:
         # probabilities (one T x T read less)
         self.attn_regen = True
         # dS / dBD straight from the saved probabilities in one launch (a3t_attn_bwd_ds) instead of the dprobs GEMM + softmax
-        # backward: dprobs is never stored.  Default where it wins inside the step: d_k >= 160 -- the kernel is bound by
-        # score traffic, the GEMM it replaces shrinks with d_k.  A3T_ATTN_BWD_DS=0 / 1: never / always.
-        ds_env = os.environ.get("A3T_ATTN_BWD_DS", "auto")
-        self.attn_bwd_ds = ds_env == "1" or (ds_env not in ("0", "1") and cfg.dk >= 160)
+        # backward: dprobs is never stored.  Default since round 5 at d_k >= 160, since round 6 (the kernel forms delta itself:
+        # one launch and one [B][H][T] tensor less) at every supported d_k -- configs[3] (d_k = 128): 61.25 ms per step against
+        # 62.33 / 62.30 with the materialised pair (profiles/r06_c4_ab.txt).  A3T_ATTN_BWD_DS=0: the materialised pair.
+        self.attn_bwd_ds = os.environ.get("A3T_ATTN_BWD_DS", "1") != "0"
         # Fused legacy rel-pos attention forward (csrc/attn_fused.hip: scores, shifted position term, softmax, dropout and PV in one
         # launch, no logits in HBM).  A3T_FUSED_ATTN = auto (default) | fwd | 0:
         #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; below that its
@@ -727,13 +727,13 @@ class MLMEngine:
             qv = self._act(self._t("tmp.qv"), (M, d))         # (read by the other side stream, whenever it gets there)
 
         def dv_gemm():
-            if make_q:
-                ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
             if rs is not None:
                 ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
             ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                      batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
                      compute=cmp, colsum=sl[3 * d:] if fz else None, **csk)
+            if make_q:      # behind dV (which does not read them): dK cannot start before the score gradients exist anyway
+                ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
         qv_ready = self._side(dv_gemm, want_event=make_q, urgent=True)
         zbd = zb
         if self.bf16:
