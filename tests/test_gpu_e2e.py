@@ -348,6 +348,8 @@ def test_grouped_weight_gradients_on_a_shallow_scratch_ring_match_single_launche
     from a3t_amd.init import xavier_init_
     from a3t_amd.params import ParamStore
     from a3t_amd.collate import synthetic_batch
+    if os.environ.get("A3T_SIDE_STREAM") == "0":
+        pytest.skip("one-stream schedule (A3T_SIDE_STREAM=0): nothing is grouped or handed over")
     c = A3TConfig(adim=384, heads=2, ff=768, enc_blocks=8, dec_blocks=8, postnet_layers=3, postnet_chans=64, vocab=40,
                   dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
     store = ParamStore(c, DEV)

@@ -87,7 +87,9 @@ if _C2_B != _C2_FULL_B and os.environ.get("A3T_REQUIRE_FULL_B") == "1":
 _CASES = {
     # tag: (oracle config, B, T_mel, T_phn)
     "c2": (dict(enc_blocks=6, dec_blocks=6), _C2_B, 1000, 120),
-    "c4": (dict(adim=512, heads=4, ff=2048, enc_blocks=6, dec_blocks=6), 4, 1600, 200),
+    # (A3T_C4_B=16: configs[3]'s own batch -- ~10 min and a few hundred GB of host memory for the oracle's backward; run once per
+    #  round by hand, profiles/r06_fullsize_c4_B16.txt; the suite's default stays 4)
+    "c4": (dict(adim=512, heads=4, ff=2048, enc_blocks=6, dec_blocks=6), int(os.environ.get("A3T_C4_B", "4")), 1600, 200),
 }
 _ORACLE = {}
 
