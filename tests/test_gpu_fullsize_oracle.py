@@ -4,7 +4,7 @@ The fixtures generated from the imported reference stop at B = 2, T = 230.  Code
 key-split tail blocks and multi-round grids of the fused attention forward, 224-panel GEMM launches, the 48-deep
 side-stream scratch ring, the 8-phase FFN GEMMs of configs[3] -- is held to the oracle here, on the shapes of
 BASELINE.json configs[1] (6+6 blocks, d=384, B=32, T_mel=1000, T_phn=120) and configs[3] (6+6 blocks, d=512, H=4,
-T_mel=1600, T_phn=200; B=4, no x-vector: the x-vector add has no reference implementation), ragged lengths, procedural
+T_mel=1600, T_phn=200; B=16 since round 6, no x-vector: the x-vector add has no reference implementation), ragged lengths, procedural
 (non-zero) weights, dropout off.  The oracle (oracle/a3t_oracle.py) is itself pinned to the reference by
 tests/test_oracle_golden.py; it follows espnet2/tts/sedit/sedit_model.py:155-187, 320-375.
 
@@ -87,9 +87,10 @@ if _C2_B != _C2_FULL_B and os.environ.get("A3T_REQUIRE_FULL_B") == "1":
 _CASES = {
     # tag: (oracle config, B, T_mel, T_phn)
     "c2": (dict(enc_blocks=6, dec_blocks=6), _C2_B, 1000, 120),
-    # (A3T_C4_B=16: configs[3]'s own batch -- ~10 min and a few hundred GB of host memory for the oracle's backward; run once per
-    #  round by hand, profiles/r06_fullsize_c4_B16.txt; the suite's default stays 4)
-    "c4": (dict(adim=512, heads=4, ff=2048, enc_blocks=6, dec_blocks=6), int(os.environ.get("A3T_C4_B", "4")), 1600, 200),
+    # configs[3] at its own batch (round 6): B = 16 where the host can hold the oracle's backward (55 s on 32 threads of the MI355X box,
+    # ~150 GB of autograd state; it has 3 TB), B = 4 below 512 GB of host memory; A3T_C4_B overrides.  No x-vector (no reference).
+    "c4": (dict(adim=512, heads=4, ff=2048, enc_blocks=6, dec_blocks=6),
+           int(os.environ.get("A3T_C4_B", "16" if _host_ram_gb() >= 512 else "4")), 1600, 200),
 }
 _ORACLE = {}
 
