@@ -28,6 +28,45 @@ HBM_PEAK = 8000.0                            # GB/s
 TRAFFIC_FILE = "r06_hbm_traffic_per_kernel.json"   # this round's PMC summary (tools/r06_profiles.sh)
 
 
+def live_hbm_traffic(kernel_name, args, timeout=300):
+    """HBM bytes per launch of `kernel_name`, measured NOW: FETCH_SIZE and WRITE_SIZE in two SEPARATE rocprofv3 --pmc passes
+    (with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; FETCH_SIZE x2 on gfx950) over one warm-up + one
+    training step of this same command in a child process.  (bytes, fetch, write, note); bytes is None when rocprofv3 is not
+    there, a pass fails or times out -- the caller then falls back to the round's tracked file and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, None, None, "rocprofv3 is not on PATH"
+    per = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="a3t_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--compute", args.compute, "--batch", str(args.batch),
+               "--tmel", str(args.tmel), "--tphn", str(args.tphn), "--blocks", str(args.blocks), "--no-cpu-baseline",
+               "--no-vocoder", "--no-collate", "--no-kernel-profile", "--no-c4", "--no-live-traffic"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            n, tot = 0, 0.0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == c and kernel_name in r.get("Kernel_Name", ""):
+                        n += 1
+                        tot += float(r["Counter_Value"])
+            if not n:
+                return None, None, None, f"{c} pass: no counter rows for {kernel_name}"
+            per[c] = tot / n * 1024.0
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError) as e:
+            return None, None, None, f"{c} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = 2.0 * per["FETCH_SIZE"], per["WRITE_SIZE"]
+    return fetch + write, fetch, write, "measured in this run"
+
+
 def fwd_flops_per_step(c, B, Tm, Tp):
     """Algorithmic forward FLOPs (SURVEY §8d / BASELINE.md §4)."""
     T = Tm + Tp
@@ -365,6 +404,8 @@ def main():
     ap.add_argument("--fake-cpu", action="store_true", help="N-rank launch-path test on gloo/CPU (no kernels)")
     ap.add_argument("--comm-dtype", default="f32", choices=["f32", "bf16"], help="gradient all-reduce bucket dtype")
     ap.add_argument("--strict-traffic", action="store_true", help="exit instead of reporting traffic = null when this round's PMC file is missing")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with two rocprofv3 --pmc passes of a child process (the tracked file is used)")
     ap.add_argument("--threads", type=int, default=32)
     ap.add_argument("--budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -535,6 +576,17 @@ def main():
                     traffic = v["hbm_bytes_per_launch"]
                     traffic_source = ("profiles/" + TRAFFIC_FILE + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "command, FETCH_SIZE x2 for gfx950; a tracked file, not measured in this run)")
+        traffic_tracked = traffic
+        if world == 1 and not a.no_live_traffic:
+            log(f"HBM traffic of {name}: two rocprofv3 --pmc passes of a child process")
+            lt, lf, lw, lnote = live_hbm_traffic(name, a)
+            if lt is not None:
+                traffic = lt
+                traffic_source = (f"measured in THIS run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes with --kernel-trace "
+                                  f"over one step of this command in a child process; fetch {lf / 1e6:.1f} MB (FETCH_SIZE x2 for gfx950) + "
+                                  f"write {lw / 1e6:.1f} MB per launch")
+            elif traffic is not None:
+                traffic_source += f"; the live measurement was not available ({lnote})"
         if traffic is None:
             traffic_source = (f"MISSING: profiles/{TRAFFIC_FILE} has no entry for {name} -- run tools/r06_profiles.sh on the GPU box and "
                               "commit its output; traffic is null, not borrowed from an older round")
@@ -578,9 +630,10 @@ def main():
                              alone_frac=fa5 / ta5 / 1e12 / peak))
         roofline = dict(bound="mfma", kernel=name, launches=n, avg_us=tt / n * 1e6, achieved=achieved, peak=peak,
                         unit="TFLOP/s", frac=achieved / peak, traffic=traffic, traffic_source=traffic_source,
+                        traffic_tracked_file=traffic_tracked,
                         traffic_algorithmic=traffic_alg, ffn_gemm_classes_alone=gemm_classes,
-                        note="durations from HIP events inside the step; this kernel runs on the side stream and "
-                             "shares the GPU with the data-gradient chain, 'alone' = same step on one stream",
+                        note="durations from HIP events inside the step, where the kernel shares the GPU with the other streams' "
+                             "kernels (weight gradients, attention dV / dK); 'alone' = same step on one stream",
                         alone=dict(avg_us=ta / na * 1e6, achieved=fa / ta / 1e12, frac=fa / ta / 1e12 / peak),
                         all_gemms_alone=dict(tflops=sum(v[0] for v in alone.values()) / sum(v[1] for v in alone.values()) / 1e12,
                                              ms=sum(v[1] for v in alone.values()) * 1e3),

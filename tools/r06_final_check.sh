@@ -1,4 +1,8 @@
 mkdir -p gpurun_out
-(echo "== A3T_SIDE_STREAM=0 tests/test_gpu_e2e.py"; A3T_SIDE_STREAM=0 python -m pytest tests/test_gpu_e2e.py -x -q 2>&1 | grep -E "passed|failed") > gpurun_out/r06_final_checks.txt
-cat gpurun_out/r06_final_checks.txt
-bash tools/step_ab.sh "default:A3T_X=0" "optimizer_on_side_stream_probe:A3T_EXP_OPT_SIDE=1" "default2:A3T_X=0" "optimizer_on_side_stream_probe2:A3T_EXP_OPT_SIDE=1"
+t0=$(date +%s); python bench.py > gpurun_out/r06_bench_live.json 2> gpurun_out/r06_bench_live.log; t1=$(date +%s); echo "bench.py wall: $((t1-t0)) s"
+grep -E "bench " gpurun_out/r06_bench_live.log | tail -12
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r06_bench_live.json').read().strip().split('\n')[-1])
+r=d['roofline']; print(d['ms_per_step'], r['kernel'], r['traffic'], r['traffic_tracked_file']); print(r['traffic_source'])
+PY
