@@ -28,7 +28,7 @@ HBM_PEAK = 8000.0                            # GB/s
 TRAFFIC_FILE = "r06_hbm_traffic_per_kernel.json"   # this round's PMC summary (tools/r06_profiles.sh)
 
 
-def live_hbm_traffic(kernel_name, args, timeout=300):
+def live_hbm_traffic(kernel_name, args, timeout=120):
     """HBM bytes per launch of `kernel_name`, measured NOW: FETCH_SIZE and WRITE_SIZE in two SEPARATE rocprofv3 --pmc passes
     (with --kernel-trace only, as MI355X_MICROARCH.md's HBM section prescribes; FETCH_SIZE x2 on gfx950) over one warm-up + one
     training step of this same command in a child process.  (bytes, fetch, write, note); bytes is None when rocprofv3 is not
