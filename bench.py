@@ -402,6 +402,9 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--fake-cpu", action="store_true", help="N-rank launch-path test on gloo/CPU (no kernels)")
+    ap.add_argument("--one-gpu-gloo", action="store_true",
+                    help="dry run of the N-rank path on a 1-GPU box: every rank on cuda:0, gloo as the transport (RCCL refuses two "
+                         "ranks on one device); the line it prints is marked and is not a measurement")
     ap.add_argument("--comm-dtype", default="f32", choices=["f32", "bf16"], help="gradient all-reduce bucket dtype")
     ap.add_argument("--strict-traffic", action="store_true", help="exit instead of reporting traffic = null when this round's PMC file is missing")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -429,13 +432,18 @@ def main():
     if a.fake_cpu:
         fake_cpu_rank(a, rank, world)
         return
-    if torch.cuda.device_count() < world:
+    if a.one_gpu_gloo:
+        local = 0
+    elif torch.cuda.device_count() < world:
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.one_gpu_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but the RCCL group has {dist.get_world_size()} ranks")
 
@@ -656,6 +664,8 @@ def main():
         }
         if comm is not None:
             out["comm"] = comm
+        if a.one_gpu_gloo:
+            out["dry_run"] = f"{world} ranks share cuda:0 over gloo: the N-rank code path, NOT a throughput measurement"
         if world == 1 and not a.no_vocoder:
             log("vocoder leg (ParallelWaveGAN v1, 8 x 1000 frames)")
             out["vocoder"] = vocoder_rtf(dev, cpu=not a.no_cpu_baseline)

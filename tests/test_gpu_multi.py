@@ -163,3 +163,25 @@ def test_two_gpu_training_steps_keep_the_replicas_identical():
 def test_two_ranks_on_one_gpu_over_gloo_training_steps_keep_the_replicas_identical():
     """The same three steps with both ranks on cuda:0 and gloo as the transport: runs on every 1-GPU box."""
     _replica_case("gloo", True)
+
+
+@pytest.mark.skipif(NGPU < 1, reason="needs a GPU")
+def test_bench_n_rank_path_dry_run_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2 --one-gpu-gloo` (round 6): the N-rank path of the benchmark -- self-launch, rank-count check,
+    strided weak-scaling batch, reducer-driven step, the `comm` object (exchange alone, step without the exchange), max over
+    ranks, ONE JSON line from rank 0 -- end to end on a 1-GPU box.  Its numbers are not measurements and the line says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-gpu-gloo", "--blocks", "1", "--batch", "4",
+                        "--tmel", "200", "--tphn", "24", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8 and "dry_run" in d
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["dist_world_size"] == 2 and c["buckets"] >= 1 and c["allreduce_ms_alone"] > 0
+    assert d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
