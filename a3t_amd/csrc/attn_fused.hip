@@ -107,6 +107,9 @@ __device__ __forceinline__ unsigned lds_base(const void* smem0) { return (unsign
 // (M0 is written and consumed inside the one statement.  It cannot be declared as a clobber -- hipcc: "inline asm clobber list
 //  contains reserved registers: m0 ... may lead to undefined behaviour" -- so the kernels that call this use no other M0 consumer:
 //  no LDS-DMA builtin, s_movrel, sendmsg or GWS; the gfx950 compiler does not keep values in M0 across statements on its own.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "buffer_load_dwordx4 ... lds (16-byte LDS-DMA) exists on gfx950 only: build with --offload-arch=gfx950"
+#endif
 __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff) {
     const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(la), "v"(voff), "s"(r) : "memory");

@@ -57,6 +57,9 @@ typedef unsigned short u16;
 // kernels wait for it themselves (counted vmcnt + s_barrier, as written).  M0 is set in the same statement that uses it; it cannot
 // be listed as a clobber (hipcc rejects reserved registers there), so the token-reduction kernels use no other M0 consumer.
 __device__ __forceinline__ unsigned g8_lds_base(const void* smem0) { return (unsigned)(uintptr_t)LDS_AS(smem0); }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "buffer_load_dwordx4 ... lds (16-byte LDS-DMA) exists on gfx950 only: build with --offload-arch=gfx950"
+#endif
 __device__ __forceinline__ void g8_dma16(const __amdgpu_buffer_rsrc_t& r, unsigned lds_addr, unsigned voff, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
