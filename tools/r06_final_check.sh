@@ -1,8 +1,6 @@
+# final check of a round on the GPU box: the full GPU suite, the e2e tests under the one-stream schedule, smoke(), the default bench line
 mkdir -p gpurun_out
-t0=$(date +%s); python bench.py > gpurun_out/r06_bench_live.json 2> gpurun_out/r06_bench_live.log; t1=$(date +%s); echo "bench.py wall: $((t1-t0)) s"
-grep -E "bench " gpurun_out/r06_bench_live.log | tail -12
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r06_bench_live.json').read().strip().split('\n')[-1])
-r=d['roofline']; print(d['ms_per_step'], r['kernel'], r['traffic'], r['traffic_tracked_file']); print(r['traffic_source'])
-PY
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed" | tail -1
+A3T_SIDE_STREAM=0 python -m pytest tests/test_gpu_e2e.py -x -q 2>&1 | grep -E "passed|failed" | tail -1
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep "smoke"
+python bench.py 2> gpurun_out/bench_final.log | tee gpurun_out/bench_final.json | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); r=d['roofline']; print(d['ms_per_step'], d['value'], r['kernel'], round(r['frac'],3), r['traffic'], d['c4']['ms_per_step'])"
