@@ -537,3 +537,39 @@ def test_fused_forward_is_deterministic_at_full_size(B, H, T, dk):
         for a, b in zip(o, outs[0]):
             assert torch.equal(a, b)
     assert bool(torch.isfinite(outs[0][0].float()).all())
+
+
+@pytest.mark.parametrize("B,H,T,dk,lengths", [(2, 2, 328, 192, [328, 211]), (3, 4, 264, 128, None), (2, 2, 104, 64, [104, 57]),
+                                              (32, 2, 1120, 192, None)])
+def test_positional_biases_added_inside_the_kernels_equal_the_add_pos_bias_tensors_bit_for_bit(B, H, T, dk, lengths):
+    """Round 6: with bias_u / bias_v the fused kernels read q from the q|k|v projection and form bf16(q + pos_bias_u) /
+    bf16(q + pos_bias_v) as they load their query fragments (attention.py:190-194; biases staged in LDS).  Every output --
+    ctx, lse, the saved probabilities and their dropped copy, 1 / row sum -- is bit-identical to the launch on the two
+    tensors a3t_add_pos_bias stores, for the training forward, the forward-only pass and (full size) the key-split tail."""
+    from a3t_amd import ops
+    rs = np.random.RandomState(7 * T + dk)
+    d = H * dk
+    qkv, _, _, P, keymask = _inputs(B, H, T, dk, seed=T + dk, lengths=lengths)
+    u = torch.from_numpy((rs.standard_normal(d) * 0.3).astype(np.float32)).to(DEV)
+    v = torch.from_numpy((rs.standard_normal(d) * 0.3).astype(np.float32)).to(DEV)
+    qu = torch.empty(B * T, d, device=DEV, dtype=torch.bfloat16)
+    qv = torch.empty_like(qu)
+    ops.add_pos_bias(qkv, u, v, qu, qv)
+    scale, drop = 1.0 / math.sqrt(dk), (0.2, 0xBEEF)
+
+    def train(pos_bias):
+        ctx = torch.zeros(B * T, d, device=DEV, dtype=torch.bfloat16)
+        lse, rsc = torch.zeros(B, H, T, device=DEV), torch.zeros(B, H, T, device=DEV)
+        probs = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+        pdrop = torch.zeros_like(probs)
+        ops.attn_fwd_train(None if pos_bias else qu, None if pos_bias else qv, qkv, P, keymask, ctx, lse, probs, pdrop, rsc, B, H, T,
+                           scale, drop=drop, pos_bias=pos_bias)
+        ctx2, lse2 = torch.zeros_like(ctx), torch.zeros_like(lse)
+        ops.attn_fwd(None if pos_bias else qu, None if pos_bias else qv, qkv, P, keymask, ctx2, lse2, B, H, T, scale, drop=drop,
+                     pos_bias=pos_bias)
+        torch.cuda.synchronize()
+        return ctx, lse, rsc, probs, pdrop, ctx2, lse2
+    a, b = train(None), train((u, v))
+    for x, y, name in zip(a, b, ("ctx", "lse", "rowscale", "probs", "pdrop", "ctx (forward only)", "lse (forward only)")):
+        assert torch.equal(x, y), name
+    assert float(a[0].float().abs().max()) > 0
