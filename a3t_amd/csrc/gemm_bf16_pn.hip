@@ -14,14 +14,16 @@
 // Structure (the discipline of the 8-phase kernel, gemm_bf16_8p.hip, on a different tile):
 //   * 8 waves = 2 (wr) x 4 (wc); wave tile 80 x 96 = 5 x 6 blocks of v_mfma_f32_16x16x32_bf16 (120 accumulator registers);
 //   * LDS = 2 K-tile buffers x {A: 160 rows, B lo: 192 rows, B hi: 192 rows} x 64 k (68 KiB per buffer);
-//   * a K-tile is four phases of 15 MFMA: (k-step 0, B lo) (k-step 1, B lo) (k-step 0, B hi) (k-step 1, B hi); the A fragments
-//     of both k-steps stay in registers for the whole K-tile, every LDS region is read in two ADJACENT phases;
-//   * phase = [ds_read_b128 fragments | DMA issue | counted wait] s_barrier [lgkmcnt(0) | setprio 1 | 15 MFMA | setprio 0]
-//     s_barrier; waves 4-7 run one barrier behind waves 0-3 (each SIMD holds one wave of each group);
-//   * DMA (buffer_load ... lds, 1 KiB per wave instruction): B hi of K-tile t+1 in phase 2, A and B lo of K-tile t+2 in phase 4
-//     -- two phases after the last read of the region they overwrite, four phases ahead of their first read; 9 instructions
-//     per wave and K-tile (the A image is 2.5 per wave: waves 4-7 repeat the third instruction of waves 0-3 -- same bytes to
-//     the same address -- so that every wave counts alike), two counted waits (vmcnt(9)) per K-tile;
+//   * a K-tile is two phases of 30 MFMA (round 6; four of 15 before): (k-steps 0 and 1, B lo) (k-steps 0 and 1, B hi); the A
+//     fragments of both k-steps stay in registers for the whole K-tile;
+//   * phase = [ds_read_b128 fragments | DMA issue | counted vmcnt | lgkmcnt(0)] s_barrier [setprio 1 | 30 MFMA | setprio 0]
+//     s_barrier; waves 4-7 run one barrier behind waves 0-3 (each SIMD holds one wave of each group: their MFMA segments
+//     alternate).  The fragment reads are waited for IN FRONT of the barrier, so every read issued before a barrier has retired
+//     when it releases and a DMA issued behind it may overwrite what was read (see the K loop);
+//   * DMA (buffer_load ... lds, 1 KiB per wave instruction): B hi of K-tile t+1 in phase A, A and B lo of K-tile t+2 in phase B
+//     -- one phase behind the last read of the region they overwrite, two to three phases ahead of their first read; 9
+//     instructions per wave and K-tile (the A image is 2.5 per wave: waves 4-7 repeat the third instruction of waves 0-3 -- same
+//     bytes to the same address -- so that every wave counts alike), two counted waits (vmcnt(9)) per K-tile;
 //   * conv padding, utterance boundaries, the M tail and the K-tiles past the end read zeros through the buffer descriptor's
 //     range check (voffset = 0x80000000): the steady state is branch-free;
 //   * B rows are permuted in the LDS image so that lane group g of wave wc owns the 8 consecutive columns
@@ -285,40 +287,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
             BAR();
             if (wr == 1) BAR();    // second group runs one barrier behind
 
+            // A K-tile = TWO phases of 30 MFMAs (round 6; four of 15 before): (both k-steps x B lo) (both k-steps x B hi).  The MFMA
+            // segments of the two wave groups alternate on a SIMD with a hand-over of ~90 cycles at every barrier
+            // (profiles/r06_pn_segments.txt): half the barriers, half the hand-overs.  What makes the longer phases safe: a wave
+            // waits for its fragment reads BEFORE the phase's first barrier (lgkmcnt(0), free -- it would wait there for the other
+            // group's MFMA segment anyway), so when a barrier releases, every fragment read that any wave issued in front of it
+            // has retired, and a DMA issued behind it may overwrite what those reads read:
+            //   phase A of K-tile kt: B hi of K-tile kt+1 -> the other buffer (last read in phase B of kt-1, by the trailing
+            //   group in front of the barrier this group has just passed);  phase B: A and B lo of K-tile kt+2 -> this buffer
+            //   (last read in phase A of kt).  Waits as before: vmcnt(9) in phase A retires B hi of THIS K-tile, in phase B the A and
+            //   B lo of the next one; the barrier behind the wait makes it everyone's.
             auto ktile = [&](const int kt, const int b) __attribute__((always_inline)) {
                 const unsigned char* cur = smem + b * BUF_BYTES;
-                // phase 1: k-step 0 x B lo
+                // phase A: k-steps 0, 1 x B lo
                 readB(cur, 0, 0, fbx);
-                readA(cur, 0);
-                BAR();
-                WAIT_LGKM(0);
-                SB();
-                mm(0, 0, fbx);
-                BAR();
-                // phase 2: k-step 1 x B lo.  DMA: B hi of the next K-tile (that region was last read two phases ago)
                 readB(cur, 0, 1, fby);
+                readA(cur, 0);
                 readA(cur, 1);
                 issueB(1, kt + 1, b ^ 1);
-                WAIT_VM(9);            // B hi of THIS K-tile has landed (this wave's share; the barrier makes it everyone's)
-                BAR();
+                WAIT_VM(9);
                 WAIT_LGKM(0);
-                SB();
+                BAR();
+                mm(0, 0, fbx);
                 mm(0, 1, fby);
                 BAR();
-                // phase 3: k-step 0 x B hi
+                // phase B: k-steps 0, 1 x B hi
                 readB(cur, 1, 0, fbx);
-                BAR();
-                WAIT_LGKM(0);
-                SB();
-                mm(1, 0, fbx);
-                BAR();
-                // phase 4: k-step 1 x B hi.  DMA: A and B lo of K-tile + 2 into this buffer (last read in phase 2)
                 readB(cur, 1, 1, fby);
                 issueA(b), issueB(0, kt + 2, b);
-                WAIT_VM(9);            // A and B lo of the next K-tile have landed
-                BAR();
+                WAIT_VM(9);
                 WAIT_LGKM(0);
-                SB();
+                BAR();
+                mm(1, 0, fbx);
                 mm(1, 1, fby);
                 BAR();
             };
