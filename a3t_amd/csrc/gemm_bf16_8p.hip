@@ -32,9 +32,6 @@
 #include <stdlib.h>
 #include "../../include/a3t_hip.h"
 #include "gemm_common.h"
-#ifndef TN3_MFMA_PRIO
-#define TN3_MFMA_PRIO 1
-#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -908,7 +905,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8p_tn3_kernel(GP p, TN3Group
         for (int j = 0; j < 2; ++j) f[j][0] = frag(img, offB[j], 0), f[j][1] = frag(img, offB[j], 1);
     };
     auto quad = [&](const int hb, const bf16x8(&f)[2][2]) __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(TN3_MFMA_PRIO);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll

@@ -41,9 +41,6 @@
 #include <stdlib.h>
 #include "../../include/a3t_hip.h"
 #include "gemm_common.h"
-#ifndef PN_MFMA_PRIO
-#define PN_MFMA_PRIO 1
-#endif
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -268,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
                 for (int j = 0; j < 3; ++j) fb[j] = *(const bf16x8*)(buf + hb * BH_BYTES + j * 2048 + (s ? (boff ^ 64u) : boff));
             };
             auto mm = [&](const int hb, const int s, const bf16x8(&fb)[3]) __attribute__((always_inline)) {
-                __builtin_amdgcn_s_setprio(PN_MFMA_PRIO);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
 #pragma unroll
