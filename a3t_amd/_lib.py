@@ -99,6 +99,7 @@ _SIGS = {
     "a3t_gemm_8p_mode": [c_int],
     "a3t_gemm_8p_supported": [c_int, c_int, c_int, c_int, c_int],
     "a3t_gemm_pn_mode": [c_int],
+    "a3t_gemm_tt_mode": [c_int],
     "a3t_gemm_tn3_mode": [c_int],
     "a3t_gemm_tn3_group": [_P, c_int, _P],
     "a3t_attn_split_mode": [c_int],

@@ -8,14 +8,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liba3t_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16_8p.hip", "gemm_bf16_pn.hip", "attn_fused.hip", "norm_reduce.hip", "convmod_attn.hip", "dwconv_vec.hip", "misc.hip", "pwg_fused.hip", "features.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16_8p.hip", "gemm_bf16_pn.hip", "gemm_bf16_tt.hip", "attn_fused.hip", "norm_reduce.hip", "convmod_attn.hip", "dwconv_vec.hip", "misc.hip", "pwg_fused.hip", "features.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("A3T_EXTRA_FLAGS", "").split()
 
 
 # The direct-to-LDS GEMM variants are tuned to a register budget (<= 128 VGPRs = 4 workgroups per CU); a harmless
 # looking edit can push one over the edge and cost 30-50 % on that GEMM class.  The build records what the compiler
 # allocated; tests/test_host_logic.py::test_gemm_register_budget checks it.
-RES_SOURCES = ("gemm_bf16.hip", "gemm_bf16_8p.hip", "gemm_bf16_pn.hip", "attn_fused.hip", "norm_reduce.hip")
+RES_SOURCES = ("gemm_bf16.hip", "gemm_bf16_8p.hip", "gemm_bf16_pn.hip", "gemm_bf16_tt.hip", "attn_fused.hip", "norm_reduce.hip")
 RES_FLAG = ["-Rpass-analysis=kernel-resource-usage"]
 
 

@@ -458,6 +458,7 @@ static inline bool m8(int64_t v) { return (v % 8) == 0; }
 
 int a3t_gemm_bf16_8p(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_8p.hip
 int a3t_gemm_bf16_pn(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_pn.hip
+int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream);   // gemm_bf16_tt.hip
 
 template <int LY, int ST, int WM, int CV, int WN = 2>
 static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
@@ -494,6 +495,10 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
     }
     {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
         const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
+        if (rc != -1) return rc;
+    }
+    if (!BKC && !(pv.keep_in || pv.keep_out)) {   // score-sized A operand x [k][n] slices (attention backward): one streaming workgroup per CU
+        const int rc = a3t_gemm_bf16_tt(pv, batch, AK ? L_NN : L_TN, stream);
         if (rc != -1) return rc;
     }
     static int forced_st = -1;

@@ -363,6 +363,10 @@ const char* a3t_gemm_last_kernel(void);
 int a3t_gemm_8p_mode(int mode);
 /* The same switch for the 384-column panel GEMM (A3T_GEMM_PN). */
 int a3t_gemm_pn_mode(int mode);
+/* The same switch for the streaming GEMM of the attention backward's score-sized products (dS K, dBD P, P^T dctx, dS^T (q+u):
+ * espnet attention.py:64-96,145-209; gemm_bf16_tt.hip): 0 never, 1 whenever legal, 2 (default) when the grid fills the chip
+ * (A3T_GEMM_TT). */
+int a3t_gemm_tt_mode(int mode);
 /* Weight gradients (token reductions, multi_layer_conv.py:52-63 / torch.nn.Linear backward): 0 = never use the 128 x 384-tile
  * 8-phase kernel with the deterministic split-K fold, 1 = whenever the descriptor is legal for it, 2 (default) = when its tiles
  * cover the output to >= 85 % and the launch has >= 96 workgroups, -1 = re-read A3T_GEMM_8P_TN3.  Returns the previous mode.

@@ -953,3 +953,96 @@ def test_release_workspaces_frees_the_split_k_slabs_and_the_next_launch_allocate
     b = run()
     assert free1 >= free0 and torch.equal(a, b)
     assert lib.a3t_release_workspaces() == 0 and lib.a3t_release_workspaces() == 0        # idempotent
+
+
+@pytest.mark.parametrize("B,H,T,dk", [(2, 2, 328, 192), (3, 4, 520, 128), (1, 2, 1120, 192), (2, 1, 264, 96), (1, 3, 648, 160)])
+def test_streaming_attention_backward_gemm_matches_the_128_row_kernel_and_the_fp32_product(B, H, T, dk):
+    """gemm_bf16_tt.hip (round 6): the score-sized products of the attention backward (espnet attention.py:64-96,145-209) --
+    dS K and dBD P ([m][k] operand, the second one added to the stored bf16 in fp32), P^T dctx / dS^T (q+u) ([k][m] operand) --
+    on the one-workgroup-per-CU streaming kernel: same bf16 bits as the 128-row kernel (both sum the K-tiles in ascending order
+    in fp32), column sums equal to fp32 accumulation noise, and both within bf16 rounding of the fp32 product.  Shapes cover
+    K tails (T % 32 = 8), row tiles that end inside a tile, N = 96 / 128 / 160 / 192 and a batch-shared B operand."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import ACC_ADD, ACC_STORE, BF16
+    ops = _ops()
+    lib = _lib.load()
+    d, M = H * dk, B * T
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + T + dk)
+    S = (torch.randn(B, H, T, T, device=DEV, generator=g) * 0.1).bfloat16()
+    qkv = torch.randn(M, 3 * d, device=DEV, generator=g).bfloat16()
+    x = torch.randn(M, d, device=DEV, generator=g).bfloat16()
+    P = torch.randn(T, d, device=DEV, generator=g).bfloat16()
+    zb = (H * T * T, T * T)
+    NS = 4
+    Sf = S.float()
+
+    def products(mode):
+        old = lib.a3t_gemm_tt_mode(mode)
+        try:
+            sl = torch.zeros(NS * 4 * d, device=DEV)
+            csk = dict(colsum_bs1=dk, colsum_slots=NS, colsum_ss=4 * d)
+            out = torch.full((M, 3 * d), 0.25, device=DEV).bfloat16()
+            names = []
+            ops.gemm(S, qkv.view(-1)[d:], out, T, dk, T, T, 1, 1, 3 * d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb,
+                     b_bs=(T * 3 * d, dk), c_bs=(T * 3 * d, dk), compute=BF16, colsum=sl, **csk)
+            names.append(lib.a3t_gemm_last_kernel().decode())
+            ops.gemm(S, P, out, T, dk, T, T, 1, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk),
+                     c_bs=(T * 3 * d, dk), acc=ACC_ADD, alpha=0.5, compute=BF16, colsum=sl[d:], **csk)
+            names.append(lib.a3t_gemm_last_kernel().decode())
+            ops.gemm(S, x, out.view(-1)[2 * d:], T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb,
+                     b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=BF16, colsum=sl[3 * d:], **csk)
+            names.append(lib.a3t_gemm_last_kernel().decode())
+            torch.cuda.synchronize()
+            return out, sl.view(NS, 4 * d).sum(0), names
+        finally:
+            lib.a3t_gemm_tt_mode(old)
+
+    o0, s0, n0 = products(0)
+    o1, s1, n1 = products(1)
+    assert all("gemm_bf16_tt_kernel" not in n for n in n0) and all("gemm_bf16_tt_kernel" in n for n in n1), (n0, n1)
+    assert n1[0].startswith("gemm_bf16_tt_kernel<false") and n1[2].startswith("gemm_bf16_tt_kernel<true")
+    assert torch.equal(o0, o1)
+    assert torch.allclose(s0, s1, rtol=1e-4, atol=1e-3 * float(s0.abs().max()))
+    # fp32 products of the same bf16 operands
+    K_ = qkv.float().view(B, T, 3, H, dk)[:, :, 1].permute(0, 2, 1, 3)            # [B][H][T][dk]
+    X_ = x.float().view(B, T, H, dk).permute(0, 2, 1, 3)
+    P_ = P.float().view(T, H, dk).permute(1, 0, 2)
+    q1 = torch.matmul(Sf, K_)
+    q2 = 0.5 * torch.matmul(Sf, P_.unsqueeze(0))
+    v = torch.matmul(Sf.transpose(2, 3), X_)
+    got = o1.float().view(B, T, 3, H, dk)
+    ref_q = (q1.bfloat16().float() + q2).permute(0, 2, 1, 3)       # the first product is stored in bf16, the second added in fp32
+    ref_v = v.permute(0, 2, 1, 3)
+    assert (got[:, :, 0] - ref_q).abs().max() <= 2e-2 * float(ref_q.abs().max())
+    assert (got[:, :, 2] - ref_v).abs().max() <= 2e-2 * float(ref_v.abs().max())
+    assert torch.equal(got[:, :, 1], torch.full_like(got[:, :, 1], 0.25))         # the k third was nobody's output
+    ref_cs = torch.cat([q1.sum(dim=(0, 2)).reshape(-1), q2.sum(dim=(0, 2)).reshape(-1)])      # sums of the increments, [h][n]
+    assert torch.allclose(s1[:2 * d], ref_cs, rtol=2e-2, atol=2e-2 * float(ref_cs.abs().max()))
+
+
+def test_streaming_attention_backward_gemm_cost_model_and_unsupported_epilogues_fall_back():
+    """Default mode: the streaming kernel takes the configs[1] attention shape (256 workgroups = one round) and leaves a grid that
+    fills a third of the chip, a short reduction and every epilogue it does not implement (bias, fp32 output) to the 128-row kernel."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import BF16
+    ops = _ops()
+    lib = _lib.load()
+    old = lib.a3t_gemm_tt_mode(2)
+    try:
+        def kernel(B, H, T, dk, out_dtype=torch.bfloat16, bias=False):
+            d, M = H * dk, B * T
+            S = torch.zeros(B, H, T, T, device=DEV).bfloat16()
+            x = torch.zeros(M, d, device=DEV).bfloat16()
+            out = torch.zeros(M, d, device=DEV, dtype=out_dtype)
+            ops.gemm(S, x, out, T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=(H * T * T, T * T), b_bs=(T * d, dk),
+                     c_bs=(T * d, dk), compute=BF16, bias=torch.zeros(dk, device=DEV) if bias else None)
+            torch.cuda.synchronize()
+            return lib.a3t_gemm_last_kernel().decode()
+        assert kernel(32, 2, 1120, 192).startswith("gemm_bf16_tt_kernel<false, 3>")
+        assert kernel(16, 4, 1120, 128).startswith("gemm_bf16_tt_kernel<false, 2>")
+        assert "tt_kernel" not in kernel(4, 2, 1120, 192)          # 32 workgroups
+        assert "tt_kernel" not in kernel(32, 2, 384, 192)          # K = 384
+        assert "tt_kernel" not in kernel(32, 2, 1120, 192, out_dtype=torch.float32)
+        assert "tt_kernel" not in kernel(32, 2, 1120, 192, bias=True)
+    finally:
+        lib.a3t_gemm_tt_mode(old)
