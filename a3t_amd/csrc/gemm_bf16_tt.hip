@@ -301,11 +301,12 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
     const int TR = (((p.M + tiles - 1) / tiles) + 31) / 32 * 32;
     const long units = (long)tiles * batch;
     if (mode == 2) {
-        // the kernel is one workgroup per CU and pays ~8 us of fill and epilogue per tile: long reductions over a score-sized
-        // operand on a grid that fills most of a round (configs[1]: 256 workgroups, K = 1120)
+        // the kernel is one workgroup per CU and pays ~10 us of fill and epilogue per tile: long reductions over a score-sized
+        // operand on a grid that fills its rounds (configs[1]: 256 workgroups = one round, K = 1120; configs[3]'s 384 workgroups =
+        // 1.5 rounds measured 0.3 ms per step slower than the 128-row kernel, profiles/r06_c4_ab_final.txt)
         const int cus = tt_cus();
         const long rounds = (units + cus - 1) / cus;
-        if (p.K < 512 || p.M < 256 || p.N < 96 || units * 10 < rounds * cus * 7) return -1;
+        if (p.K < 512 || p.M < 256 || p.N < 96 || units * 10 < rounds * cus * 9) return -1;
     }
     GP pv = p;
     pv.ntiles = tiles;
