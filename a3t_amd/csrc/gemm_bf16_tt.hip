@@ -297,16 +297,27 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
     // one batch element's operands through 32-bit buffer offsets
     const int64_t a_ld = ly == 1 ? p.a_rs : p.a_cs;
     if (a_ld * 2 * (int64_t)(ly == 1 ? p.M : p.K) >= (1ll << 31) || p.b_cs * 2 * (int64_t)p.K >= (1ll << 31)) return -1;
-    const int tiles = (p.M + TT_MAX_ROWS - 1) / TT_MAX_ROWS;
-    const int TR = (((p.M + tiles - 1) / tiles) + 31) / 32 * 32;
+    // Row tiling: the fewest workgroup-rounds x rows per tile.  A workgroup streams its rows' share of A whatever happens beside
+    // it, so the launch takes rounds(tiles x batch) x (TR + ~64 rows' worth of fill and epilogue): configs[1] (M = 1120, 64 batch
+    // elements) -> 4 tiles of 288 rows = 256 workgroups = one round; configs[3] (M = 1800) -> 8 tiles of 256 rows = two full rounds
+    // (6 tiles of 320 would be 1.5 rounds for the price of two).  A last tile with a few rows is cheap (its A pieces are zeros).
+    const int cus = tt_cus();
+    int tiles = 0, TR = 0;
+    long best = 0;
+    for (int t = (p.M + TT_MAX_ROWS - 1) / TT_MAX_ROWS, n = 0; n < 6; ++t, ++n) {
+        const int tr = (((p.M + t - 1) / t) + 31) / 32 * 32;
+        if (tr > TT_MAX_ROWS || (long)tr * (t - 1) >= p.M) continue;       // (an empty last tile: t is not a tiling of its own)
+        const long cost = (((long)t * batch + cus - 1) / cus) * (tr + 64);
+        if (!tiles || cost < best) tiles = t, TR = tr, best = cost;
+    }
+    if (!tiles) return -1;
     const long units = (long)tiles * batch;
     if (mode == 2) {
-        // the kernel is one workgroup per CU and pays ~10 us of fill and epilogue per tile: long reductions over a score-sized
-        // operand on a grid that fills its rounds (configs[1]: 256 workgroups = one round, K = 1120; configs[3]'s 384 workgroups =
-        // 1.5 rounds measured 0.3 ms per step slower than the 128-row kernel, profiles/r06_c4_ab_final.txt)
-        const int cus = tt_cus();
-        const long rounds = (units + cus - 1) / cus;
-        if (p.K < 512 || p.M < 256 || p.N < 96 || units * 10 < rounds * cus * 9) return -1;
+        // long reductions over a score-sized operand on ONE well-filled round of the chip (configs[1]).  Two rounds pay the first
+        // tile's latency and the epilogue twice with nothing beside them on the CU: configs[3] (M = 1800, d_k = 128: 512
+        // workgroups) runs these products in 135 / 155 / 110 us against 136 / 141 / 117 on the 128-row kernel and its step
+        // 0.3-0.4 ms slower (profiles/r06_tt_gemm.txt)
+        if (p.K < 512 || p.M < 256 || p.N < 96 || units > cus || units * TR * 4 > (long)p.M * batch * 5 || units * 10 < cus * 7) return -1;
     }
     GP pv = p;
     pv.ntiles = tiles;
