@@ -35,6 +35,7 @@ class GemmDesc(ctypes.Structure):
         ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("drop_key", ctypes.c_uint32),
         ("drop_p", c_float), ("colsum_ss", c_int32),
         ("keep_out", c_void_p), ("keep_in", c_void_p),
+        ("a_signmask", c_int32),
     ]
 
 
@@ -61,7 +62,7 @@ _SIGS = {
                            c_int64, c_float, c_float, ctypes.c_uint32, _P, _P, _P],
     "a3t_attn_scale_rows": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_attn_bwd_ds": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_float,
-                        c_float, ctypes.c_uint32, _P],
+                        c_float, ctypes.c_uint32, c_int, _P],
     "a3t_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                      c_float, c_float, ctypes.c_uint32, _P, _P, _P],
     "a3t_pwg_block": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],

@@ -502,8 +502,12 @@ __device__ __forceinline__ f32x16 mfma32(const bf16x8& a, const bf16x8& b, const
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NDB, bool DROP, bool SAVE, bool TWOPASS = false, bool SPLIT = false>
+template <int NDB, bool DROP, bool SAVE, bool TWOPASS = false, bool SPLIT = false, bool SGN = false>
 __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
+    // SGN (training with dropout, probs_drop == NULL): ONE saved tensor -- probs = exp(s - m_ref) with the sign bit set where the
+    // dropout mask dropped the element.  Its readers take |x| as the probability and the sign as the mask (a3t_attn_bwd_ds,
+    // a3t_gemm_desc::a_signmask for dV): the dropped copy (T x T per head, written here and read once) does not exist.
+    constexpr bool SG = SGN && DROP && SAVE;
     using D = DT32<NDB>;
     constexpr int DK = D::DK, KS = DK / 16, TB = D::BYTES, CPR = D::CPR, RB = D::RB, NPW = D::NP / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         if (SAVE && i < T)
             for (int c = 32 * sa_ + lh * 4; c < 32 * sb && c < T; c += 8) {
                 *(uint2*)(p.probs + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
-                if (DROP) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+                if (DROP && !SG) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
             }
         f32x16 Oz[NDB];
 #pragma unroll
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
                 if (lh == 0) p.rowscale[(int64_t)bh * T + i] = 0.f;
                 for (int c = lh * 4; c < T; c += 8) {
                     *(uint2*)(p.probs + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
-                    if (DROP) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+                    if (DROP && !SG) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
                 }
             }
         }
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     if (SAVE && i < T)                                    // key tiles in front of the first valid one are skipped: their probabilities are 0
         for (int c = 32 * sa_ + lh * 4; c < 32 * s0 && c < 32 * sb; c += 8) {
             *(uint2*)(p.probs + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
-            if (DROP) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
+            if (DROP && !SG) *(uint2*)(p.pdrop + ((int64_t)bh * T + i) * T + c) = make_uint2(0, 0);
         }
 
     // ---- DMA geometry: buffer descriptors whose range check supplies every zero (rows past the utterance, band rows
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 #endif
     const int ttb = (int)((unsigned)T * (unsigned)T * 2u);
     const __amdgpu_buffer_rsrc_t rSP = __builtin_amdgcn_make_buffer_rsrc(SAVE ? (void*)(p.probs + (int64_t)bh * T * T) : (void*)p.ctx, 0, ttb, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rSD = __builtin_amdgcn_make_buffer_rsrc((SAVE && DROP) ? (void*)(p.pdrop + (int64_t)bh * T * T) : (void*)p.ctx, 0, ttb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rSD = __builtin_amdgcn_make_buffer_rsrc((SAVE && DROP) ? (void*)((SG ? p.probs : p.pdrop) + (int64_t)bh * T * T) : (void*)p.ctx, 0, ttb, 0x00020000);
     f32x16 O[NDB];
 #pragma unroll
     for (int d = 0; d < NDB; ++d) O[d] = zero16();
@@ -880,12 +884,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             if (DROP) {
                 bool kp[4];
                 rng_keep4(p.drop_key, ibase + (unsigned int)(32 * s + 8 * g + 4 * lh), p.drop_thr, kp);
+                if (SG) {       // the saved probability itself, tagged: image 1 (the dropped copy's) carries the one tensor
+                    unsigned char* im = stg + (w * 2 + 1) * 2048;
+                    uint2 v2;
+                    v2.x = io_pack2(kp[0] ? pv[4 * g] : -pv[4 * g], kp[1] ? pv[4 * g + 1] : -pv[4 * g + 1]);
+                    v2.y = io_pack2(kp[2] ? pv[4 * g + 2] : -pv[4 * g + 2], kp[3] ? pv[4 * g + 3] : -pv[4 * g + 3]);
+                    *(uint2*)(im + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = v2;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) pv[4 * g + e] = kp[e] ? pv[4 * g + e] * p.drop_inv : 0.f;
             }
         };
         auto dsave = [&](const int g) __attribute__((always_inline)) {
-            if (SAVE && DROP) stage4(1, g);
+            if (SAVE && DROP && !SG) stage4(1, g);
         };
         // softmax slices over the KS product stages: exponentials first, then the dropout quads, then the packing
         // (measured: 4 / 6 / 8 exponential stages and a fence every stage or every second one all land within 2 %)
@@ -895,11 +906,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r)
                 if (r * EXS / 16 == t) expo(r);
             if (KS >= 8) {
-                if (t == EXS - 1 && SAVE) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3);   // (all sixteen exponentials are done after stage EXS - 1)
-                if (t == EXS + 1 && SAVE) flush(rSP, 0);
+                if (t == EXS - 1 && SAVE && !SG) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3);   // (all sixteen exponentials are done after stage EXS - 1)
+                if (t == EXS + 1 && SAVE && !SG) flush(rSP, 0);
                 if (t >= EXS && t < EXS + 4) drop4(t - EXS), dsave(t - EXS);
             } else if (t == KS - 1) {
-                if (SAVE) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3), flush(rSP, 0);
+                if (SAVE && !SG) stage4(0, 0), stage4(0, 1), stage4(0, 2), stage4(0, 3), flush(rSP, 0);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) drop4(g), dsave(g);
             }
@@ -963,7 +974,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     };
     typedef std::integral_constant<bool, false> FalseT;
     typedef std::integral_constant<bool, true> TrueT;
-    constexpr int NSV = SAVE ? (DROP ? 4 : 2) : 0;      // probability stores per iteration
+    constexpr int NSV = SAVE ? ((DROP && !SG) ? 4 : 2) : 0;      // probability stores per iteration
 
     for (int s = sa; s < sb; ++s) {
         // resident: K(s+1), V(s), ring tiles s+1 .. s+5; registers: Sc = S(s), bd = band values of step s
@@ -1037,6 +1048,7 @@ struct DsArgs {
     float scale, drop_inv;
     unsigned int drop_thr, drop_key;
     unsigned long long* timing;   // A3T_DS_TIMING builds: per-wave cycle totals of the eight phases
+    int signed_probs;     // the dropout mask is the sign bit of probs (a3t_attn_fwd_train without probs_drop)
 };
 
 // chunk ci (row-contiguous 16-byte pieces, chunk index fastest) of the wave's probability strip
@@ -1061,7 +1073,9 @@ __device__ __forceinline__ uint4 ds_ld_chunk(const u16* prB, int T, int q0, int 
 // T-1-i, keys >= i+2 into row i+1 from column 0) and are written in DESTINATION-aligned 16-byte chunks: five dwords of the
 // image funnel-shifted by the source's parity; the partial chunks at the ends of a run go out element by element.
 // V tiles are shared by the four waves: DMA into a double buffer, one barrier per tile.
-template <int NDB, bool DROP, int KT>
+// DROP: 0 no dropout, 1 the mask comes back from the counter RNG, 2 it is read off the sign bits of probs (the one-tensor save of
+// a3t_attn_fwd_train: p = |x|, dropped where x carries the sign bit)
+template <int NDB, int DROP, int KT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
     using D = DT32<NDB>;
     constexpr int DK = D::DK, KS = DK / 16, TB = D::BYTES, CPR = D::CPR, RS = KT * 64 + 16, IMG = 32 * RS, NPMIN = D::NP / 4;
@@ -1223,9 +1237,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint2 pk = *(const uint2*)(cell + 16 * g);
-                const float p0 = io_bf2f(pk.x & 0xffff), p1 = io_bf2f(pk.x >> 16), p2 = io_bf2f(pk.y & 0xffff), p3 = io_bf2f(pk.y >> 16);
+                const float p0 = __uint_as_float((pk.x << 16) & 0x7fffffffu), p1 = __uint_as_float(pk.x & 0x7fff0000u);
+                const float p2 = __uint_as_float((pk.y << 16) & 0x7fffffffu), p3 = __uint_as_float(pk.y & 0x7fff0000u);
                 float d0_ = dP[4 * g], d1_ = dP[4 * g + 1], d2_ = dP[4 * g + 2], d3_ = dP[4 * g + 3];
-                if (DROP) {
+                if (DROP == 2) {
+                    d0_ = (pk.x & 0x8000u) ? 0.f : d0_ * p.drop_inv, d1_ = (pk.x & 0x80000000u) ? 0.f : d1_ * p.drop_inv;
+                    d2_ = (pk.y & 0x8000u) ? 0.f : d2_ * p.drop_inv, d3_ = (pk.y & 0x80000000u) ? 0.f : d3_ * p.drop_inv;
+                } else if (DROP) {
                     const unsigned int i0 = ibase + (unsigned int)(32 * (c_sa + k) + 8 * g + 4 * lh);
                     const unsigned int h0 = rng_pair(p.drop_key, i0 >> 1), h1 = rng_pair(p.drop_key, (i0 >> 1) + 1), t = p.drop_thr >> 16;
                     d0_ = (h0 & 0xffffu) >= t ? d0_ * p.drop_inv : 0.f, d1_ = (h0 >> 16) >= t ? d1_ * p.drop_inv : 0.f;
@@ -1458,34 +1476,38 @@ static int launch_fwd16(const AttnArgs& a, hipStream_t s) {
             at.item0 = (int)nfull, at.nparts = nparts;
         }
         const bool split = at.part_ws != nullptr;
-#define A3T_L32(DR, SV)                                                                                                              \
+#define A3T_L32(DR, SV, SG)                                                                                                             \
     do {                                                                                                                             \
-        (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);   \
+        (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV, false, false, SG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);   \
         if (split) {                                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV, false, true>,                                      \
+            (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, DR, SV, false, true, SG>,                                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds32);                                            \
-            hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV, false, true>), dim3(nfull + ntail * nparts), dim3(256), lds32, s, at); \
+            hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV, false, true, SG>), dim3(nfull + ntail * nparts), dim3(256), lds32, s, at); \
             hipLaunchKernelGGL(attn_split_finish_kernel, dim3(ntail * 32), dim3(256), 0, s, at, (int)ntail, DT32<NDB>::DK);            \
         } else {                                                                                                                     \
-            hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV>), dim3(grid), dim3(256), lds32, s, a);                                 \
+            hipLaunchKernelGGL((attn_fwd32_kernel<NDB, DR, SV, false, false, SG>), dim3(grid), dim3(256), lds32, s, a);                                 \
         }                                                                                                                            \
     } while (0)
         if (a.probs) {
             // training: the fixup of an overflowed block has to re-write its saved probabilities too -> the same kernel with
             // a first sweep for the true row maximum (every block but the flagged ones exits at once)
-            if (a.drop_thr) {
-                A3T_L32(true, true);
+            if (a.drop_thr && !a.pdrop) {       // one saved tensor: the dropout mask rides on the sign bits of probs
+                A3T_L32(true, true, true);
+                (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, true, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
+                hipLaunchKernelGGL((attn_fwd32_kernel<NDB, true, true, true, false, true>), dim3(grid), dim3(256), lds32, s, a);
+            } else if (a.drop_thr) {
+                A3T_L32(true, true, false);
                 (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
                 hipLaunchKernelGGL((attn_fwd32_kernel<NDB, true, true, true>), dim3(grid), dim3(256), lds32, s, a);
             } else {
-                A3T_L32(false, true);
+                A3T_L32(false, true, false);
                 (void)hipFuncSetAttribute((const void*)attn_fwd32_kernel<NDB, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
                 hipLaunchKernelGGL((attn_fwd32_kernel<NDB, false, true, true>), dim3(grid), dim3(256), lds32, s, a);
             }
             return (int)hipGetLastError();
         } else {
-            if (a.drop_thr) A3T_L32(true, false);
-            else A3T_L32(false, false);
+            if (a.drop_thr) A3T_L32(true, false, false);
+            else A3T_L32(false, false, false);
         }
 #undef A3T_L32
         a16.use_redo = 1;        // the same grid again: a block exits at once unless its row sums overflowed
@@ -1501,7 +1523,7 @@ static bool attn_shape_ok(int dk, int T) { return dk % 32 == 0 && dk <= 192 && d
 
 extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v, const void* probs, const float* rowscale,
                                void* ds, void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb,
-                               int64_t dbd_bsh, float scale, float drop_p, uint32_t drop_key, void* stream) {
+                               int64_t dbd_bsh, float scale, float drop_p, uint32_t drop_key, int signed_probs, void* stream) {
     if (!attn_shape_ok(dk, T) || drop_p < 0.f || drop_p >= 1.f || !dctx || !ctx || !v || !probs || !rowscale || !ds || !dbd)
         return A3T_EINVAL;
     if (!al16(dctx) || !al16(ctx) || !al16(v) || !al16(probs) || !al16(ds) || !al16(dbd) || ldo % 8 || ldkv % 8 || dbd_bsb % 8 ||
@@ -1515,6 +1537,7 @@ extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v,
     a.scale = scale;
     a.drop_thr = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u, a.drop_key = drop_key, a.drop_inv = 1.f / (1.f - drop_p);
     a.timing = (unsigned long long*)g_attn_timing_buf;
+    a.signed_probs = (signed_probs && a.drop_thr) ? 1 : 0;
     // tasks = (128 queries) x (5 key tiles): several times more tasks than workgroup slots (2 per CU), so the last round is short
     constexpr int KT = 5;
     const int NS = (T + 31) / 32;
@@ -1530,8 +1553,9 @@ extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v,
     } while (0)
 #define A3T_DS(NDB)                      \
     do {                                 \
-        if (a.drop_thr) A3T_DS1(NDB, true); \
-        else A3T_DS1(NDB, false);        \
+        if (a.signed_probs) A3T_DS1(NDB, 2); \
+        else if (a.drop_thr) A3T_DS1(NDB, 1); \
+        else A3T_DS1(NDB, 0);            \
     } while (0)
     switch (dk / 32) {
         case 1: A3T_DS(1); break;
@@ -1613,7 +1637,7 @@ extern "C" int a3t_attn_fwd_train(const void* qu, const void* qv, const void* k,
                                   float* rowscale, int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp,
                                   int64_t ldo, float scale, float drop_p, uint32_t drop_key, const float* bias_u,
                                   const float* bias_v, void* stream) {
-    if (!probs || !rowscale || (drop_p > 0.f && !probs_drop) || (T % 8)) return A3T_EINVAL;
+    if (!probs || !rowscale || (T % 8)) return A3T_EINVAL;      // (drop_p > 0 without probs_drop: the sign-tagged single tensor)
     if (((uintptr_t)probs & 7) || ((uintptr_t)probs_drop & 7)) return A3T_EINVAL;
     return attn_fwd_impl(qu, qv, k, v, pos, keymask, ctx, lse, probs, drop_p > 0.f ? probs_drop : nullptr, rowscale, B, H, T, dk, ldq,
                          ldkv, ldp, ldo, scale, drop_p, drop_key, bias_u, bias_v, stream);

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
+    const short afloor = p.a_signmask ? (short)0 : (short)-32768;      // (a3t_gemm_desc::a_signmask; plain TN launches only)
     constexpr std::integral_constant<int, BM * 2> RB_A{};
     constexpr std::integral_constant<int, BN * 2> RB_B{};
 
@@ -373,6 +374,7 @@ __global__ __launch_bounds__(128 * WM, (WN == 3 ? (STAGES == 2 ? 2 : 3) : (STAGE
             } else {
                 a0 = frag_rc(sA, RB_A, wm, kk);
                 a1 = frag_rc(sA, RB_A, wm + 32, kk);
+                if (LAYOUT == L_TN && CONV == 0) a0 = a3t_sign_floor(a0, afloor), a1 = a3t_sign_floor(a1, afloor);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) bq[j] = B_KC ? frag_kc(sB, wn + 32 * j + lr, kk) : frag_rc(sB, RB_B, wn + 32 * j, kk);
@@ -489,11 +491,12 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
                  al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
     if (p.colsum && !pv.epi_vec) return -1;
 
-    if (!(pv.keep_in || pv.keep_out)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
+    if (p.a_signmask && (AK || BKC || p.taps > 1 || p.kshift_mode)) return -1;   // (fragment-register pass of the m-contiguous A only)
+    if (!(pv.keep_in || pv.keep_out || p.a_signmask)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
         const int rc = a3t_gemm_bf16_pn(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }
-    {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
+    if (!p.a_signmask) {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
         const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }

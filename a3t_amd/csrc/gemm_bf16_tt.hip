@@ -79,7 +79,7 @@ extern "C" int a3t_debug_read_tt(void* dst, size_t bytes) { return (int)hipMemcp
 #define TT_STAMP(k)
 #endif
 
-template <bool ATN, int NJ>
+template <bool ATN, int NJ, bool ASGN = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
             if (ATN)
-                fa[i] = frag_rc(sA, (rb0 + i) * 16);
+                fa[i] = ASGN ? a3t_sign_floor(frag_rc(sA, (rb0 + i) * 16), 0) : frag_rc(sA, (rb0 + i) * 16);     // (a3t_gemm_desc::a_signmask)
             else
                 fa[i] = *(const bf16x8*)(sA + (rb0 + i) * 1024 + offkc);
         }
@@ -278,10 +278,10 @@ static int tt_cus() {
     return n;
 }
 
-template <bool ATN, int NJ>
+template <bool ATN, int NJ, bool ASGN = false>
 static void launch_tt(const GP& pv, int TR, int grid, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_tt_kernel<ATN, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS);
-    hipLaunchKernelGGL((gemm_bf16_tt_kernel<ATN, NJ>), dim3(grid), dim3(512), TT_LDS, stream, pv, TR);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_tt_kernel<ATN, NJ, ASGN>, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS);
+    hipLaunchKernelGGL((gemm_bf16_tt_kernel<ATN, NJ, ASGN>), dim3(grid), dim3(512), TT_LDS, stream, pv, TR);
 }
 
 // Called by a3t_gemm_bf16_glds after the alignment contract has been checked (ly: 1 = NN, 2 = TN; B is [k][n], n-contiguous).
@@ -289,6 +289,7 @@ static void launch_tt(const GP& pv, int TR, int grid, hipStream_t stream) {
 int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
     const int mode = tt_mode();
     if (mode == 0 || (ly != 1 && ly != 2) || p.splitk != 1 || p.accumulate == A3T_ACC_ATOMIC) return -1;
+    if (p.a_signmask && ly != 2) return -1;
     if (p.taps > 1 || p.kshift_mode || p.keep_in || p.keep_out || !p.epi_vec) return -1;
     if (p.b_rs != 1 || p.N > 192 || p.N % 8 || p.M % 8 || p.K % 8) return -1;
     if (ly == 1 ? (p.a_cs != 1 || p.a_rs % 8) : (p.a_rs != 1 || p.a_cs % 8)) return -1;
@@ -322,7 +323,12 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
     GP pv = p;
     pv.ntiles = tiles;
     const int nj = p.N <= 128 ? 2 : 3;
-    if (ly == 2) {
+    if (ly == 2 && p.a_signmask) {
+        if (nj == 3)
+            launch_tt<true, 3, true>(pv, TR, (int)units, stream);
+        else
+            launch_tt<true, 2, true>(pv, TR, (int)units, stream);
+    } else if (ly == 2) {
         if (nj == 3)
             launch_tt<true, 3>(pv, TR, (int)units, stream);
         else
@@ -333,6 +339,6 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
         else
             launch_tt<false, 2>(pv, TR, (int)units, stream);
     }
-    a3t_note_kernel("gemm_bf16_tt_kernel<%s, %d>", ly == 2 ? "true" : "false", nj);
+    a3t_note_kernel("gemm_bf16_tt_kernel<%s, %d, %s>", ly == 2 ? "true" : "false", nj, (ly == 2 && p.a_signmask) ? "true" : "false");
     return (int)hipGetLastError();
 }

@@ -36,9 +36,20 @@ struct GP {
     unsigned int a_bytes, b_bytes;  // operand extents for the buffer descriptors
     float* slab;                    // token-reduction variant: split-K partial tiles (plain stores) for the deterministic fold
     int sole_writer;                // A3T_ACC_SOLE: the fold may add with plain read-modify-writes
+    int a_signmask;                 // A elements with the sign bit set are read as zero (m-contiguous bf16 A: gemm_bf16_tt.hip, gemm_bf16.hip L_TN)
 };
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return io_f2bf(f); }   // hardware RNE conversion
+
+// Sign-tagged bf16 operands (a3t_gemm_desc::a_signmask): a fragment of eight bf16 read as packed signed 16-bit integers -- an
+// element with the sign bit set is negative there, every other one is not -- and v_pk_max_i16 against `fl` = 0 turns the tagged
+// elements into +0 (fl = -32768: the identity).  Four VALU instructions per fragment.
+template <typename V>
+__device__ __forceinline__ V a3t_sign_floor(V v, short fl) {
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+    const s16x8_ f = {fl, fl, fl, fl, fl, fl, fl, fl};
+    return __builtin_bit_cast(V, __builtin_elementwise_max(__builtin_bit_cast(s16x8_, v), f));
+}
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
 template <typename T>

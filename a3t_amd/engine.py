@@ -205,6 +205,11 @@ class MLMEngine:
         # one launch and one [B][H][T] tensor less) at every supported d_k -- configs[3] (d_k = 128): 61.25 ms per step against
         # 62.33 / 62.30 with the materialised pair (profiles/r06_c4_ab.txt).  A3T_ATTN_BWD_DS=0: the materialised pair.
         self.attn_bwd_ds = os.environ.get("A3T_ATTN_BWD_DS", "1") != "0"
+        # With attention dropout the fused training forward saves ONE score-sized tensor: exp(s - m_ref) with the dropout mask in its
+        # sign bits (a3t_attn_fwd_train without probs_drop); a3t_attn_bwd_ds reads the mask there and the dV product clamps the
+        # tagged elements to zero in its fragment registers (a3t_gemm_desc::a_signmask).  The dropped copy -- 161 MB written by
+        # the forward per layer at configs[1], 415 MB at configs[3] -- is gone.  A3T_ATTN_SIGNED=0: two tensors (the A/B twin).
+        self.attn_signed = os.environ.get("A3T_ATTN_SIGNED", "1") != "0"
         # Fused legacy rel-pos attention forward (csrc/attn_fused.hip: scores, shifted position term, softmax, dropout and PV in one
         # launch, no logits in HBM).  A3T_FUSED_ATTN = auto (default) | fwd | 0:
         #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; below that its
@@ -633,16 +638,21 @@ class MLMEngine:
             return xo
         self.sv.pop(tag + ".fused", None)
         self.sv.pop(tag + ".rs", None)
+        self.sv.pop(tag + ".signed", None)
         if self._fused_train_now and ops.attn_fused_supported(dk, T):
             # fused forward, materialised backward: probabilities stay un-normalised (1 / row sum in `rs`)
             adr = self._drop(c.attention_dropout_rate, tag + ".att")
             probs = self._act(tag + ".probs", (B, H, T, T))
-            pdrop = self._act(tag + ".pdrop", (B, H, T, T)) if adr else None
+            # attention dropout: ONE saved tensor -- the mask rides on the sign bits of probs (the score-gradient kernel and the dV
+            # product read it there); the dropped copy only exists for the materialised score gradients (A3T_ATTN_BWD_DS=0)
+            signed = bool(adr) and self.bf16 and self.attn_bwd_ds and self.attn_signed and T <= 2048     # (= the backward's ds_fused)
+            pdrop = self._act(tag + ".pdrop", (B, H, T, T)) if adr and not signed else None
             ctx = self._act(tag + ".ctx", (M, d))
             lse = self.ws.get(tag + ".lse", (B, H, T))
             rs = self.ws.get(tag + ".rs", (B, H, T))
             ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk),
                                drop=adr or (0.0, 0), pos_bias=pbias if qu is None else None)
+            self.sv[tag + ".signed"] = signed
             xo = self.ws.get(tag + ".xo", (M, d))
             ops.linear_fwd(ctx, self.W(pre + ".wo"), xo, bias=p[pre + ".bo"], R=x, compute=cmp,
                            drop=self._drop(c.dropout_rate, tag + ".o"))
@@ -698,7 +708,8 @@ class MLMEngine:
         dctx_v = dctx
         if rs is not None:                 # dV = pdrop^T (rs * dctx): fold the row normalisation into the small operand
             dctx_v = self._act(self._t("tmp.dctxs"), (M, d))      # (scaled on the side stream, in front of the one GEMM that reads it)
-        adr = self._drop(c.attention_dropout_rate, tag + ".att") if pdrop is not None else None
+        signed = bool(self.sv.get(tag + ".signed"))      # the forward saved ONE tensor: |probs| = the probability, sign = dropped
+        adr = self._drop(c.attention_dropout_rate, tag + ".att") if (pdrop is not None or signed) else None
         # bf16 path: the attention-dropout mask comes back from the counter RNG (same key and index as the forward) instead
         # of being read off the dropped probabilities: one T x T read less in the most HBM-bound kernel of the step
         regen = self.bf16 and self.attn_regen and adr is not None and T % 8 == 0 and T <= 2048
@@ -706,6 +717,7 @@ class MLMEngine:
         ds_fused = (rs is not None and self.bf16 and self.attn_bwd_ds and (adr is None or regen) and dk % 32 == 0 and dk <= 192
                     and dk != 160 and T % 8 == 0)
         zb = (H * T * T, T * T)
+        assert ds_fused or not signed
         if not ds_fused:
             dpr = self.ws.get("tmp.ac", (B, H, T, T), sdt)      # reuse the score buffers
             # dprobs[b,h] = dctx[b,:,h,:] V[b,h]^T
@@ -731,7 +743,8 @@ class MLMEngine:
                 ops.attn_scale_rows(dctx, rs, dctx_v, B, H, T)
             ops.gemm(pdrop if pdrop is not None else probs, dctx_v, dvv, T, dk, T, 1, T, 1, d, 3 * d,
                      batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk),
-                     compute=cmp, colsum=sl[3 * d:] if fz else None, **csk)
+                     compute=cmp, colsum=sl[3 * d:] if fz else None, a_signmask=signed,
+                     alpha=1.0 / (1.0 - adr[0]) if signed else 1.0, **csk)
             if make_q:      # behind dV (which does not read them): dK cannot start before the score gradients exist anyway
                 ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
         qv_ready = self._side(dv_gemm, want_event=make_q, urgent=True)
@@ -743,7 +756,7 @@ class MLMEngine:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
         if ds_fused:
-            ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0))
+            ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0), signed_probs=signed)
         else:
             ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
                                    drop_p=adr[0] if adr else 0.0, drop_key=adr[1] if regen else 0, rowscale=rs)

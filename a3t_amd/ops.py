@@ -38,7 +38,7 @@ def _dt(t):
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
          act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
-         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None):
+         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, a_signmask=False):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -62,6 +62,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.drop_p, d.drop_key = (drop if drop is not None else (0.0, 0))
     d.keep_out = keep_out.data_ptr() if keep_out is not None else None
     d.keep_in = keep_in.data_ptr() if keep_in is not None else None
+    d.a_signmask = 1 if a_signmask else 0
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -353,7 +354,8 @@ def attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, scale, drop=(0.0, 0), p
 
 def attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, probs_drop, rowscale, B, H, T, scale, drop=(0.0, 0), pos_bias=None):
     """a3t_attn_fwd for training steps: also stores un-normalised probabilities (probs, probs_drop [B][H][T][T] bf16) and
-    rowscale [B][H][T] = 1 / row sum for the materialised backward."""
+    rowscale [B][H][T] = 1 / row sum for the materialised backward.  probs_drop=None with dropout on: ONE tensor, the mask in the
+    sign bits of probs (attn_bwd_ds(signed_probs=True), gemm(a_signmask=True, alpha=1/(1-p)) read it)."""
     d = qkv.shape[1] // 3
     dk = d // H
     kk = qkv.view(-1)[d:]
@@ -368,7 +370,7 @@ def attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, probs_drop, rowscal
                                         drop[0], drop[1], pbu, pbv, _stream()), "attn_fwd_train")
     if e0 is not None:
         e1.record()
-        PROFILE.append((f"attn_fwd32_kernel<{dk // 32}, {'true' if drop[0] > 0 else 'false'}, true>", 3 * 2.0 * B * H * T * T * dk, e0, e1,
+        PROFILE.append((f"attn_fwd32_kernel<{dk // 32}, {'true' if drop[0] > 0 else 'false'}, true, false, false, {'true' if (drop[0] > 0 and probs_drop is None) else 'false'}>", 3 * 2.0 * B * H * T * T * dk, e0, e1,
                         (T, T, dk, B * H, 1, 1)))
 
 
@@ -377,15 +379,16 @@ def attn_scale_rows(x, rowscale, y, B, H, T):
     L.check(L.load().a3t_attn_scale_rows(_ptr(x), _ptr(rowscale), _ptr(y), B, H, T, d // H, _stream()), "attn_scale_rows")
 
 
-def attn_bwd_ds(dctx, ctx, qkv, probs, rowscale, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=False):
+def attn_bwd_ds(dctx, ctx, qkv, probs, rowscale, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=False, signed_probs=False):
     """dS and the compact dBD from the saved un-normalised probabilities of attn_fwd_train (dP = dctx V^T is never stored; the row
     term delta = dctx . ctx is formed in the kernel): replaces the dprobs GEMM + relpos_softmax_bwd.  qkv: [B*T, 3d], V in
-    columns 2d..3d; ctx: the forward's output [B*T, d]."""
+    columns 2d..3d; ctx: the forward's output [B*T, d].  signed_probs: probs is the sign-tagged single tensor of
+    attn_fwd_train(probs_drop=None) -- the dropout mask is read off its sign bits."""
     d = dctx.shape[1]
     v = qkv.view(-1)[2 * d:]
     bsb, bsh = ((T * T, B * T * T) if dbd_head_major else (0, 0))
     L.check(L.load().a3t_attn_bwd_ds(_ptr(dctx), _ptr(ctx), _ptr(v), _ptr(probs), _ptr(rowscale), _ptr(ds), _ptr(dbd), B, H, T,
-                                     d // H, d, 3 * d, bsb, bsh, scale, drop[0], drop[1], _stream()), "attn_bwd_ds")
+                                     d // H, d, 3 * d, bsb, bsh, scale, drop[0], drop[1], 1 if signed_probs else 0, _stream()), "attn_bwd_ds")
 
 
 def mask_fill(speech, masked, mask_feature, out):

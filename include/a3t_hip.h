@@ -101,6 +101,11 @@ typedef struct a3t_gemm_desc {
                                             multi_layer_conv.py:52-63's hidden layer on its way back).  a3t_gemm fails with
                                             A3T_EINVAL when either is set and the 8-phase kernel does not take the problem:
                                             ask a3t_gemm_8p_supported first. */
+    int32_t a_signmask;                /* 1: bf16 elements of A whose sign bit is set are read as zero -- the dV product of the
+                                            attention backward (attention.py:64-96) over the probabilities a3t_attn_fwd_train
+                                            stores with the dropout mask in their sign bits.  m-contiguous bf16 A only (the
+                                            streaming kernel of csrc/gemm_bf16_tt.hip or the 128-row kernel); anything else:
+                                            A3T_EINVAL */
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
@@ -224,7 +229,11 @@ int a3t_attn_fwd(const void* qu, const void* qv, const void* k, const void* v, c
  * maximum of a row is fixed at the first key tile that holds a valid key, there is no rescaling pass), probs_drop = the
  * same after attention dropout (x 1/(1-p); NULL when drop_p == 0) and rowscale [B][H][T] = 1 / sum_j probs, the factor
  * a consumer applies per row.  No logits (ac, bd) and no second softmax kernel: one launch replaces two GEMMs, the
- * softmax and probs @ V of attention.py:190-209, 78-96.  probs / probs_drop: [B][H][T][T], 8-byte aligned, T % 8 == 0. */
+ * softmax and probs @ V of attention.py:190-209, 78-96.  probs / probs_drop: [B][H][T][T], 8-byte aligned, T % 8 == 0.
+ * drop_p > 0 with probs_drop == NULL: ONE saved tensor -- probs holds exp(s - m_ref) with the SIGN BIT set on the elements the
+ * dropout mask dropped (value |x|, mask = sign; a dropped zero is -0).  Its readers: a3t_attn_bwd_ds(signed_probs = 1) and the
+ * dV product through a3t_gemm_desc::a_signmask with alpha = 1 / (1 - drop_p).  The dropped copy (one T x T write and one read per
+ * head and layer) does not exist in that mode. */
 int a3t_attn_fwd_train(const void* qu, const void* qv, const void* k, const void* v, const void* pos,
                        const uint8_t* keymask, void* ctx, float* lse, void* probs, void* probs_drop, float* rowscale,
                        int B, int H, int T, int dk, int64_t ldq, int64_t ldkv, int64_t ldp, int64_t ldo, float scale,
@@ -239,10 +248,13 @@ int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y, int B, in
  * attention.py:86, formed in the kernel from the forward's output ctx, row stride ldo);  dbd = the same values in the compact dBD layout of
  * a3t_relpos_softmax_bwd (block (b, h) at b*dbd_bsb + h*dbd_bsh elements, both 0 = [B][H][T][T]; every entry is written).
  * Replaces the dprobs GEMM + a3t_relpos_softmax_bwd of the materialised backward.  dctx row stride ldo, v row stride ldkv
- * (head h at column h*dk), dk % 32 == 0 (<= 192, not 160), T % 8 == 0. */
+ * (head h at column h*dk), dk % 32 == 0 (<= 192, not 160), T % 8 == 0.
+ * signed_probs != 0 (drop_p > 0): probs is the sign-tagged single tensor of a3t_attn_fwd_train -- the probability is |x|, keep_ij
+ * is read off the sign bit instead of being regenerated (drop_key unused); signed_probs == 0 also accepts such a tensor (|x| is
+ * taken either way) as long as drop_key is the forward's. */
 int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v, const void* probs, const float* rowscale, void* ds,
                     void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb, int64_t dbd_bsh,
-                    float scale, float drop_p, uint32_t drop_key, void* stream);
+                    float scale, float drop_p, uint32_t drop_key, int signed_probs, void* stream);
 
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
 int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,

@@ -45,7 +45,8 @@ def test_gemm_desc_layout_matches_header():
     assert GemmDesc.s_dtype.offset == 220 and GemmDesc.colsum.offset == 232 and GemmDesc.drop_p.offset == 256
     assert GemmDesc.keep_out.offset == 264 and GemmDesc.keep_in.offset == 272
     # (round 6: the fused-LayerNorm block of round 4 left the descriptor with its kernel, tools/experiments/ln_fwd_in_panel_epilogue.patch)
-    assert ctypes.sizeof(GemmDesc) == 280
+    # (round 6: + a_signmask, the sign-tagged probabilities of the attention backward's dV product)
+    assert GemmDesc.a_signmask.offset == 280 and ctypes.sizeof(GemmDesc) == 288
 
 
 def test_gemm_desc_layout_as_the_c_compiler_sees_the_header(tmp_path):

@@ -573,3 +573,141 @@ def test_positional_biases_added_inside_the_kernels_equal_the_add_pos_bias_tenso
     for x, y, name in zip(a, b, ("ctx", "lse", "rowscale", "probs", "pdrop", "ctx (forward only)", "lse (forward only)")):
         assert torch.equal(x, y), name
     assert float(a[0].float().abs().max()) > 0
+
+
+def _sign_bits(x):
+    return (x.view(torch.int16) < 0)
+
+
+@pytest.mark.parametrize("B,H,T,dk,lengths", CASES[:4] + [(2, 2, 328, 192, [328, 0]), (3, 2, 1120, 96, [1120, 900, 1000]),
+                                              (32, 2, 1120, 192, None)])
+def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, dk, lengths):
+    """Round 6: a3t_attn_fwd_train without probs_drop stores ONE score-sized tensor -- exp(s - m_ref) with the sign bit set where
+    attention dropout dropped the element (attention.py:84-96).  Against the two-tensor launch on the same inputs: ctx / lse /
+    1 / row sum bit-identical, |x| = probs bit for bit, sign = the mask the dropped copy shows; a3t_attn_bwd_ds reading the mask
+    off the sign bits writes the same dS / dBD bits as with the regenerated mask; and the dV product over the tagged tensor
+    (a3t_gemm_desc::a_signmask, alpha = 1 / (1 - p)) equals the product over the dropped copy to bf16 rounding -- on the
+    128-row kernel and on the streaming kernel (same bits), incl. the full configs[1] shape with its key-split tail blocks."""
+    from a3t_amd import _lib, ops
+    from a3t_amd._lib import BF16
+    lib = _lib.load()
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=3 * T + dk, lengths=lengths)
+    d, M = H * dk, B * T
+    scale, drop = 1.0 / math.sqrt(dk), (0.2, 0xC0FFEE)
+    inv = 1.0 / (1.0 - drop[0])
+
+    def fwd(two):
+        ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+        lse, rs = torch.zeros(B, H, T, device=DEV), torch.zeros(B, H, T, device=DEV)
+        probs = torch.full((B, H, T, T), 5.0, device=DEV, dtype=torch.bfloat16)
+        pdrop = torch.full((B, H, T, T), 5.0, device=DEV, dtype=torch.bfloat16) if two else None
+        ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, scale, drop=drop)
+        torch.cuda.synchronize()
+        return ctx, lse, rs, probs, pdrop
+    ctx, lse, rs, probs, pdrop = fwd(True)
+    ctx1, lse1, rs1, sp, _ = fwd(False)
+    assert torch.equal(ctx, ctx1) and torch.equal(lse, lse1) and torch.equal(rs, rs1)
+    assert torch.equal((sp.view(torch.int16) & 0x7fff), probs.view(torch.int16)), "|x| is the saved probability"
+    sgn = _sign_bits(sp)
+    nz = probs.view(torch.int16) != 0
+    assert torch.equal(sgn & nz, (pdrop.view(torch.int16) == 0) & nz), "sign = dropped (where the probability is not zero)"
+    assert not bool((sgn & (pdrop.view(torch.int16) != 0)).any())
+    frac = float((sgn & nz).sum()) / max(1, int(nz.sum()))
+    assert abs(frac - drop[0]) < 0.02, frac
+    del nz
+
+    # score gradients: mask off the sign bits == mask from the counter RNG, bit for bit (and |x| is taken either way)
+    g = torch.Generator(device=DEV).manual_seed(T + dk)
+    dctx = torch.randn(M, d, device=DEV, generator=g).bfloat16()
+    outs = []
+    for pr, sg in ((probs, False), (sp, True), (sp, False)):
+        ds = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+        dbd = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+        ops.attn_bwd_ds(dctx, ctx, qkv, pr, rs, ds, dbd, B, H, T, scale, drop=drop, signed_probs=sg)
+        torch.cuda.synchronize()
+        outs.append((ds, dbd))
+    for ds, dbd in outs[1:]:
+        assert torch.equal(ds, outs[0][0]) and torch.equal(dbd, outs[0][1])
+    assert float(outs[0][0].float().abs().max()) > 0
+    del outs
+
+    # dV = dropped(P)^T (rs * dctx): the tagged tensor through a_signmask against the dropped copy
+    dcs = torch.empty_like(dctx)
+    ops.attn_scale_rows(dctx, rs, dcs, B, H, T)
+    zb = (H * T * T, T * T)
+
+    def dv(A, mode, **kw):
+        old = lib.a3t_gemm_tt_mode(mode)
+        try:
+            out = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+            cs = torch.zeros(d, device=DEV)
+            ops.gemm(A, dcs, out, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
+                     c_bs=(T * d, dk), compute=BF16, colsum=cs, colsum_bs1=dk, **kw)
+            torch.cuda.synchronize()
+            return out, cs, lib.a3t_gemm_last_kernel().decode()
+        finally:
+            lib.a3t_gemm_tt_mode(old)
+    ref, cs_ref, _ = dv(pdrop, 0)
+    got0, cs0, n0 = dv(sp, 0, a_signmask=True, alpha=inv)
+    assert "gemm_bf16_glds_kernel<2" in n0, n0
+    tol = 2e-2 * float(ref.float().abs().max())
+    assert float((got0.float() - ref.float()).abs().max()) <= tol
+    assert torch.allclose(cs0, cs_ref, rtol=2e-2, atol=2e-2 * float(cs_ref.abs().max()))
+    if T >= 512 and dk >= 96:
+        got1, cs1, n1 = dv(sp, 1, a_signmask=True, alpha=inv)
+        assert n1.startswith("gemm_bf16_tt_kernel<true") and n1.endswith("true>"), n1
+        assert torch.equal(got0, got1)
+        assert torch.allclose(cs0, cs1, rtol=1e-4, atol=1e-3 * float(cs0.abs().max()))
+    # the exact product of the bf16 operands (small cases): sum over queries of keep * p * dcs / (1 - p_drop)
+    if B * H * T * T <= 4e6:
+        keep = (~sgn).double().cpu()
+        Pm = sp.double().abs().cpu() * keep * inv
+        X = dcs.double().cpu().view(B, T, H, dk).permute(0, 2, 1, 3)
+        want = torch.matmul(Pm.transpose(2, 3), X).permute(0, 2, 1, 3).reshape(M, d)
+        assert float((got0.double().cpu() - want).abs().max()) <= 1e-2 * float(want.abs().max()) + 1e-6
+    # anything but an m-contiguous bf16 A refuses the flag
+    with pytest.raises(Exception):
+        ops.gemm(sp, dcs, torch.zeros(M, d, device=DEV, dtype=torch.bfloat16), T, dk, T, T, 1, 1, d, d, batch=B * H, batch_inner=H,
+                 a_bs=zb, b_bs=(T * d, dk), c_bs=(T * d, dk), compute=BF16, a_signmask=True)
+
+
+@pytest.mark.parametrize("signed", ["0", "1"])
+def test_engine_step_with_one_saved_probability_tensor_matches_the_two_tensor_step(signed, monkeypatch):
+    """The default training step (sign-tagged probabilities, no dropped copy: A3T_ATTN_SIGNED=1) against the two-tensor step
+    (=0): same dropout masks, same loss bits (the forward is the same kernel schedule), every parameter gradient to bf16
+    accuracy (dV sums bf16(p) x 1 / (1 - p_drop) in fp32 instead of bf16(p / (1 - p_drop)): one rounding less)."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.params import ParamStore
+    monkeypatch.delenv("A3T_FUSED_ATTN", raising=False)
+    monkeypatch.setenv("A3T_FUSED_ATTN_TRAIN", "2")
+    oc = O.A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
+    c = A3TConfig(adim=128, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab,
+                  dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
+    state = O.procedural_state(O.param_shapes(oc), 5)
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(oc, B=8, T_mel=232, T_phn=24, seed=9, lengths=[232] * 5 + [141, 77, 8],
+                                                        text_lengths=[24] * 5 + [17, 9, 3]).items()}
+    res = {}
+    for sg in ("0", signed):
+        monkeypatch.setenv("A3T_ATTN_SIGNED", sg)
+        store = ParamStore(c, DEV)
+        store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+        eng = MLMEngine(c, store, compute="bf16", training=True, dropout=True)
+        assert eng.attn_signed == (sg == "1")
+        loss = float(eng.forward(batch)["loss"])
+        n_pdrop = sum(1 for k, v in eng.sv.items() if isinstance(v, tuple) and len(v) == 9 and v[8] is not None)
+        assert n_pdrop == (0 if sg == "1" else 3), n_pdrop
+        store.zero_grad()
+        eng.backward()
+        torch.cuda.synchronize()
+        res[sg] = (loss, store.state_dict(grads=True))
+    l0, g0 = res["0"]
+    l1, g1 = res[signed]
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    for k in g0:
+        a, b_ = g1[k].double().flatten(), g0[k].double().flatten()
+        nb = float(b_.norm())
+        if nb < 1e-6 or k.endswith("linear_k.bias"):       # (zero in exact arithmetic: the softmax is invariant to a key bias)
+            continue
+        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
+        assert cos > 0.999 and 0.98 < float(a.norm()) / nb < 1.02, (k, cos, float(a.norm()) / nb)

@@ -1038,8 +1038,8 @@ def test_streaming_attention_backward_gemm_cost_model_and_unsupported_epilogues_
                      c_bs=(T * d, dk), compute=BF16, bias=torch.zeros(dk, device=DEV) if bias else None)
             torch.cuda.synchronize()
             return lib.a3t_gemm_last_kernel().decode()
-        assert kernel(32, 2, 1120, 192).startswith("gemm_bf16_tt_kernel<false, 3>")
-        assert kernel(16, 4, 1120, 128).startswith("gemm_bf16_tt_kernel<false, 2>")
+        assert kernel(32, 2, 1120, 192).startswith("gemm_bf16_tt_kernel<false, 3,")
+        assert kernel(16, 4, 1120, 128).startswith("gemm_bf16_tt_kernel<false, 2,")
         assert "tt_kernel" not in kernel(4, 2, 1120, 192)          # 32 workgroups
         assert "tt_kernel" not in kernel(16, 4, 1800, 128)         # 384 workgroups = 1.5 rounds (configs[3])
         assert "tt_kernel" not in kernel(32, 2, 384, 192)          # K = 384

@@ -49,6 +49,14 @@ def ds_only():
     ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True)
 
 
+sprobs = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, sprobs, None, rs, B, H, T, scale, drop=drop)
+
+
+def ds_signed():      # the engine's default since round 6: the mask is the sign bit of the one saved tensor
+    ops.attn_bwd_ds(dctx, ctx, qkv, sprobs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True, signed_probs=True)
+
+
 def ds_nodrop():
     ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=True)
 
@@ -58,7 +66,7 @@ def gemm_only():
              c_bs=zb, compute=BF16)
 
 
-for name, fn in (("new", new), ("old", old), ("ds", ds_only), ("ds_nodrop", ds_nodrop), ("dprobs_gemm", gemm_only)):
+for name, fn in (("new", new), ("old", old), ("ds", ds_only), ("ds_signed", ds_signed), ("ds_nodrop", ds_nodrop), ("dprobs_gemm", gemm_only)):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

@@ -16,9 +16,9 @@ qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=1)
 ctx = torch.zeros(M, d, device="cuda", dtype=torch.bfloat16)
 lse = torch.zeros(B, H, T, device="cuda")
 fn = lambda: ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=DROP)
-if os.environ.get("TRAIN") == "1":
+if os.environ.get("TRAIN") in ("1", "2"):       # 1: probs + dropped copy, 2: one sign-tagged tensor (the engine's default)
     probs = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
-    pdrop = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+    pdrop = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16) if os.environ.get("TRAIN") == "1" else None
     rs = torch.zeros(B, H, T, device="cuda")
     fn = lambda: ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk), drop=DROP)
 x = torch.randn(4096, 4096, device="cuda")

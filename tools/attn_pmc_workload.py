@@ -21,6 +21,9 @@ rs = torch.zeros(B, H, T, device="cuda")
 for _ in range(3):
     ops.attn_fwd(qu, qv, qkv, P, keymask, ctx, lse, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
     ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, probs, pdrop, rs, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
+sprobs = torch.zeros(B, H, T, T, device="cuda", dtype=torch.bfloat16)
+for _ in range(3):      # the engine's default: one sign-tagged tensor (kernel name ends in ", true>")
+    ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, sprobs, None, rs, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
 torch.cuda.synchronize()
 # the score-gradient kernel of the backward (a3t_attn_bwd_ds: default at d_k >= 160 since round 5) on the same tensors
 dctx = (torch.randn(M, d, device="cuda") * 0.1).bfloat16()
@@ -29,4 +32,6 @@ ds = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
 dbd = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
     ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
+for _ in range(3):      # mask off the sign bits (attn_bwd_ds_kernel<6, 2, 5>)
+    ops.attn_bwd_ds(dctx, ctx, qkv, sprobs, rs, ds, dbd, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345), signed_probs=True)
 torch.cuda.synchronize()
