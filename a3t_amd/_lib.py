@@ -35,7 +35,7 @@ class GemmDesc(ctypes.Structure):
         ("colsum", c_void_p), ("colsum_bs1", c_int64), ("colsum_scale", c_float), ("drop_key", ctypes.c_uint32),
         ("drop_p", c_float), ("colsum_ss", c_int32),
         ("keep_out", c_void_p), ("keep_in", c_void_p),
-        ("a_signmask", c_int32),
+        ("a_signmask", c_int32), ("keep_layout", c_int32),
     ]
 
 

@@ -470,6 +470,8 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.a_bytes = p.b_bytes = 0;
     p.slab = nullptr;
     p.a_signmask = d->a_signmask ? 1 : 0;
+    p.keep_layout = (p.keep_out || p.keep_in) ? d->keep_layout : 0;
+    if (p.keep_layout != 0 && p.keep_layout != 1) return A3T_EINVAL;
     const bool keep = p.keep_out || p.keep_in;
     if (keep && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16)) return A3T_EINVAL;
     // bf16 C accumulates only by plain read-modify-write (A3T_ACC_ADD, one launch per element at a time): no bf16 atomics

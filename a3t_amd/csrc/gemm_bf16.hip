@@ -491,12 +491,16 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
                  al16(p.C) && (!p.R || al16(p.R)) && (!p.S || ((uintptr_t)p.S & 7) == 0) && (!p.bias || al16(p.bias));
     if (p.colsum && !pv.epi_vec) return -1;
 
+    const bool keep_rm = p.keep_layout == 1 && (p.keep_in || p.keep_out);      // row-major nibble image: vector epilogue / panel kernel
+    if (keep_rm && (!pv.epi_vec || p.c_rs != p.N || batch != 1 || p.splitk != 1 || p.accumulate != A3T_ACC_STORE || p.N % 8 ||
+                    (p.keep_out && p.R) || (p.keep_in && p.S)))
+        return A3T_EINVAL;
     if (p.a_signmask && (AK || BKC || p.taps > 1 || p.kshift_mode)) return -1;   // (fragment-register pass of the m-contiguous A only)
-    if (!(pv.keep_in || pv.keep_out || p.a_signmask)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
+    if (!(pv.keep_out || (pv.keep_in && !keep_rm) || p.a_signmask)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
         const int rc = a3t_gemm_bf16_pn(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }
-    if (!p.a_signmask) {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
+    if (!p.a_signmask && !keep_rm) {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
         const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }

@@ -159,6 +159,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = sv[e] > 0.f ? v[e] : 0.f;
                 }
+                if (q->keep_in) {  // the same mask as two nibbles of the row-major keep image (a3t_gemm_desc::keep_layout = 1)
+                    const unsigned kb = ok ? *(const unsigned short*)(q->keep_in + (idx >> 2)) : 0u;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((kb >> ((e >> 2) * 8 + (e & 3))) & 1u) ? v[e] : 0.f;
+                }
                 if (q->drop_inv > 0.f) {
                     const unsigned t = q->drop_thr >> 16;
 #pragma unroll
@@ -364,7 +369,7 @@ static bool pn_applicable(const GP& p, int batch, int ly) {
     const int mode = pn_mode();
     if (mode == 0 || ly != 0 || batch != 1 || p.splitk != 1 || p.accumulate != A3T_ACC_STORE) return false;
     if (p.N % 8 != 0 || p.K % 64 != 0 || p.c_rs % 8 != 0 || p.a_cs != 1 || p.b_cs != 1) return false;
-    if (p.kshift_mode || p.keep_in || p.keep_out) return false;
+    if (p.kshift_mode || p.keep_out || (p.keep_in && p.keep_layout != 1)) return false;      // (keep_in: the row-major nibble image only)
     if (p.S && ((uintptr_t)p.S & 15)) return false;
     if (p.R && ((uintptr_t)p.R & 15)) return false;
     if (p.colsum && p.colsum_slots > 1) return false;
@@ -385,13 +390,13 @@ static bool pn_applicable(const GP& p, int batch, int ly) {
         // them, 48.2-48.6 without, gpurun_out/pn_step_ab4.log) -- a loop of one 224-workgroup kernel fills the 32 idle CUs with the
         // next launch, a step does not.  The exception is the data gradient of the second FFN conv, whose ReLU' mask read makes the
         // 128x128 kernel's epilogue slow: -0.5 ms per step.  Hence: several chunks only for problems that carry a mask tensor.
-        if (p.N % PN_COLS != 0 || (p.N > PN_COLS && !p.S)) return false;
+        if (p.N % PN_COLS != 0 || (p.N > PN_COLS && !p.S && !p.keep_in)) return false;
         const long panels = (p.M + PN_ROWS - 1) / PN_ROWS, chunks = p.N / PN_COLS;
         const int cus = pn_cus();
         const double rounds = (double)((panels + cus - 1) / cus);
         double fixed = 8.0;
         if (p.drop_inv > 0.f) fixed += 1.5;
-        if (p.R || p.c_dtype == A3T_F32 || p.S) fixed += 1.5;
+        if (p.R || p.c_dtype == A3T_F32 || p.S || p.keep_in) fixed += 1.5;
         const int nk2 = ((p.K / 64 + 1) / 2) * 2;
         const double tpn = rounds * (chunks * (nk2 * 1.55 + fixed) - (chunks - 1) * 3.0);
         const double t128 = 2.0 * p.M * p.N * (double)p.K / (p.K >= 1024 ? (p.N >= 1024 ? 780e6 : 700e6) : 450e6) + 6.0;     // us
@@ -401,7 +406,7 @@ static bool pn_applicable(const GP& p, int batch, int ly) {
 }
 
 // flags as for a3t_gemm_8p_supported: 1 bias / activation, 2 dropout, 16 fp32 output / residual, 32 column sums, 64 ReLU' mask
-// tensor S (4 | 8: never)
+// tensor S, 8 keep_in as the row-major nibble image of a3t_gemm_desc::keep_layout = 1 (4: never)
 extern "C" int a3t_gemm_pn_supported(int M, int N, int K, int taps, int flags) {
     static float dummy[4] __attribute__((aligned(16)));
     GP p = {};
@@ -411,7 +416,7 @@ extern "C" int a3t_gemm_pn_supported(int M, int N, int K, int taps, int flags) {
     if (flags & 1) p.bias = dummy, p.act = A3T_ACT_RELU;
     if (flags & 2) p.drop_inv = 1.25f;
     if (flags & 4) p.keep_out = (unsigned char*)dummy;
-    if (flags & 8) p.keep_in = (const unsigned char*)dummy;
+    if (flags & 8) p.keep_in = (const unsigned char*)dummy, p.keep_layout = 1;      // (the row-major nibble image)
     if (flags & 32) p.colsum = dummy;
     if (flags & 64) p.S = dummy, p.s_dtype = A3T_BF16;
     return pn_applicable(p, 1, 0) ? 1 : 0;

@@ -36,6 +36,7 @@ struct GP {
     unsigned int a_bytes, b_bytes;  // operand extents for the buffer descriptors
     float* slab;                    // token-reduction variant: split-K partial tiles (plain stores) for the deterministic fold
     int sole_writer;                // A3T_ACC_SOLE: the fold may add with plain read-modify-writes
+    int keep_layout;                // 1: keep_out / keep_in are the row-major nibble image (a3t_gemm_desc::keep_layout)
     int a_signmask;                 // A elements with the sign bit set are read as zero (m-contiguous bf16 A: gemm_bf16_tt.hip, gemm_bf16.hip L_TN)
 };
 
@@ -152,6 +153,10 @@ __device__ __forceinline__ void epilogue_vec4(const GP& p, float4 v, int64_t idx
         v.x = sv.x > 0.f ? v.x : 0.f, v.y = sv.y > 0.f ? v.y : 0.f;
         v.z = sv.z > 0.f ? v.z : 0.f, v.w = sv.w > 0.f ? v.w : 0.f;
     }
+    if (p.keep_layout == 1 && p.keep_in) {      // row-major nibble image in the place of S (host contract: c_rs == N, no batch)
+        const unsigned kb = p.keep_in[idx >> 2];
+        v.x = (kb & 1u) ? v.x : 0.f, v.y = (kb & 2u) ? v.y : 0.f, v.z = (kb & 4u) ? v.z : 0.f, v.w = (kb & 8u) ? v.w : 0.f;
+    }
     if (p.drop_inv > 0.f) {
         const unsigned int i0 = (unsigned int)idx;
         bool kp[4];
@@ -160,6 +165,8 @@ __device__ __forceinline__ void epilogue_vec4(const GP& p, float4 v, int64_t idx
         v.z = kp[2] ? v.z * p.drop_inv : 0.f, v.w = kp[3] ? v.w * p.drop_inv : 0.f;
     }
     v.x *= p.alpha, v.y *= p.alpha, v.z *= p.alpha, v.w *= p.alpha;
+    if (p.keep_layout == 1 && p.keep_out)       // (value > 0 after activation / dropout: the mask its data gradient needs)
+        p.keep_out[idx >> 2] = (unsigned char)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u));
     if (p.R && ks == 0) {
         float4 rv = *(const float4*)(p.R + idx);
         v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;

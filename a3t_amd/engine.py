@@ -333,7 +333,7 @@ class MLMEngine:
         key = (M, self._need_grad, self._mode_tag)
         if key not in self._ffn_plans:
             c = self.c
-            keep = d1 = d2 = False
+            keep = d1 = d2 = keep4 = False
             if self._need_grad and self.bf16 and self.dev.type == "cuda" and os.environ.get("A3T_FFN_8P", "1") != "0":
                 k = c.ff_kernel
                 drop = ops.G8_DROP if (self.dropping and c.dropout_rate > 0) else 0
@@ -344,12 +344,18 @@ class MLMEngine:
                 #  activation as its ReLU' mask, 
                 d2 = (not keep) and \
                     ops.gemm_pn_supported(M, c.ff, k * c.adim, k, ops.G8_SMASK | ops.G8_COLSUM)
+                # ... or, round 6, with a row-major keep image the forward conv writes from the 128-row kernel's epilogue (4 bits
+                # per byte: 14 MB read in the place of the 110-MB activation at configs[1]; A3T_FFN_KEEP4=0: the activation)
+                keep4 = (not keep) and os.environ.get("A3T_FFN_KEEP4", "1") != "0" and c.ff % 8 == 0 and \
+                    ops.gemm_pn_supported(M, c.ff, k * c.adim, k, ops.G8_KEEP_IN | ops.G8_COLSUM)
+                d2 = d2 or keep4
                 if (keep or d2) and "w2" not in self._wt:
                     self._setup_wt("w2", (c.adim, k, c.ff))
                 if d1 and "w1" not in self._wt:
                     self._setup_wt("w1", (c.ff, k, c.adim))
                 keep, d1, d2 = keep and "w2" in self._wt, d1 and "w1" in self._wt, d2 and "w2" in self._wt
-            self._ffn_plans[key] = (keep, d1, d2)
+                keep4 = keep4 and d2
+            self._ffn_plans[key] = (keep, d1, d2, keep4)
         return self._ffn_plans[key]
 
     def _lin_dgrad(self, dy, name, dx):
@@ -547,22 +553,24 @@ class MLMEngine:
         pad = (c.ff_kernel - 1) // 2
         y = self._ln_fwd(tag + ".ln", x, pre + ".ln")
         h = self._act(tag + ".h", (M, c.ff))
-        keep = None
+        keep, lay = None, 0
         if self._ffn_plan(M)[0]:  # one bit per element of h (value > 0 after relu / dropout) for the backward mask
             keep = self.ws.get(tag + ".keep", (ops.gemm_keep_bytes(M, c.ff),), torch.uint8)
+        elif self._ffn_plan(M)[3]:      # the same bits as a row-major nibble image (128-row kernel -> panel kernel)
+            keep, lay = self.ws.get(tag + ".keep4", (M * c.ff // 4,), torch.uint8), 1
         ops.conv_fwd(y, self.W(pre + ".w1"), h, T, pad, bias=p[pre + ".b1"], act=ACT_RELU, compute=self.cmp,
-                     drop=self._drop(c.dropout_rate, tag + ".h"), keep_out=keep)
+                     drop=self._drop(c.dropout_rate, tag + ".h"), keep_out=keep, keep_layout=lay)
         xo = self.ws.get(tag + ".xo", (M, c.adim))
         ops.conv_fwd(h, self.W(pre + ".w2"), xo, T, pad, bias=p[pre + ".b2"], R=x, alpha=0.5, compute=self.cmp,
                      drop=self._drop(c.dropout_rate, tag + ".o"))
-        self.sv[tag] = (y, h, keep)
+        self.sv[tag] = (y, h, keep, lay)
         return xo
 
     def _ffn_bwd(self, tag, pre, g, T, nb=None, nxt=None):
         """g = grad wrt the sub-layer output (fp32 residual stream, updated in place to the grad wrt
         the sub-layer input); in bf16 mode grad.x16 holds the same values in bf16 on entry and exit."""
         p, gr, c = self.store.p, self.store.g, self.c
-        y, h, keep = self.sv[tag]
+        y, h, keep, lay = self.sv[tag]
         M = g.shape[0]
         pad = (c.ff_kernel - 1) // 2
         self._sub_begin()
@@ -576,7 +584,7 @@ class MLMEngine:
         a_dh = 0.5 / (1.0 - hd[0]) if hd else 0.5
         if keep is not None:     # k-contiguous conv of ga with the transposed weights, masked by the forward's keep bits
             ops.conv_fwd(ga, self._wt["w2"][2][pre + ".w2"], dh, T, c.ff_kernel - 1 - pad, alpha=a_dh, compute=self.cmp,
-                         keep_in=keep, colsum=gr[pre + ".b1"])
+                         keep_in=keep, keep_layout=lay, colsum=gr[pre + ".b1"])
         elif self._ffn_plan(M)[2]:
             ops.conv_fwd(ga, self._wt["w2"][2][pre + ".w2"], dh, T, c.ff_kernel - 1 - pad, alpha=a_dh, compute=self.cmp,
                          S=h, colsum=gr[pre + ".b1"])

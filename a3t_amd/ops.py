@@ -38,7 +38,7 @@ def _dt(t):
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
          act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
-         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, a_signmask=False):
+         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, a_signmask=False, keep_layout=0):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -63,6 +63,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.keep_out = keep_out.data_ptr() if keep_out is not None else None
     d.keep_in = keep_in.data_ptr() if keep_in is not None else None
     d.a_signmask = 1 if a_signmask else 0
+    d.keep_layout = keep_layout
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -150,12 +151,12 @@ def linear_bwd_weight_group(items, compute=F32):
 
 # ---- Conv1d over time as implicit-im2col GEMM; weights kept as Wk[N][taps][Cin] --------------
 def conv_fwd(x, Wk, out, Tseq, pad, dil=1, bias=None, R=None, alpha=1.0, act=ACT_NONE, compute=F32, drop=None,
-             keep_out=None, keep_in=None, colsum=None, S=None):
+             keep_out=None, keep_in=None, colsum=None, S=None, keep_layout=0):
     M, Cin = x.shape
     N, taps, _ = Wk.shape
     gemm(x, Wk, out, M, N, taps * Cin, Cin, 1, taps * Cin, 1, N, b_ts=Cin, bias=bias, R=R, taps=taps, pad=pad,
          dil=dil, Tseq=Tseq, alpha=alpha, act=act, compute=compute, drop=drop, keep_out=keep_out, keep_in=keep_in,
-         colsum=colsum, S=S)
+         colsum=colsum, S=S, keep_layout=keep_layout)
 
 
 G8_BIAS_ACT, G8_DROP, G8_KEEP_OUT, G8_KEEP_IN, G8_F32_OR_RES, G8_COLSUM, G8_SMASK = 1, 2, 4, 8, 16, 32, 64

@@ -106,6 +106,14 @@ typedef struct a3t_gemm_desc {
                                             stores with the dropout mask in their sign bits.  m-contiguous bf16 A only (the
                                             streaming kernel of csrc/gemm_bf16_tt.hip or the 128-row kernel); anything else:
                                             A3T_EINVAL */
+    int32_t keep_layout;               /* layout of the keep_out / keep_in image.  0: the 8-phase kernel's tile-major bit image
+                                            (above).  1: a row-major image of M * N / 4 bytes -- byte m * (N / 4) + n / 4 holds
+                                            (stored value > 0) of columns n .. n + 3 in its bits 0-3: written by the 128-row
+                                            kernel's vector epilogue (no residual, bf16 or fp32 C with c_rs == N, no batch, no
+                                            split), read as the mask in the place of S by the 128-row kernel and by the 384-column
+                                            panel kernel.  The first FFN conv of multi_layer_conv.py:52-63 hands its ReLU / dropout
+                                            mask to the data gradient of the second one this way where the 8-phase kernel does
+                                            not run (configs[1]): 14 MB instead of a 110-MB read of the saved activation. */
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);

@@ -252,9 +252,69 @@ def test_panel_gemm_kernel_against_the_128_kernel_and_torch():
         flags = ops.G8_BIAS_ACT | ops.G8_DROP | ops.G8_F32_OR_RES | ops.G8_COLSUM
         assert ops.gemm_pn_supported(35840, 384, 4608, 3, flags) and ops.gemm_pn_supported(35840, 1536, 1152, 3, ops.G8_SMASK | ops.G8_COLSUM)
         assert not ops.gemm_pn_supported(35840, 512, 2048) and not ops.gemm_pn_supported(1000, 384, 4608, 3, flags)
-        assert not ops.gemm_pn_supported(35840, 384, 4608, 3, ops.G8_KEEP_IN) and not ops.gemm_pn_supported(35840, 384, 100)
+        assert not ops.gemm_pn_supported(35840, 384, 100)
+        assert ops.gemm_pn_supported(35840, 1536, 1152, 3, ops.G8_KEEP_IN | ops.G8_COLSUM)      # (the row-major nibble image, below)
     finally:
         lib.a3t_gemm_pn_mode(old)
+
+
+def test_row_major_keep_image_replaces_the_saved_activation_as_the_relu_mask():
+    """Round 6 (a3t_gemm_desc::keep_layout = 1): the first FFN conv (multi_layer_conv.py:52-63; bias, ReLU, dropout) writes, from
+    the 128-row kernel's vector epilogue, one nibble per four outputs = (stored value > 0); the data gradient of the second conv
+    reads that image in the place of the saved activation -- on the panel kernel and on the 128-row kernel, bit-identical to the
+    launch that reads the activation itself (S = h), column sums included.  M tails, utterance boundaries, both output types."""
+    from a3t_amd import _lib, ops
+    from a3t_amd._lib import ACT_RELU, BF16
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rn = lambda *s, sc=1.0: torch.randn(*s, device=DEV, generator=g) * sc
+    for (B, T, cin, ff) in [(6, 300, 384, 1536), (3, 171, 128, 512), (32, 1120, 384, 1536)]:
+        M = B * T
+        x, W1, b1 = rn(M, cin).bfloat16(), rn(ff, 3, cin, sc=0.05).bfloat16(), rn(ff, sc=0.3)
+        h0 = torch.empty(M, ff, device=DEV, dtype=torch.bfloat16)
+        ops.conv_fwd(x, W1, h0, T, 1, bias=b1, act=ACT_RELU, compute=BF16, drop=(0.1, 77))
+        bits = (h0.float() > 0).view(M, ff // 4, 4).to(torch.uint8)
+        want = bits[..., 0] | (bits[..., 1] << 1) | (bits[..., 2] << 2) | (bits[..., 3] << 3)
+        for mode in (0, 2):      # the writer is the 128-row kernel's vector epilogue whatever the panel kernel's mode
+            h = torch.empty_like(h0)
+            keep = torch.full((M * ff // 4,), 0xFF, device=DEV, dtype=torch.uint8)
+            oldp = lib.a3t_gemm_pn_mode(mode)
+            try:
+                ops.conv_fwd(x, W1, h, T, 1, bias=b1, act=ACT_RELU, compute=BF16, drop=(0.1, 77), keep_out=keep, keep_layout=1)
+                torch.cuda.synchronize()
+            finally:
+                lib.a3t_gemm_pn_mode(oldp)
+            assert "gemm_bf16_glds_kernel" in lib.a3t_gemm_last_kernel().decode()
+            assert torch.equal(h, h0)
+            assert torch.equal(keep.view(M, ff // 4), want), mode
+        assert 0.3 < float(bits.float().mean()) < 0.6
+        ga, W2t = rn(M, cin).bfloat16(), rn(ff, 3, cin, sc=0.05).bfloat16()
+        old8 = lib.a3t_gemm_8p_mode(0)
+        try:
+            for mode, dt in ((0, torch.bfloat16), (1, torch.bfloat16), (1, torch.float32)):
+                oldp = lib.a3t_gemm_pn_mode(mode)
+                try:
+                    outs = []
+                    for kw in (dict(S=h), dict(keep_in=keep, keep_layout=1)):
+                        dh = torch.empty(M, ff, device=DEV, dtype=dt)
+                        cs = torch.zeros(ff, device=DEV)
+                        ops.conv_fwd(ga, W2t, dh, T, 1, alpha=0.625, compute=BF16, colsum=cs, **kw)
+                        torch.cuda.synchronize()
+                        outs.append((dh, cs, lib.a3t_gemm_last_kernel().decode()))
+                finally:
+                    lib.a3t_gemm_pn_mode(oldp)
+                (d0, c0, k0), (d1, c1, k1) = outs
+                assert ("pn_kernel" in k1) == (mode == 1) and ("pn_kernel" in k0) == (mode == 1), (mode, k0, k1)
+                assert torch.equal(d0, d1), (M, mode)
+                assert torch.allclose(c0, c1, rtol=1e-4, atol=1e-3 * float(c0.abs().max()))
+                assert bool(((d1 == 0) | (h > 0)).all()) and float(d1.float().abs().max()) > 0
+        finally:
+            lib.a3t_gemm_8p_mode(old8)
+    # the contract: no residual with keep_out, no S beside keep_in, bf16 operands
+    with pytest.raises(Exception):
+        ops.conv_fwd(x, W1, torch.empty(M, ff, device=DEV), T, 1, R=torch.zeros(M, ff, device=DEV), compute=BF16, keep_out=keep, keep_layout=1)
+    with pytest.raises(Exception):
+        ops.conv_fwd(ga, W2t, torch.empty(M, ff, device=DEV, dtype=torch.bfloat16), T, 1, compute=BF16, S=h, keep_in=keep, keep_layout=1)
 
 
 def test_panel_gemm_inside_the_benchmark_step():
