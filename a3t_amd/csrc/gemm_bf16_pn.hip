@@ -130,6 +130,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
                 const float4 b0 = *(const float4*)(q->bias + ncol), b1 = *(const float4*)(q->bias + ncol + 4);
                 b8[0] = b0.x, b8[1] = b0.y, b8[2] = b0.z, b8[3] = b0.w, b8[4] = b1.x, b8[5] = b1.y, b8[6] = b1.z, b8[7] = b1.w;
             }
+            // keep image: the five mask words of this column block are requested together, ahead of the stores below (which the
+            // compiler has to assume they alias: one exposed load latency per block instead of one per row group)
+            unsigned kbv[5] = {0u, 0u, 0u, 0u, 0u};
+            if (q->keep_in) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int m = tile * PN_ROWS + wr * 80 + i * 16 + fr;
+                    if (nok && m < q->M) kbv[i] = *(const unsigned short*)(q->keep_in + (((int64_t)m * q->c_rs + ncol) >> 2));
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int m = tile * PN_ROWS + wr * 80 + i * 16 + fr;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pn_kernel(GP p) {
                     for (int e = 0; e < 8; ++e) v[e] = sv[e] > 0.f ? v[e] : 0.f;
                 }
                 if (q->keep_in) {  // the same mask as two nibbles of the row-major keep image (a3t_gemm_desc::keep_layout = 1)
-                    const unsigned kb = ok ? *(const unsigned short*)(q->keep_in + (idx >> 2)) : 0u;
+                    const unsigned kb = kbv[i];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = ((kb >> ((e >> 2) * 8 + (e & 3))) & 1u) ? v[e] : 0.f;
                 }
