@@ -579,9 +579,10 @@ def _sign_bits(x):
     return (x.view(torch.int16) < 0)
 
 
-@pytest.mark.parametrize("B,H,T,dk,lengths", CASES[:4] + [(2, 2, 328, 192, [328, 0]), (3, 2, 1120, 96, [1120, 900, 1000]),
-                                              (32, 2, 1120, 192, None)])
-def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, dk, lengths):
+@pytest.mark.parametrize("B,H,T,dk,lengths,boost", [c + (False,) for c in CASES[:4]] + [
+    (2, 2, 328, 192, [328, 0], False), (3, 2, 1120, 96, [1120, 900, 1000], False), (32, 2, 1120, 192, None, False),
+    (2, 2, 328, 64, None, True)])        # boost: keys scaled by 40 -> row sums overflow, the two-pass fixup re-writes the tagged tensor
+def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, dk, lengths, boost):
     """Round 6: a3t_attn_fwd_train without probs_drop stores ONE score-sized tensor -- exp(s - m_ref) with the sign bit set where
     attention dropout dropped the element (attention.py:84-96).  Against the two-tensor launch on the same inputs: ctx / lse /
     1 / row sum bit-identical, |x| = probs bit for bit, sign = the mask the dropped copy shows; a3t_attn_bwd_ds reading the mask
@@ -593,6 +594,10 @@ def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, d
     lib = _lib.load()
     qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=3 * T + dk, lengths=lengths)
     d, M = H * dk, B * T
+    if boost:
+        qkv = qkv.clone()
+        kview = qkv.view(B, T, 3 * d)
+        kview[1, 200:, d:2 * d] = (kview[1, 200:, d:2 * d].float() * 40.0).bfloat16()
     scale, drop = 1.0 / math.sqrt(dk), (0.2, 0xC0FFEE)
     inv = 1.0 / (1.0 - drop[0])
 
@@ -608,6 +613,8 @@ def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, d
     ctx1, lse1, rs1, sp, _ = fwd(False)
     assert torch.equal(ctx, ctx1) and torch.equal(lse, lse1) and torch.equal(rs, rs1)
     assert torch.equal((sp.view(torch.int16) & 0x7fff), probs.view(torch.int16)), "|x| is the saved probability"
+    if boost:
+        assert float(lse.max()) > 100.0 and bool(torch.isfinite(probs.float()).all()) and bool(torch.isfinite(ctx.float()).all())
     sgn = _sign_bits(sp)
     nz = probs.view(torch.int16) != 0
     assert torch.equal(sgn & nz, (pdrop.view(torch.int16) == 0) & nz), "sign = dropped (where the probability is not zero)"
