@@ -36,6 +36,7 @@ class GemmDesc(ctypes.Structure):
         ("drop_p", c_float), ("colsum_ss", c_int32),
         ("keep_out", c_void_p), ("keep_in", c_void_p),
         ("a_signmask", c_int32), ("keep_layout", c_int32),
+        ("A2", c_void_p), ("B2", c_void_p), ("b2_cs", c_int64), ("b2_bs0", c_int64), ("b2_bs1", c_int64), ("colsum2", c_void_p),
     ]
 
 
@@ -106,6 +107,7 @@ _SIGS = {
     "a3t_attn_split_mode": [c_int],
     "a3t_release_workspaces": [],
     "a3t_gemm_pn_supported": [c_int, c_int, c_int, c_int, c_int],
+    "a3t_gemm_tt_supported": [c_int, c_int, c_int, c_int],
     "a3t_dropout_bwd_cast": [_P, _P, c_int, _P, c_float, c_int, c_int, c_float, ctypes.c_uint32, _P],
 }
 EXPORTS = sorted(list(_SIGS) + ["a3t_version", "a3t_gemm_last_kernel", "a3t_gemm_keep_bytes"])

@@ -470,6 +470,8 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.a_bytes = p.b_bytes = 0;
     p.slab = nullptr;
     p.a_signmask = d->a_signmask ? 1 : 0;
+    p.A2 = d->A2, p.B2 = d->B2, p.b2_cs = d->b2_cs, p.b2_bs0 = d->b2_bs0, p.b2_bs1 = d->b2_bs1, p.colsum2 = d->colsum2;
+    if ((p.A2 == nullptr) != (p.B2 == nullptr) || (!p.A2 && p.colsum2)) return A3T_EINVAL;
     p.keep_layout = (p.keep_out || p.keep_in) ? d->keep_layout : 0;
     if (p.keep_layout != 0 && p.keep_layout != 1) return A3T_EINVAL;
     const bool keep = p.keep_out || p.keep_in;
@@ -480,7 +482,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     if (!AK && d->a_rs != 1) return A3T_EINVAL;
     if (!BKC && d->b_rs != 1) return A3T_EINVAL;
     if (p.taps > 1 && !AK) {  // fused conv weight gradient: only the direct-to-LDS bf16 kernel implements it
-        if (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16 || d->b_cs == 1 || p.a_signmask) return A3T_EINVAL;
+        if (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16 || d->b_cs == 1 || p.a_signmask || p.A2) return A3T_EINVAL;
         p.tiles_n = (p.N + 127) / 128;
         int rc = a3t_gemm_bf16_glds(p, batch, false, false, stream);
         return rc >= 0 ? rc : A3T_EINVAL;
@@ -491,7 +493,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     dim3 grid((unsigned)(p.tiles_n * tiles_m), (unsigned)(batch * p.splitk)), block(256);
 
     if (d->compute == A3T_F32) {
-        if (d->a_dtype != A3T_F32 || d->b_dtype != A3T_F32 || d->colsum || p.a_signmask) return A3T_EINVAL;
+        if (d->a_dtype != A3T_F32 || d->b_dtype != A3T_F32 || d->colsum || p.a_signmask || p.A2) return A3T_EINVAL;
         bool vec = al(p.A, 16) && al(p.B, 16) && m4(p.a_bs0, 4) && m4(p.a_bs1, 4) && m4(p.b_bs0, 4) && m4(p.b_bs1, 4);
         if (AK)
             vec = vec && m4(p.a_rs, 4) && m4(p.K, 4) && m4(p.Kc, 4);
@@ -523,7 +525,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         int rc = a3t_gemm_bf16_glds(p, batch, AK, BKC, stream);   // direct-to-LDS production kernel
         if (rc >= 0) return rc;                                   // -1: alignment contract not met
     }
-    if (keep || p.a_signmask) return A3T_EINVAL;        // keep-bit images only exist in the 8-phase kernel, sign masks in the direct-to-LDS TN kernels
+    if (keep || p.a_signmask || p.A2) return A3T_EINVAL;        // keep-bit images only exist in the 8-phase kernel, sign masks in the direct-to-LDS TN kernels
     if (d->colsum) return A3T_EINVAL;   // fused column sums live in the direct-to-LDS kernel's epilogue
     {
         const int ea = d->a_dtype == A3T_BF16 ? 2 : 4, eb = d->b_dtype == A3T_BF16 ? 2 : 4;

@@ -496,11 +496,11 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
                     (p.keep_out && p.R) || (p.keep_in && p.S)))
         return A3T_EINVAL;
     if (p.a_signmask && (AK || BKC || p.taps > 1 || p.kshift_mode)) return -1;   // (fragment-register pass of the m-contiguous A only)
-    if (!(pv.keep_out || (pv.keep_in && !keep_rm) || p.a_signmask)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
+    if (!(pv.keep_out || (pv.keep_in && !keep_rm) || p.a_signmask || p.A2)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
         const int rc = a3t_gemm_bf16_pn(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }
-    if (!p.a_signmask && !keep_rm) {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
+    if (!p.a_signmask && !keep_rm && !p.A2) {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
         const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }
@@ -508,6 +508,7 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
         const int rc = a3t_gemm_bf16_tt(pv, batch, AK ? L_NN : L_TN, stream);
         if (rc != -1) return rc;
     }
+    if (p.A2) return A3T_EINVAL;        // two products in one launch: the streaming kernel only (ask a3t_gemm_tt_supported first)
     static int forced_st = -1;
     if (forced_st < 0) {
         const char* e = getenv("A3T_GEMM_STAGES");

@@ -79,7 +79,10 @@ extern "C" int a3t_debug_read_tt(void* dst, size_t bytes) { return (int)hipMemcp
 #define TT_STAMP(k)
 #endif
 
-template <bool ATN, int NJ, bool ASGN = false>
+// DUAL ([m][k] operand only): C = alpha (A B + A2 B2) in ONE launch -- dq = dS K + dBD P of the attention backward (attention.py:190-203
+// on its way back): the K loop walks the K-tiles of the first product, then those of the second (A2 has A's strides, B2 its own);
+// the column sums of the first product are taken off the accumulators at the hand-over, those of the second are the rest.
+template <bool ATN, int NJ, bool ASGN = false, bool DUAL = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,6 +109,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
     const unsigned b_ext = (unsigned)(p.K - 1) * b_ld + (unsigned)p.N * 2u;
     const bool is_a = w < 5;        // waves 0-4 request the A pieces, waves 5-7 the B pieces
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(is_a ? A : B), 0, (int)(is_a ? a_ext : b_ext), 0x00020000);
+    const unsigned b2_ld = DUAL ? (unsigned)p.b2_cs * 2u : 0u;
+    const void* X2 = DUAL ? (is_a ? (const void*)((const u16*)p.A2 + z0 * p.a_bs0 + z1 * p.a_bs1) : (const void*)((const u16*)p.B2 + z0 * p.b2_bs0 + z1 * p.b2_bs1)) : (const void*)A;
+    const __amdgpu_buffer_rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc((void*)X2, 0, (int)(is_a ? a_ext : (unsigned)(p.K - 1) * b2_ld + (unsigned)p.N * 2u), 0x00020000);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_AS(smem));
 
     // ---- DMA lane geometry.  Slot s = 4 w + q: s < 20 -> A piece s, else B piece s - 20.
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
     //  [k][x] image: piece s = panel s >> 2 (64 columns), k-rows 8 (s & 3) .. +7 (128 B each); lane -> k-row 8 (s & 3) + (lane >> 3),
     //      position lane & 7 holds source chunk (lane & 7) ^ 2 sw(k-row), sw(r) = (r >> 1 & 1) | (r >> 3 & 1) << 1
     unsigned voff[4];       // byte offset inside the batch element's operand at K-tile 0 (OOB: never valid)
+    unsigned voff2[4];      // DUAL: the same for the second product (differs for the B waves: B2's row stride)
     int kq[4];              // first k this lane's 16 bytes hold (NN: the chunk's k; TN / B: the k-row), for the K tail
     const unsigned ld = is_a ? a_ld : b_ld;
 #pragma unroll
@@ -123,6 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
             const int g = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
             const bool ok = R < TR && m0 + R < p.M;
             voff[q] = ok ? (unsigned)(m0 + R) * a_ld + (unsigned)g * 16u : OOB;
+            voff2[q] = voff[q];
             kq[q] = g * 8;
         } else {
             const int s = is_a ? w * 4 + q : (w - 5) * 4 + q;
@@ -131,13 +139,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
             const int col = (s >> 2) * 64 + (((lane & 7) ^ (sw << 1)) << 3);
             const bool ok = is_a ? (col < TR && m0 + col < p.M) : (col < p.N && col < 64 * NJ);
             voff[q] = ok ? (unsigned)r * ld + (unsigned)((is_a ? m0 : 0) + col) * 2u : OOB;
+            voff2[q] = ok ? (unsigned)r * (is_a ? ld : b2_ld) + (unsigned)((is_a ? m0 : 0) + col) * 2u : OOB;
             kq[q] = r;
         }
     }
     const unsigned kstep = (is_a && !ATN) ? 64u : 32u * ld;       // bytes one K-tile advances the lane's source
+    const unsigned kstep2 = (is_a && !ATN) ? 64u : 32u * (is_a ? ld : b2_ld);
     const unsigned dst0 = lds0 + (is_a ? (unsigned)(w * 4) * 1024u : (unsigned)TT_A_BYTES + (unsigned)((w - 5) * 4) * 1024u);
     auto issue = [&](const int kt) __attribute__((always_inline)) {
         const unsigned dst = dst0 + (unsigned)(kt & 3) * (unsigned)TT_STAGE;
+        if (DUAL && kt >= nkt) {                // the second product's K-tiles
+            const int k2 = kt - nkt;
+            const unsigned so = (unsigned)k2 * kstep2;
+            const int krem = p.K - k2 * TT_BK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tt_dma16(rX2, dst + q * 1024, kq[q] < krem ? voff2[q] : OOB, so);
+            return;
+        }
         const unsigned so = (unsigned)kt * kstep;
         const int krem = p.K - kt * TT_BK;      // <= 0: a K-tile past the end (zeros)
 #pragma unroll
@@ -168,7 +186,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
 
     issue(0), issue(1), issue(2);
     const int rb0 = wr * nbi;       // first 16-row block of this wave row
-    for (int kt = 0; kt < nkt; ++kt) {
+    const int nkt_all = DUAL ? 2 * nkt : nkt;
+    float cs1[NJ][4];               // DUAL: this lane's column partial sums of the FIRST product
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs1[j][r] = 0.f;
+    for (int kt = 0; kt < nkt_all; ++kt) {
         WAIT_VM(8);
         BAR();
 #ifdef TT_TIMING
@@ -195,6 +219,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
         for (int i = 0; i < 10; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        if (DUAL && kt == nkt - 1 && p.colsum) {      // hand-over: the accumulators hold the first product alone
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+                if (i < nbi) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cs1[j][r] += acc[i][j][r];
+                }
+        }
     }
     WAIT_VM(0);
     __syncthreads();
@@ -244,7 +278,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float t = tt_row16_sum(cs[j][r]);
-                if (pp == 0 && ccol + j * 16 < p.N) atomicAdd(o + j * 16 + r, p.colsum_scale * t);
+                if (DUAL) {     // first product's sums from the hand-over, second = the rest
+                    const float t1 = tt_row16_sum(cs1[j][r] * alpha);
+                    if (pp == 0 && ccol + j * 16 < p.N) {
+                        atomicAdd(o + j * 16 + r, p.colsum_scale * t1);
+                        atomicAdd(o + (p.colsum2 - p.colsum) + j * 16 + r, p.colsum_scale * (t - t1));
+                    }
+                } else if (pp == 0 && ccol + j * 16 < p.N) {
+                    atomicAdd(o + j * 16 + r, p.colsum_scale * t);
+                }
             }
     }
 #ifdef TT_TIMING
@@ -278,10 +320,46 @@ static int tt_cus() {
     return n;
 }
 
-template <bool ATN, int NJ, bool ASGN = false>
+template <bool ATN, int NJ, bool ASGN = false, bool DUAL = false>
 static void launch_tt(const GP& pv, int TR, int grid, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_tt_kernel<ATN, NJ, ASGN>, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS);
-    hipLaunchKernelGGL((gemm_bf16_tt_kernel<ATN, NJ, ASGN>), dim3(grid), dim3(512), TT_LDS, stream, pv, TR);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_tt_kernel<ATN, NJ, ASGN, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS);
+    hipLaunchKernelGGL((gemm_bf16_tt_kernel<ATN, NJ, ASGN, DUAL>), dim3(grid), dim3(512), TT_LDS, stream, pv, TR);
+}
+
+// Row tiling and (mode 2) the cost model of the streaming kernel for M x N outputs over a reduction of K per batch element.
+// Row tiling: the fewest workgroup-rounds x rows per tile.  A workgroup streams its rows' share of A whatever happens beside
+// it, so the launch takes rounds(tiles x batch) x (TR + ~64 rows' worth of fill and epilogue): configs[1] (M = 1120, 64 batch
+// elements) -> 4 tiles of 288 rows = 256 workgroups = one round; configs[3] (M = 1800) -> 8 tiles of 256 rows = two full rounds
+// (6 tiles of 320 would be 1.5 rounds for the price of two).  A last tile with a few rows is cheap (its A pieces are zeros).
+static bool tt_tiling(int M, int N, int K, int batch, int mode, int& tiles, int& TR) {
+    const int cus = tt_cus();
+    tiles = 0, TR = 0;
+    long best = 0;
+    for (int t = (M + TT_MAX_ROWS - 1) / TT_MAX_ROWS, n = 0; n < 6; ++t, ++n) {
+        const int tr = (((M + t - 1) / t) + 31) / 32 * 32;
+        if (tr > TT_MAX_ROWS || (long)tr * (t - 1) >= M) continue;       // (an empty last tile: t is not a tiling of its own)
+        const long cost = (((long)t * batch + cus - 1) / cus) * (tr + 64);
+        if (!tiles || cost < best) tiles = t, TR = tr, best = cost;
+    }
+    if (!tiles) return false;
+    const long units = (long)tiles * batch;
+    if (mode == 2) {
+        // long reductions over a score-sized operand on ONE well-filled round of the chip (configs[1]).  Two rounds pay the first
+        // tile's latency and the epilogue twice with nothing beside them on the CU: configs[3] (M = 1800, d_k = 128: 512
+        // workgroups) runs these products in 135 / 155 / 110 us against 136 / 141 / 117 on the 128-row kernel and its step
+        // 0.3-0.4 ms slower (profiles/r06_tt_gemm.txt)
+        if (K < 512 || M < 256 || N < 96 || units > cus || units * TR * 4 > (long)M * batch * 5 || units * 10 < cus * 7) return false;
+    }
+    return true;
+}
+
+// 1 when a3t_gemm runs the batched bf16 product (M x N per batch element, reduction K, A score-sized [m][k], B [k][n]) on the
+// streaming kernel under the current mode -- the engine asks before it hands it TWO products for one launch (a3t_gemm_desc::A2)
+extern "C" int a3t_gemm_tt_supported(int M, int N, int K, int batch) {
+    int tiles, TR;
+    const int mode = tt_mode();
+    if (mode == 0 || N > 192 || N % 8 || M % 8 || K % 8) return 0;
+    return tt_tiling(M, N, K, batch, mode, tiles, TR) ? 1 : 0;
 }
 
 // Called by a3t_gemm_bf16_glds after the alignment contract has been checked (ly: 1 = NN, 2 = TN; B is [k][n], n-contiguous).
@@ -290,6 +368,9 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
     const int mode = tt_mode();
     if (mode == 0 || (ly != 1 && ly != 2) || p.splitk != 1 || p.accumulate == A3T_ACC_ATOMIC) return -1;
     if (p.a_signmask && ly != 2) return -1;
+    if (p.A2 && (ly != 1 || p.accumulate != A3T_ACC_STORE || !p.B2 || p.b2_cs % 8 || (p.b2_bs0 | p.b2_bs1) % 8 || ((uintptr_t)p.A2 | (uintptr_t)p.B2) & 15 ||
+                 p.b2_cs * 2 * (int64_t)p.K >= (1ll << 31) || (p.colsum != nullptr) != (p.colsum2 != nullptr)))
+        return -1;
     if (p.taps > 1 || p.kshift_mode || p.keep_in || p.keep_out || !p.epi_vec) return -1;
     if (p.b_rs != 1 || p.N > 192 || p.N % 8 || p.M % 8 || p.K % 8) return -1;
     if (ly == 1 ? (p.a_cs != 1 || p.a_rs % 8) : (p.a_rs != 1 || p.a_cs % 8)) return -1;
@@ -298,28 +379,9 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
     // one batch element's operands through 32-bit buffer offsets
     const int64_t a_ld = ly == 1 ? p.a_rs : p.a_cs;
     if (a_ld * 2 * (int64_t)(ly == 1 ? p.M : p.K) >= (1ll << 31) || p.b_cs * 2 * (int64_t)p.K >= (1ll << 31)) return -1;
-    // Row tiling: the fewest workgroup-rounds x rows per tile.  A workgroup streams its rows' share of A whatever happens beside
-    // it, so the launch takes rounds(tiles x batch) x (TR + ~64 rows' worth of fill and epilogue): configs[1] (M = 1120, 64 batch
-    // elements) -> 4 tiles of 288 rows = 256 workgroups = one round; configs[3] (M = 1800) -> 8 tiles of 256 rows = two full rounds
-    // (6 tiles of 320 would be 1.5 rounds for the price of two).  A last tile with a few rows is cheap (its A pieces are zeros).
-    const int cus = tt_cus();
     int tiles = 0, TR = 0;
-    long best = 0;
-    for (int t = (p.M + TT_MAX_ROWS - 1) / TT_MAX_ROWS, n = 0; n < 6; ++t, ++n) {
-        const int tr = (((p.M + t - 1) / t) + 31) / 32 * 32;
-        if (tr > TT_MAX_ROWS || (long)tr * (t - 1) >= p.M) continue;       // (an empty last tile: t is not a tiling of its own)
-        const long cost = (((long)t * batch + cus - 1) / cus) * (tr + 64);
-        if (!tiles || cost < best) tiles = t, TR = tr, best = cost;
-    }
-    if (!tiles) return -1;
+    if (!tt_tiling(p.M, p.N, p.K, batch, mode, tiles, TR)) return -1;
     const long units = (long)tiles * batch;
-    if (mode == 2) {
-        // long reductions over a score-sized operand on ONE well-filled round of the chip (configs[1]).  Two rounds pay the first
-        // tile's latency and the epilogue twice with nothing beside them on the CU: configs[3] (M = 1800, d_k = 128: 512
-        // workgroups) runs these products in 135 / 155 / 110 us against 136 / 141 / 117 on the 128-row kernel and its step
-        // 0.3-0.4 ms slower (profiles/r06_tt_gemm.txt)
-        if (p.K < 512 || p.M < 256 || p.N < 96 || units > cus || units * TR * 4 > (long)p.M * batch * 5 || units * 10 < cus * 7) return -1;
-    }
     GP pv = p;
     pv.ntiles = tiles;
     const int nj = p.N <= 128 ? 2 : 3;
@@ -333,12 +395,18 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
             launch_tt<true, 3>(pv, TR, (int)units, stream);
         else
             launch_tt<true, 2>(pv, TR, (int)units, stream);
+    } else if (p.A2) {
+        if (nj == 3)
+            launch_tt<false, 3, false, true>(pv, TR, (int)units, stream);
+        else
+            launch_tt<false, 2, false, true>(pv, TR, (int)units, stream);
     } else {
         if (nj == 3)
             launch_tt<false, 3>(pv, TR, (int)units, stream);
         else
             launch_tt<false, 2>(pv, TR, (int)units, stream);
     }
-    a3t_note_kernel("gemm_bf16_tt_kernel<%s, %d, %s>", ly == 2 ? "true" : "false", nj, (ly == 2 && p.a_signmask) ? "true" : "false");
+    a3t_note_kernel("gemm_bf16_tt_kernel<%s, %d, %s, %s>", ly == 2 ? "true" : "false", nj, (ly == 2 && p.a_signmask) ? "true" : "false",
+                    (ly == 1 && p.A2) ? "true" : "false");
     return (int)hipGetLastError();
 }

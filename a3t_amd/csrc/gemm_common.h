@@ -36,6 +36,10 @@ struct GP {
     unsigned int a_bytes, b_bytes;  // operand extents for the buffer descriptors
     float* slab;                    // token-reduction variant: split-K partial tiles (plain stores) for the deterministic fold
     int sole_writer;                // A3T_ACC_SOLE: the fold may add with plain read-modify-writes
+    const void* A2;                 // second product of the same launch (streaming kernel, [m][k] operand): C = alpha (A B + A2 B2)
+    const void* B2;
+    int64_t b2_cs, b2_bs0, b2_bs1;
+    float* colsum2;
     int keep_layout;                // 1: keep_out / keep_in are the row-major nibble image (a3t_gemm_desc::keep_layout)
     int a_signmask;                 // A elements with the sign bit set are read as zero (m-contiguous bf16 A: gemm_bf16_tt.hip, gemm_bf16.hip L_TN)
 };

@@ -210,6 +210,7 @@ class MLMEngine:
         # tagged elements to zero in its fragment registers (a3t_gemm_desc::a_signmask).  The dropped copy -- 161 MB written by
         # the forward per layer at configs[1], 415 MB at configs[3] -- is gone.  A3T_ATTN_SIGNED=0: two tensors (the A/B twin).
         self.attn_signed = os.environ.get("A3T_ATTN_SIGNED", "1") != "0"
+        self.attn_dq_dual = os.environ.get("A3T_ATTN_DQ_DUAL", "1") != "0"
         # Fused legacy rel-pos attention forward (csrc/attn_fused.hip: scores, shifted position term, softmax, dropout and PV in one
         # launch, no logits in HBM).  A3T_FUSED_ATTN = auto (default) | fwd | 0:
         #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; below that its
@@ -788,14 +789,22 @@ class MLMEngine:
         dqv = dqkv if dq_acc else self._act("tmp.dqv", (M, d))
         ldq, cbq = (3 * d, (T * 3 * d, dk)) if dq_acc else (d, (T * d, dk))
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
-        ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zb,
-                 b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl if fz else None, **csk)
+        # bf16 path on the streaming kernel: dq = ds K + dbd P as ONE launch (two K loops into one accumulator set, one rounding, no
+        # read-modify-write of the q third; their column sums come apart at the hand-over) -- A3T_ATTN_DQ_DUAL=0: two launches
+        dual = dq_acc and self.attn_dq_dual and ops.gemm_tt_supported(T, dk, T, B * H)
+        if dual:
+            ops.gemm(ds, kk, dqkv, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zb,
+                     b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl, second=(dbd, P, d, (0, dk), sl[d:]), **csk)
+        else:
+            ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zb,
+                     b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl if fz else None, **csk)
         dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
                                               a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
                                               colsum=sl[2 * d:] if fz else None, **csk), want_event=True, urgent=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
-        ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, ldq, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
-                 c_bs=cbq, acc=ACC_ADD if dq_acc else ACC_STORE, compute=cmp, colsum=sl[d:] if fz else None, **csk)
+        if not dual:
+            ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, ldq, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
+                     c_bs=cbq, acc=ACC_ADD if dq_acc else ACC_STORE, compute=cmp, colsum=sl[d:] if fz else None, **csk)
         if not dq_acc:
             ops.add_pos_bias_bwd(dqu, dqv, dqkv)      # (the dq slice only)
         if dk_done is not None:      # the dV / dK slices of dqkv and their column sums come from the side stream

@@ -38,7 +38,7 @@ def _dt(t):
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
          act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
-         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, a_signmask=False, keep_layout=0):
+         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, a_signmask=False, keep_layout=0, second=None):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -64,6 +64,11 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.keep_in = keep_in.data_ptr() if keep_in is not None else None
     d.a_signmask = 1 if a_signmask else 0
     d.keep_layout = keep_layout
+    if second is not None:      # (A2, B2, b2_cs, (b2_bs0, b2_bs1), colsum2): C = alpha (A B + A2 B2) in one launch of the streaming kernel
+        A2, B2, b2_cs, b2_bs, cs2 = second
+        d.A2, d.B2, d.b2_cs = A2.data_ptr(), B2.data_ptr(), b2_cs
+        d.b2_bs0, d.b2_bs1 = b2_bs
+        d.colsum2 = cs2.data_ptr() if cs2 is not None else None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -171,6 +176,12 @@ def gemm_8p_supported(M, N, K, taps=1, flags=0):
 def gemm_pn_supported(M, N, K, taps=1, flags=0):
     """True when a3t_gemm runs this k-contiguous bf16 problem on the 384-column panel kernel (csrc/gemm_bf16_pn.hip)."""
     return bool(L.load().a3t_gemm_pn_supported(int(M), int(N), int(K), int(taps), int(flags)))
+
+
+def gemm_tt_supported(M, N, K, batch):
+    """True when a3t_gemm runs the batched score-sized product on the streaming kernel (csrc/gemm_bf16_tt.hip) -- the precondition
+    of gemm(second=...)."""
+    return bool(L.load().a3t_gemm_tt_supported(int(M), int(N), int(K), int(batch)))
 
 
 def gemm_mode_tag():

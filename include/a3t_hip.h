@@ -114,6 +114,15 @@ typedef struct a3t_gemm_desc {
                                             panel kernel.  The first FFN conv of multi_layer_conv.py:52-63 hands its ReLU / dropout
                                             mask to the data gradient of the second one this way where the 8-phase kernel does
                                             not run (configs[1]): 14 MB instead of a 110-MB read of the saved activation. */
+    const void* A2;                    /* optional SECOND product accumulated in the same launch: C = alpha (A B + A2 B2), one rounding. */
+    const void* B2;                    /*   A2 has A's strides and batch strides, B2 [k][n] n-contiguous with row stride b2_cs and batch
+                                            strides b2_bs0/1; same M, N, K.  dq = dS K + dBD P of the attention backward
+                                            (attention.py:190-203 on its way back) as ONE launch of the streaming kernel
+                                            (csrc/gemm_bf16_tt.hip, [m][k] operand, A3T_ACC_STORE): anything else A3T_EINVAL -- ask
+                                            a3t_gemm_tt_supported first. */
+    int64_t b2_cs, b2_bs0, b2_bs1;
+    float* colsum2;                    /* with colsum: column sums of the second product's share (colsum takes the first's); same
+                                            slots / strides as colsum */
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
@@ -127,6 +136,9 @@ int64_t a3t_gemm_keep_bytes(int M, int N);
  * attention.py:64-96, pointwise_conv2 of the conformer ConvolutionModule, and their data gradients through transposed
  * weight shadows); same `flags` as above (4 and 8: never). */
 int a3t_gemm_pn_supported(int M, int N, int K, int taps, int flags);
+/* 1 when a3t_gemm runs the batched bf16 product (M x N per batch element over a reduction of K; A score-sized [m][k] or [k][m],
+ * B [k][n]) on the streaming kernel (csrc/gemm_bf16_tt.hip) under its current mode: the precondition of a3t_gemm_desc::A2 */
+int a3t_gemm_tt_supported(int M, int N, int K, int batch);
 
 /* LayerNorm over the last dim (transformer/layer_norm.py:12-42 eps=1e-12; torch.nn.LayerNorm
  * eps=1e-5 in the speech embed, conformer/encoder.py:404).  mean/rstd: [M] saved for backward. */

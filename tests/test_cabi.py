@@ -46,7 +46,9 @@ def test_gemm_desc_layout_matches_header():
     assert GemmDesc.keep_out.offset == 264 and GemmDesc.keep_in.offset == 272
     # (round 6: the fused-LayerNorm block of round 4 left the descriptor with its kernel, tools/experiments/ln_fwd_in_panel_epilogue.patch)
     # (round 6: + a_signmask, the sign-tagged probabilities of the attention backward's dV product)
-    assert GemmDesc.a_signmask.offset == 280 and ctypes.sizeof(GemmDesc) == 288
+    assert GemmDesc.a_signmask.offset == 280 and GemmDesc.keep_layout.offset == 284 and GemmDesc.A2.offset == 288
+    # (... and the second product of one streaming launch: A2, B2, b2_cs, b2_bs0, b2_bs1, colsum2)
+    assert GemmDesc.colsum2.offset == 328 and ctypes.sizeof(GemmDesc) == 336
 
 
 def test_gemm_desc_layout_as_the_c_compiler_sees_the_header(tmp_path):

@@ -1020,6 +1020,75 @@ def test_streaming_attention_backward_gemm_matches_the_128_row_kernel_and_the_fp
     assert torch.allclose(s1[:2 * d], ref_cs, rtol=2e-2, atol=2e-2 * float(ref_cs.abs().max()))
 
 
+@pytest.mark.parametrize("B,H,T,dk", [(32, 2, 1120, 192), (16, 4, 1120, 128), (3, 2, 616, 96), (2, 2, 328, 160)])
+def test_two_products_in_one_streaming_launch(B, H, T, dk):
+    """a3t_gemm_desc::A2 (round 6): dq = dS K + dBD P (attention.py:190-203 on its way back) as ONE launch of the streaming kernel --
+    both K loops into one accumulator set, one bf16 rounding, the column sums of the two products taken apart at the hand-over.
+    Against the two-launch form (second product added in its epilogue: two roundings) and the fp32 products of the same operands;
+    the k third and the v third of the output row are nobody's.  Anything the streaming kernel does not take is refused."""
+    from a3t_amd import _lib
+    from a3t_amd._lib import ACC_ADD, BF16
+    ops = _ops()
+    lib = _lib.load()
+    d, M = H * dk, B * T
+    g = torch.Generator(device=DEV).manual_seed(B * 77 + T + dk)
+    S1 = (torch.randn(B, H, T, T, device=DEV, generator=g) * 0.1).bfloat16()
+    S2 = (torch.randn(B, H, T, T, device=DEV, generator=g) * 0.1).bfloat16()
+    qkv = torch.randn(M, 3 * d, device=DEV, generator=g).bfloat16()
+    P = torch.randn(T, d, device=DEV, generator=g).bfloat16()
+    zb = (H * T * T, T * T)
+    NS = 4
+    csk = dict(colsum_bs1=dk, colsum_slots=NS, colsum_ss=4 * d)
+    old = lib.a3t_gemm_tt_mode(1)
+    try:
+        assert ops.gemm_tt_supported(T, dk, T, B * H)
+        o2 = torch.full((M, 3 * d), 0.25, device=DEV).bfloat16()
+        s2 = torch.zeros(NS * 4 * d, device=DEV)
+        ops.gemm(S1, qkv.view(-1)[d:], o2, T, dk, T, T, 1, 1, 3 * d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * 3 * d, dk),
+                 c_bs=(T * 3 * d, dk), compute=BF16, colsum=s2, **csk)
+        ops.gemm(S2, P, o2, T, dk, T, T, 1, 1, d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(0, dk), c_bs=(T * 3 * d, dk),
+                 acc=ACC_ADD, compute=BF16, colsum=s2[d:], **csk)
+        o1 = torch.full((M, 3 * d), 0.25, device=DEV).bfloat16()
+        s1 = torch.zeros(NS * 4 * d, device=DEV)
+        ops.gemm(S1, qkv.view(-1)[d:], o1, T, dk, T, T, 1, 1, 3 * d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * 3 * d, dk),
+                 c_bs=(T * 3 * d, dk), compute=BF16, colsum=s1, second=(S2, P, d, (0, dk), s1[d:]), **csk)
+        torch.cuda.synchronize()
+        name = lib.a3t_gemm_last_kernel().decode()
+        assert name.startswith("gemm_bf16_tt_kernel<false") and name.endswith("true>"), name
+    finally:
+        lib.a3t_gemm_tt_mode(old)
+    K_ = qkv.float().view(B, T, 3, H, dk)[:, :, 1].permute(0, 2, 1, 3)
+    P_ = P.float().view(T, H, dk).permute(1, 0, 2).unsqueeze(0)
+    q1, q2 = torch.matmul(S1.float(), K_), torch.matmul(S2.float(), P_)
+    ref = (q1 + q2).permute(0, 2, 1, 3)
+    got1, got2 = o1.float().view(B, T, 3, H, dk), o2.float().view(B, T, 3, H, dk)
+    sc = float(ref.abs().max())
+    e1, e2 = float((got1[:, :, 0] - ref).abs().max()) / sc, float((got2[:, :, 0] - ref).abs().max()) / sc
+    assert e1 <= 6e-3 and e1 <= e2 * 1.05 + 1e-4, (e1, e2)         # one rounding instead of two
+    assert torch.equal(got1[:, :, 1:], torch.full_like(got1[:, :, 1:], 0.25))
+    c1, c2 = s1.view(NS, 4 * d).sum(0), s2.view(NS, 4 * d).sum(0)
+    ref_cs = torch.cat([q1.sum(dim=(0, 2)).reshape(-1), q2.sum(dim=(0, 2)).reshape(-1)])
+    tol = 2e-3 * float(ref_cs.abs().max()) + 1e-3
+    assert torch.allclose(c1[:2 * d], ref_cs, rtol=0, atol=tol), float((c1[:2 * d] - ref_cs).abs().max())
+    assert torch.allclose(c1[:2 * d], c2[:2 * d], rtol=0, atol=2e-2 * float(ref_cs.abs().max()))
+    assert float(c1[2 * d:].abs().max()) == 0.0
+    # refused: the [k][m] operand, an accumulating output, a shape the streaming kernel leaves to the 128-row kernel
+    with pytest.raises(Exception):
+        ops.gemm(S1, qkv.view(-1)[d:], o1, T, dk, T, 1, T, 1, 3 * d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * 3 * d, dk),
+                 c_bs=(T * 3 * d, dk), compute=BF16, second=(S2, P, d, (0, dk), None))
+    with pytest.raises(Exception):
+        ops.gemm(S1, qkv.view(-1)[d:], o1, T, dk, T, T, 1, 1, 3 * d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * 3 * d, dk),
+                 c_bs=(T * 3 * d, dk), acc=ACC_ADD, compute=BF16, second=(S2, P, d, (0, dk), None))
+    old = lib.a3t_gemm_tt_mode(0)
+    try:
+        assert not ops.gemm_tt_supported(T, dk, T, B * H)
+        with pytest.raises(Exception):
+            ops.gemm(S1, qkv.view(-1)[d:], o1, T, dk, T, T, 1, 1, 3 * d, 3 * d, batch=B * H, batch_inner=H, a_bs=zb,
+                     b_bs=(T * 3 * d, dk), c_bs=(T * 3 * d, dk), compute=BF16, second=(S2, P, d, (0, dk), None))
+    finally:
+        lib.a3t_gemm_tt_mode(old)
+
+
 def test_streaming_attention_backward_gemm_cost_model_and_unsupported_epilogues_fall_back():
     """Default mode: the streaming kernel takes the configs[1] attention shape (256 workgroups = one round) and leaves a grid that
     fills a third of the chip, a short reduction and every epilogue it does not implement (bias, fp32 output) to the 128-row kernel."""
