@@ -662,7 +662,7 @@ def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, d
     assert torch.allclose(cs0, cs_ref, rtol=2e-2, atol=2e-2 * float(cs_ref.abs().max()))
     if T >= 512 and dk >= 96:
         got1, cs1, n1 = dv(sp, 1, a_signmask=True, alpha=inv)
-        assert n1.startswith("gemm_bf16_tt_kernel<true") and n1.endswith("true>"), n1
+        assert n1.startswith("gemm_bf16_tt_kernel<true") and n1.endswith(", true, false>"), n1
         assert torch.equal(got0, got1)
         assert torch.allclose(cs0, cs1, rtol=1e-4, atol=1e-3 * float(cs0.abs().max()))
     # the exact product of the bf16 operands (small cases): sum over queries of keep * p * dcs / (1 - p_drop)
