@@ -74,7 +74,7 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
         L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
         e1.record()
-        PROFILE.append((lib.a3t_gemm_last_kernel().decode(), 2.0 * M * N * K * batch, e0, e1,
+        PROFILE.append((lib.a3t_gemm_last_kernel().decode(), (2.0 if second is None else 4.0) * M * N * K * batch, e0, e1,
                         (M, N, K, batch, taps, splitk)))
         return
     L.check(lib.a3t_gemm(ctypes.byref(d), _stream()), "a3t_gemm")
