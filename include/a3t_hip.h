@@ -61,6 +61,8 @@ extern "C" {
  * One of a_rs/a_cs (and of b_rs/b_cs) must be 1.
  * Batching: z in [0,batch): z0 = z / batch_inner, z1 = z % batch_inner; X += z0*x_bs0 + z1*x_bs1.
  * splitk>1 splits K over extra workgroups; requires accumulate == A3T_ACC_ATOMIC or A3T_ACC_SOLE.
+ * ZERO-INITIALISE the descriptor (`a3t_gemm_desc d = {0};`): optional fields are appended as the library grows (round 6: a_signmask,
+ * keep_layout, A2 .. colsum2) and zero / NULL always means "off".
  */
 typedef struct a3t_gemm_desc {
     const void* A;
