@@ -850,6 +850,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
         const unsigned int vm = msk ? kmw[s] >> (4 * lh) : 0u;   // bit (r & 3) + 8 (r >> 2) = this lane's key of register r
         Sn = zero16(), Bn = zero16();
         float pv[16];
+        unsigned int sw[8];       // SG: the tile's sixteen tagged probabilities as packed bf16 pairs (quad g -> sw[2 g], sw[2 g + 1])
         float psum = 0.f;
         auto expo = [&](const int r) __attribute__((always_inline)) {
             const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(Sc[r] + bd[r], sl2, -m2));
@@ -884,15 +885,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
             if (DROP) {
                 bool kp[4];
                 rng_keep4(p.drop_key, ibase + (unsigned int)(32 * s + 8 * g + 4 * lh), p.drop_thr, kp);
-                if (SG) {       // the saved probability itself, tagged: image 1 (the dropped copy's) carries the one tensor
+                if (SG) {       // the saved probability itself, tagged: image 1 (the dropped copy's) carries the one tensor.  The
+                    // P operand of the PV product comes off the SAME packed words (sign-tagged -> +0 by one packed integer max per
+                    // pair, below); 1 / (1 - p) multiplies the accumulators once, after the key loop
                     unsigned char* im = stg + (w * 2 + 1) * 2048;
                     uint2 v2;
                     v2.x = io_pack2(kp[0] ? pv[4 * g] : -pv[4 * g], kp[1] ? pv[4 * g + 1] : -pv[4 * g + 1]);
                     v2.y = io_pack2(kp[2] ? pv[4 * g + 2] : -pv[4 * g + 2], kp[3] ? pv[4 * g + 3] : -pv[4 * g + 3]);
                     *(uint2*)(im + lr * 64 + ((g ^ ((lr >> 2) & 3)) << 4) + 8 * lh) = v2;
-                }
+                    sw[2 * g] = v2.x, sw[2 * g + 1] = v2.y;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pv[4 * g + e] = kp[e] ? pv[4 * g + e] * p.drop_inv : 0.f;
+                    for (int e = 0; e < 4; ++e) pv[4 * g + e] = kp[e] ? pv[4 * g + e] * p.drop_inv : 0.f;
+                }
             }
         };
         auto dsave = [&](const int g) __attribute__((always_inline)) {
@@ -914,7 +919,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) drop4(g), dsave(g);
             }
-            if (t == KS - 1) pf0 = pack_frag(pv), pf1 = pack_frag(pv + 8);
+            if (t == KS - 1) {
+                if (SG) {
+                    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+                    const s16x8_ z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const uint4 u0 = make_uint4(sw[0], sw[1], sw[2], sw[3]), u1 = make_uint4(sw[4], sw[5], sw[6], sw[7]);
+                    pf0 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8_, u0), z));
+                    pf1 = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8_, u1), z));
+                } else {
+                    pf0 = pack_frag(pv), pf1 = pack_frag(pv + 8);
+                }
+            }
         };
         rd(0, Kt, slot, Vt);
         rd(1, Kt, slot, Vt);
@@ -1006,6 +1021,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd32_kernel(AttnArgs p) {
     }
 #endif
 
+    if (SG) {     // (the P operands were bf16(p) * keep: attention dropout's 1 / (1 - p) once per output element)
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[d][r] *= p.drop_inv;
+    }
     float l = l_run + __shfl_xor(l_run, 32, 64);
     if (split) {
         part_out(O, l, m2);

@@ -611,7 +611,11 @@ def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, d
         return ctx, lse, rs, probs, pdrop
     ctx, lse, rs, probs, pdrop = fwd(True)
     ctx1, lse1, rs1, sp, _ = fwd(False)
-    assert torch.equal(ctx, ctx1) and torch.equal(lse, lse1) and torch.equal(rs, rs1)
+    assert torch.equal(lse, lse1) and torch.equal(rs, rs1)
+    # ctx: the one-tensor kernel multiplies bf16(p) * keep with V and applies 1 / (1 - p_drop) to the fp32 sums, the two-tensor kernel
+    # multiplies bf16(p / (1 - p_drop)) * keep: equal to the rounding of the P operand (2^-9 per element, averaged over the keys)
+    cs_ = float(ctx.float().abs().max())
+    assert float((ctx.float() - ctx1.float()).abs().max()) <= 1e-2 * cs_ + 1e-6, float((ctx.float() - ctx1.float()).abs().max()) / cs_      # (one bf16 ulp of the largest output is 7.8e-3 of it)
     assert torch.equal((sp.view(torch.int16) & 0x7fff), probs.view(torch.int16)), "|x| is the saved probability"
     if boost:
         assert float(lse.max()) > 100.0 and bool(torch.isfinite(probs.float()).all()) and bool(torch.isfinite(ctx.float()).all())
@@ -681,8 +685,8 @@ def test_single_tensor_save_carries_the_dropout_mask_in_the_sign_bits(B, H, T, d
 @pytest.mark.parametrize("signed", ["0", "1"])
 def test_engine_step_with_one_saved_probability_tensor_matches_the_two_tensor_step(signed, monkeypatch):
     """The default training step (sign-tagged probabilities, no dropped copy: A3T_ATTN_SIGNED=1) against the two-tensor step
-    (=0): same dropout masks, same loss bits (the forward is the same kernel schedule), every parameter gradient to bf16
-    accuracy (dV sums bf16(p) x 1 / (1 - p_drop) in fp32 instead of bf16(p / (1 - p_drop)): one rounding less)."""
+    (=0): same dropout masks, loss and every parameter gradient to bf16 accuracy (ctx and dV sum bf16(p) x keep and apply
+    1 / (1 - p_drop) in fp32 instead of multiplying bf16(p / (1 - p_drop)): one rounding less)."""
     from a3t_amd.config import A3TConfig
     from a3t_amd.engine import MLMEngine
     from a3t_amd.params import ParamStore
@@ -710,7 +714,7 @@ def test_engine_step_with_one_saved_probability_tensor_matches_the_two_tensor_st
         res[sg] = (loss, store.state_dict(grads=True))
     l0, g0 = res["0"]
     l1, g1 = res[signed]
-    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)
     for k in g0:
         a, b_ = g1[k].double().flatten(), g0[k].double().flatten()
         nb = float(b_.norm())
