@@ -37,6 +37,7 @@ class GemmDesc(ctypes.Structure):
         ("keep_out", c_void_p), ("keep_in", c_void_p),
         ("a_signmask", c_int32), ("keep_layout", c_int32),
         ("A2", c_void_p), ("B2", c_void_p), ("b2_cs", c_int64), ("b2_bs0", c_int64), ("b2_bs1", c_int64), ("colsum2", c_void_p),
+        ("a2_rs", c_int64), ("a_unaligned", c_int32),
     ]
 
 
@@ -63,7 +64,7 @@ _SIGS = {
                            c_int64, c_float, c_float, ctypes.c_uint32, _P, _P, _P],
     "a3t_attn_scale_rows": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "a3t_attn_bwd_ds": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_float,
-                        c_float, ctypes.c_uint32, c_int, _P],
+                        c_float, ctypes.c_uint32, c_int, c_int64, _P],
     "a3t_attn_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                      c_float, c_float, ctypes.c_uint32, _P, _P, _P],
     "a3t_pwg_block": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],

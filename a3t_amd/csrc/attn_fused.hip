@@ -1070,6 +1070,7 @@ struct DsArgs {
     unsigned int drop_thr, drop_key;
     unsigned long long* timing;   // A3T_DS_TIMING builds: per-wave cycle totals of the eight phases
     int signed_probs;     // the dropout mask is the sign bit of probs (a3t_attn_fwd_train without probs_drop)
+    int64_t ds_bs;        // elements between the (b, h) blocks of ds (T * T, or more: blocks with room in front of them)
 };
 
 // chunk ci (row-contiguous 16-byte pieces, chunk index fastest) of the wave's probability strip
@@ -1096,7 +1097,11 @@ __device__ __forceinline__ uint4 ds_ld_chunk(const u16* prB, int T, int q0, int 
 // V tiles are shared by the four waves: DMA into a double buffer, one barrier per tile.
 // DROP: 0 no dropout, 1 the mask comes back from the counter RNG, 2 it is read off the sign bits of probs (the one-tensor save of
 // a3t_attn_fwd_train: p = |x|, dropped where x carries the sign bit)
-template <int NDB, int DROP, int KT>
+// WDBD = false: dbd is not written at all -- the compact dBD matrix is the SAME flat sequence as dS shifted by T - 1 elements
+// (dbd[r][c] = ds_flat[r (T + 1) + c - (T - 1)]), so a consumer can read it as a strided VIEW of dS (row stride T + 1, rows that start
+// at odd element offsets: the 16-byte LDS-DMA takes 2-byte aligned sources, tools/probes/unaligned_dma_probe.hip) when T zeros sit in
+// front of every (b, h) block of dS (ds_bs >= T * T + T; row 0 of dBD, whose first T - 1 entries never reach the scores, reads them).
+template <int NDB, int DROP, int KT, bool WDBD = true>
 __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
     using D = DT32<NDB>;
     constexpr int DK = D::DK, KS = DK / 16, TB = D::BYTES, CPR = D::CPR, RS = KT * 64 + 16, IMG = 32 * RS, NPMIN = D::NP / 4;
@@ -1226,9 +1231,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         }
         const float rsc = in_rsc, dl = in_dl;
         const unsigned int ibase = (unsigned int)(((int64_t)c_bh * T + i) * T);
-        u16* dsB = p.ds + (int64_t)c_bh * T * T;
-        u16* dbB = p.dbd + (int64_t)c_b * p.dbd_bsb + (int64_t)c_h * p.dbd_bsh;
-        if (c_q0 == 0 && c_sa == 0)          // BD[0][0 .. T-2] never reaches the scores (attention.py:157-165)
+        u16* dsB = p.ds + (int64_t)c_bh * p.ds_bs;
+        u16* dbB = WDBD ? p.dbd + (int64_t)c_b * p.dbd_bsb + (int64_t)c_h * p.dbd_bsh : nullptr;
+        if (WDBD && c_q0 == 0 && c_sa == 0)          // BD[0][0 .. T-2] never reaches the scores (attention.py:157-165)
             for (int c = lane; c < T - 1; c += 64) dbB[c] = 0;
         DSTAMP(2);
         // ---- tiles
@@ -1295,7 +1300,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_ds_kernel(DsArgs p) {
         // ---- dBD: per query row a lower run (keys <= i -> row i) and an upper run (keys >= i+2 -> row i+1)
         const int nslot = cpr + 1, nps = 32 * nslot;
 #pragma unroll 1
-        for (int run = 0; run < 2; ++run) {
+        for (int run = 0; run < (WDBD ? 2 : 0); ++run) {
             if (run == 0 ? (c_J0 > c_q0 + 31) : (c_J1 - 1 < c_q0 + 2)) continue;        // no row of this wave has that run
             // whole 16-byte chunks of the destination
             for (int c0 = 0; c0 < nps; c0 += 64) {
@@ -1544,11 +1549,12 @@ static bool attn_shape_ok(int dk, int T) { return dk % 32 == 0 && dk <= 192 && d
 
 extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v, const void* probs, const float* rowscale,
                                void* ds, void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb,
-                               int64_t dbd_bsh, float scale, float drop_p, uint32_t drop_key, int signed_probs, void* stream) {
-    if (!attn_shape_ok(dk, T) || drop_p < 0.f || drop_p >= 1.f || !dctx || !ctx || !v || !probs || !rowscale || !ds || !dbd)
+                               int64_t dbd_bsh, float scale, float drop_p, uint32_t drop_key, int signed_probs, int64_t ds_bs, void* stream) {
+    if (!attn_shape_ok(dk, T) || drop_p < 0.f || drop_p >= 1.f || !dctx || !ctx || !v || !probs || !rowscale || !ds)
         return A3T_EINVAL;
+    if (ds_bs == 0) ds_bs = (int64_t)T * T;
     if (!al16(dctx) || !al16(ctx) || !al16(v) || !al16(probs) || !al16(ds) || !al16(dbd) || ldo % 8 || ldkv % 8 || dbd_bsb % 8 ||
-        dbd_bsh % 8)
+        dbd_bsh % 8 || ds_bs % 8 || ds_bs < (int64_t)T * T)
         return A3T_EINVAL;
     if ((int64_t)B * H * T * T >= (1ll << 32)) return A3T_EINVAL;       // (the dropout counter is 32 bits, as in the forward)
     if (dbd_bsb == 0 && dbd_bsh == 0) dbd_bsb = (int64_t)H * T * T, dbd_bsh = (int64_t)T * T;
@@ -1559,6 +1565,7 @@ extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v,
     a.drop_thr = drop_p > 0.f ? (unsigned int)((double)drop_p * 4294967296.0) : 0u, a.drop_key = drop_key, a.drop_inv = 1.f / (1.f - drop_p);
     a.timing = (unsigned long long*)g_attn_timing_buf;
     a.signed_probs = (signed_probs && a.drop_thr) ? 1 : 0;
+    a.ds_bs = ds_bs;
     // tasks = (128 queries) x (5 key tiles): several times more tasks than workgroup slots (2 per CU), so the last round is short
     constexpr int KT = 5;
     const int NS = (T + 31) / 32;
@@ -1566,11 +1573,16 @@ extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v,
     int64_t grid = (int64_t)attn_cus() * 2;
     if (grid > ntasks) grid = ntasks;
     hipStream_t s = (hipStream_t)stream;
-#define A3T_DS1(NDB, DR)                                                                                                         \
-    do {                                                                                                                         \
-        constexpr int lds = 3 * DT32<NDB>::BYTES + 4 * 32 * (KT * 64 + 16);                                                      \
-        (void)hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<NDB, DR, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((attn_bwd_ds_kernel<NDB, DR, KT>), dim3((unsigned)grid), dim3(256), lds, s, a);                        \
+#define A3T_DS2(NDB, DR, WD)                                                                                                         \
+    do {                                                                                                                             \
+        constexpr int lds = 3 * DT32<NDB>::BYTES + 4 * 32 * (KT * 64 + 16);                                                          \
+        (void)hipFuncSetAttribute((const void*)attn_bwd_ds_kernel<NDB, DR, KT, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((attn_bwd_ds_kernel<NDB, DR, KT, WD>), dim3((unsigned)grid), dim3(256), lds, s, a);                        \
+    } while (0)
+#define A3T_DS1(NDB, DR)              \
+    do {                              \
+        if (a.dbd) A3T_DS2(NDB, DR, true); \
+        else A3T_DS2(NDB, DR, false); \
     } while (0)
 #define A3T_DS(NDB)                      \
     do {                                 \
@@ -1587,6 +1599,7 @@ extern "C" int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v,
         default: return A3T_EINVAL;
     }
 #undef A3T_DS1
+#undef A3T_DS2
 #undef A3T_DS
     return (int)hipGetLastError();
 }

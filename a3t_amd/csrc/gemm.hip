@@ -471,7 +471,11 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
     p.slab = nullptr;
     p.a_signmask = d->a_signmask ? 1 : 0;
     p.A2 = d->A2, p.B2 = d->B2, p.b2_cs = d->b2_cs, p.b2_bs0 = d->b2_bs0, p.b2_bs1 = d->b2_bs1, p.colsum2 = d->colsum2;
-    if ((p.A2 == nullptr) != (p.B2 == nullptr) || (!p.A2 && p.colsum2)) return A3T_EINVAL;
+    p.a2_rs = d->a2_rs, p.a_unaligned = d->a_unaligned;
+    if ((p.A2 == nullptr) != (p.B2 == nullptr) || (!p.A2 && (p.colsum2 || p.a2_rs || (p.a_unaligned & 2))) || (p.a_unaligned & ~3)) return A3T_EINVAL;
+    if ((p.a_unaligned & 1) && (d->compute != A3T_BF16 || d->a_dtype != A3T_BF16 || d->b_dtype != A3T_BF16 || p.taps > 1 || d->Tseq > 0 ||
+                                ((uintptr_t)p.A & 1)))
+        return A3T_EINVAL;
     p.keep_layout = (p.keep_out || p.keep_in) ? d->keep_layout : 0;
     if (p.keep_layout != 0 && p.keep_layout != 1) return A3T_EINVAL;
     const bool keep = p.keep_out || p.keep_in;
@@ -525,7 +529,7 @@ extern "C" int a3t_gemm(const a3t_gemm_desc* d, void* stream_) {
         int rc = a3t_gemm_bf16_glds(p, batch, AK, BKC, stream);   // direct-to-LDS production kernel
         if (rc >= 0) return rc;                                   // -1: alignment contract not met
     }
-    if (keep || p.a_signmask || p.A2) return A3T_EINVAL;        // keep-bit images only exist in the 8-phase kernel, sign masks in the direct-to-LDS TN kernels
+    if (keep || p.a_signmask || p.A2 || p.a_unaligned) return A3T_EINVAL;        // keep-bit images only exist in the 8-phase kernel, sign masks in the direct-to-LDS TN kernels
     if (d->colsum) return A3T_EINVAL;   // fused column sums live in the direct-to-LDS kernel's epilogue
     {
         const int ea = d->a_dtype == A3T_BF16 ? 2 : 4, eb = d->b_dtype == A3T_BF16 ? 2 : 4;

@@ -472,12 +472,13 @@ static void launch_variant(const GP& pv, dim3 grid, hipStream_t stream) {
 
 // returns -1 when the descriptor does not meet the alignment contract of this kernel
 int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t stream) {
-    bool ok = al16(p.A) && al16(p.B) && m8(p.a_bs0) && m8(p.a_bs1) && m8(p.b_bs0) && m8(p.b_bs1);
+    const bool aview = (p.a_unaligned & 1) != 0;     // A: a 2-byte aligned strided view (the loaders only do pointer arithmetic)
+    bool ok = (aview || al16(p.A)) && al16(p.B) && m8(p.a_bs0) && m8(p.a_bs1) && m8(p.b_bs0) && m8(p.b_bs1);
     if (AK || BKC) ok = ok && m8(p.Kc);      // (16-byte granules run along k only for k-contiguous operands)
     if (AK)
-        ok = ok && m8(p.a_rs) && m8(p.K);
+        ok = ok && (aview || m8(p.a_rs)) && m8(p.K);
     else
-        ok = ok && m8(p.a_cs) && m8(p.M);
+        ok = ok && (aview || m8(p.a_cs)) && m8(p.M);
     if (BKC)
         ok = ok && m8(p.b_rs) && m8(p.K) && m8(p.b_ts);
     else
@@ -496,15 +497,15 @@ int a3t_gemm_bf16_glds(const GP& p, int batch, bool AK, bool BKC, hipStream_t st
                     (p.keep_out && p.R) || (p.keep_in && p.S)))
         return A3T_EINVAL;
     if (p.a_signmask && (AK || BKC || p.taps > 1 || p.kshift_mode)) return -1;   // (fragment-register pass of the m-contiguous A only)
-    if (!(pv.keep_out || (pv.keep_in && !keep_rm) || p.a_signmask || p.A2)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
+    if (!(pv.keep_out || (pv.keep_in && !keep_rm) || p.a_signmask || p.A2 || aview)) {   // N = 384 outputs: one 160-row panel x all columns per workgroup (-1: does not qualify)
         const int rc = a3t_gemm_bf16_pn(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }
-    if (!p.a_signmask && !keep_rm && !p.A2) {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
+    if (!p.a_signmask && !keep_rm && !p.A2 && !aview) {   // many-tile k-contiguous GEMMs: persistent 256x256 8-phase kernel (returns -1 when the problem does not qualify)
         const int rc = a3t_gemm_bf16_8p(pv, batch, (AK && BKC) ? L_NT : (AK ? L_NN : L_TN), stream);
         if (rc != -1) return rc;
     }
-    if (!BKC && !(pv.keep_in || pv.keep_out)) {   // score-sized A operand x [k][n] slices (attention backward): one streaming workgroup per CU
+    if (!BKC && !(pv.keep_in || pv.keep_out) && !aview) {   // score-sized A operand x [k][n] slices (attention backward): one streaming workgroup per CU
         const int rc = a3t_gemm_bf16_tt(pv, batch, AK ? L_NN : L_TN, stream);
         if (rc != -1) return rc;
     }

@@ -111,7 +111,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(is_a ? A : B), 0, (int)(is_a ? a_ext : b_ext), 0x00020000);
     const unsigned b2_ld = DUAL ? (unsigned)p.b2_cs * 2u : 0u;
     const void* X2 = DUAL ? (is_a ? (const void*)((const u16*)p.A2 + z0 * p.a_bs0 + z1 * p.a_bs1) : (const void*)((const u16*)p.B2 + z0 * p.b2_bs0 + z1 * p.b2_bs1)) : (const void*)A;
-    const __amdgpu_buffer_rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc((void*)X2, 0, (int)(is_a ? a_ext : (unsigned)(p.K - 1) * b2_ld + (unsigned)p.N * 2u), 0x00020000);
+    const unsigned a2_ld = (DUAL && p.a2_rs) ? (unsigned)p.a2_rs * 2u : a_ld;      // (A2 may be a view with a row stride of its own)
+    const __amdgpu_buffer_rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc((void*)X2, 0, (int)(is_a ? (unsigned)(p.M - 1) * a2_ld + (unsigned)p.K * 2u : (unsigned)(p.K - 1) * b2_ld + (unsigned)p.N * 2u), 0x00020000);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_AS(smem));
 
     // ---- DMA lane geometry.  Slot s = 4 w + q: s < 20 -> A piece s, else B piece s - 20.
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tt_kernel(GP p, int TR) {
             const int g = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
             const bool ok = R < TR && m0 + R < p.M;
             voff[q] = ok ? (unsigned)(m0 + R) * a_ld + (unsigned)g * 16u : OOB;
-            voff2[q] = voff[q];
+            voff2[q] = ok ? (unsigned)(m0 + R) * a2_ld + (unsigned)g * 16u : OOB;
             kq[q] = g * 8;
         } else {
             const int s = is_a ? w * 4 + q : (w - 5) * 4 + q;
@@ -368,9 +369,14 @@ int a3t_gemm_bf16_tt(const GP& p, int batch, int ly, hipStream_t stream) {
     const int mode = tt_mode();
     if (mode == 0 || (ly != 1 && ly != 2) || p.splitk != 1 || p.accumulate == A3T_ACC_ATOMIC) return -1;
     if (p.a_signmask && ly != 2) return -1;
-    if (p.A2 && (ly != 1 || p.accumulate != A3T_ACC_STORE || !p.B2 || p.b2_cs % 8 || (p.b2_bs0 | p.b2_bs1) % 8 || ((uintptr_t)p.A2 | (uintptr_t)p.B2) & 15 ||
-                 p.b2_cs * 2 * (int64_t)p.K >= (1ll << 31) || (p.colsum != nullptr) != (p.colsum2 != nullptr)))
-        return -1;
+    if (p.A2) {
+        const bool v2 = (p.a_unaligned & 2) != 0;       // A2: a 2-byte aligned view with any row stride
+        const int64_t a2 = p.a2_rs ? p.a2_rs : p.a_rs;
+        if (ly != 1 || p.accumulate != A3T_ACC_STORE || !p.B2 || p.b2_cs % 8 || (p.b2_bs0 | p.b2_bs1) % 8 || ((uintptr_t)p.B2 & 15) ||
+            ((uintptr_t)p.A2 & (v2 ? 1 : 15)) || (!v2 && a2 % 8) || a2 < p.K || a2 * 2 * (int64_t)p.M >= (1ll << 31) ||
+            p.b2_cs * 2 * (int64_t)p.K >= (1ll << 31) || (p.colsum != nullptr) != (p.colsum2 != nullptr))
+            return -1;
+    }
     if (p.taps > 1 || p.kshift_mode || p.keep_in || p.keep_out || !p.epi_vec) return -1;
     if (p.b_rs != 1 || p.N > 192 || p.N % 8 || p.M % 8 || p.K % 8) return -1;
     if (ly == 1 ? (p.a_cs != 1 || p.a_rs % 8) : (p.a_rs != 1 || p.a_cs % 8)) return -1;

@@ -40,6 +40,8 @@ struct GP {
     const void* B2;
     int64_t b2_cs, b2_bs0, b2_bs1;
     float* colsum2;
+    int64_t a2_rs;                  // row stride of A2 (0: A's)
+    int a_unaligned;                // bit 0: A, bit 1: A2 is a 2-byte aligned strided view (a3t_gemm_desc::a_unaligned)
     int keep_layout;                // 1: keep_out / keep_in are the row-major nibble image (a3t_gemm_desc::keep_layout)
     int a_signmask;                 // A elements with the sign bit set are read as zero (m-contiguous bf16 A: gemm_bf16_tt.hip, gemm_bf16.hip L_TN)
 };

@@ -211,6 +211,7 @@ class MLMEngine:
         # the forward per layer at configs[1], 415 MB at configs[3] -- is gone.  A3T_ATTN_SIGNED=0: two tensors (the A/B twin).
         self.attn_signed = os.environ.get("A3T_ATTN_SIGNED", "1") != "0"
         self.attn_dq_dual = os.environ.get("A3T_ATTN_DQ_DUAL", "1") != "0"
+        self.attn_dbd_view = os.environ.get("A3T_ATTN_DBD_VIEW", "1") != "0"
         # Fused legacy rel-pos attention forward (csrc/attn_fused.hip: scores, shifted position term, softmax, dropout and PV in one
         # launch, no logits in HBM).  A3T_FUSED_ATTN = auto (default) | fwd | 0:
         #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; below that its
@@ -758,14 +759,26 @@ class MLMEngine:
                 ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
         qv_ready = self._side(dv_gemm, want_event=make_q, urgent=True)
         zbd = zb
-        if self.bf16:
+        # dq = ds K + dbd P as one launch of the streaming kernel (below) -- and then the compact dBD matrix is not stored at all: it
+        # is the flat dS sequence shifted by T - 1 elements, read by its two consumers as a strided VIEW of dS (row stride T + 1,
+        # 2-byte aligned rows: the LDS-DMA takes them) with T zeros in front of every (b, h) block for the entries of its first row
+        # that never reach the scores (attention.py:157-165).  A3T_ATTN_DBD_VIEW=0: the stored matrix.
+        dual = ds_fused and fz and self.attn_dq_dual and ops.gemm_tt_supported(T, dk, T, B * H)
+        dview = dual and self.attn_dbd_view
+        if dview:
+            bsv = T + T * T
+            flat = self.ws.get(self._t("tmp.dsv"), (B * H * bsv,), torch.bfloat16, zero_once=True)
+            ds, dbd = flat[T:], flat[1:]
+            zbd = (H * bsv, bsv)       # (batch strides of ds and of its dbd view; zb stays the probabilities')
+        elif self.bf16:
             ds = self.ws.get("tmp.ds16", (B, H, T, T), torch.bfloat16)
             dbd = self.ws.get(self._t("tmp.dbd16"), (B, H, T, T), torch.bfloat16)
         else:
             ds = dpr
             dbd = self.ws.get(self._t("tmp.dbd"), (B, H, T, T), sdt)
         if ds_fused:
-            ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=adr or (0.0, 0), signed_probs=signed)
+            ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, None if dview else dbd, B, H, T, scale, drop=adr or (0.0, 0),
+                            signed_probs=signed, ds_bs=zbd[1] if dview else 0)
         else:
             ops.relpos_softmax_bwd(probs, dpr, ds, dbd, B, H, T, scale, probs_drop=None if regen else pdrop,
                                    drop_p=adr[0] if adr else 0.0, drop_key=adr[1] if regen else 0, rowscale=rs)
@@ -773,8 +786,8 @@ class MLMEngine:
             if qv_ready is not None and self.side is not None:
                 qv_ready.wait_on(self.side)
             dP = self._arena_slot("bwd32", tag + ".dP", T * d).view(T, d)   # cleared once per backward (main stream)
-            ops.gemm(dbd, qv, dP, T, dk, T, 1, T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zb, b_bs=(T * d, dk),
-                     c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp)
+            ops.gemm(dbd, qv, dP, T, dk, T, 1, T + 1 if dview else T, 1, d, d, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(T * d, dk),
+                     c_bs=(0, dk), acc=ACC_ATOMIC, compute=cmp, a_view=dview)
             if self.bf16:
                 dP16 = self.ws.get("tmp.dP16", (T, d), torch.bfloat16)
                 ops.cast_bf16(dP, dP16)
@@ -791,15 +804,15 @@ class MLMEngine:
         # dqu[b,h] = ds K ; dK[b,h] = ds^T (q+u)
         # bf16 path on the streaming kernel: dq = ds K + dbd P as ONE launch (two K loops into one accumulator set, one rounding, no
         # read-modify-write of the q third; their column sums come apart at the hand-over) -- A3T_ATTN_DQ_DUAL=0: two launches
-        dual = dq_acc and self.attn_dq_dual and ops.gemm_tt_supported(T, dk, T, B * H)
         if dual:
-            ops.gemm(ds, kk, dqkv, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zb,
-                     b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl, second=(dbd, P, d, (0, dk), sl[d:]), **csk)
+            ops.gemm(ds, kk, dqkv, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zbd,
+                     b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl,
+                     second=(dbd, P, d, (0, dk), sl[d:]) + ((T + 1,) if dview else ()), **csk)
         else:
-            ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zb,
+            ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zbd,
                      b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl if fz else None, **csk)
         dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
-                                              a_bs=zb, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
+                                              a_bs=zbd, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
                                               colsum=sl[2 * d:] if fz else None, **csk), want_event=True, urgent=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         if not dual:

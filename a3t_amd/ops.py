@@ -38,7 +38,7 @@ def _dt(t):
 def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R=None, S=None, batch=1,
          batch_inner=1, a_bs=(0, 0), b_bs=(0, 0), c_bs=(0, 0), taps=1, pad=0, dil=1, Tseq=0, kshift=0, alpha=1.0,
          act=ACT_NONE, acc=ACC_STORE, splitk=1, compute=F32, colsum=None, colsum_bs1=0, colsum_scale=1.0,
-         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, a_signmask=False, keep_layout=0, second=None):
+         drop=None, colsum_slots=1, colsum_ss=0, keep_out=None, keep_in=None, a_signmask=False, keep_layout=0, second=None, a_view=False):
     """C (op)= alpha*mask(act(A(m,k) B(n,k) + bias)) + R  -- see a3t_gemm_desc in include/a3t_hip.h."""
     lib = L.load()
     d = L.GemmDesc()
@@ -64,11 +64,15 @@ def gemm(A, B, C, M, N, K, a_rs, a_cs, b_rs, b_cs, c_rs, *, b_ts=0, bias=None, R
     d.keep_in = keep_in.data_ptr() if keep_in is not None else None
     d.a_signmask = 1 if a_signmask else 0
     d.keep_layout = keep_layout
-    if second is not None:      # (A2, B2, b2_cs, (b2_bs0, b2_bs1), colsum2): C = alpha (A B + A2 B2) in one launch of the streaming kernel
-        A2, B2, b2_cs, b2_bs, cs2 = second
+    d.a_unaligned = 1 if a_view else 0      # A is a 2-byte aligned strided view (the compact dBD read off dS)
+    if second is not None:      # (A2, B2, b2_cs, (b2_bs0, b2_bs1), colsum2[, a2_rs]): C = alpha (A B + A2 B2) in one launch of the
+        A2, B2, b2_cs, b2_bs, cs2 = second[:5]      # streaming kernel; a2_rs given: A2 is such a view with that row stride
         d.A2, d.B2, d.b2_cs = A2.data_ptr(), B2.data_ptr(), b2_cs
         d.b2_bs0, d.b2_bs1 = b2_bs
         d.colsum2 = cs2.data_ptr() if cs2 is not None else None
+        if len(second) > 5:
+            d.a2_rs = second[5]
+            d.a_unaligned |= 2
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to a3t_gemm
@@ -391,16 +395,18 @@ def attn_scale_rows(x, rowscale, y, B, H, T):
     L.check(L.load().a3t_attn_scale_rows(_ptr(x), _ptr(rowscale), _ptr(y), B, H, T, d // H, _stream()), "attn_scale_rows")
 
 
-def attn_bwd_ds(dctx, ctx, qkv, probs, rowscale, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=False, signed_probs=False):
+def attn_bwd_ds(dctx, ctx, qkv, probs, rowscale, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=False, signed_probs=False,
+                ds_bs=0):
     """dS and the compact dBD from the saved un-normalised probabilities of attn_fwd_train (dP = dctx V^T is never stored; the row
     term delta = dctx . ctx is formed in the kernel): replaces the dprobs GEMM + relpos_softmax_bwd.  qkv: [B*T, 3d], V in
     columns 2d..3d; ctx: the forward's output [B*T, d].  signed_probs: probs is the sign-tagged single tensor of
-    attn_fwd_train(probs_drop=None) -- the dropout mask is read off its sign bits."""
+    attn_fwd_train(probs_drop=None) -- the dropout mask is read off its sign bits.  dbd=None: only dS is written, into (b, h) blocks
+    ds_bs elements apart (T zeros in front of each): the compact dBD matrix is then the view ds.view(-1)[-(T-1):] with row stride T + 1."""
     d = dctx.shape[1]
     v = qkv.view(-1)[2 * d:]
     bsb, bsh = ((T * T, B * T * T) if dbd_head_major else (0, 0))
     L.check(L.load().a3t_attn_bwd_ds(_ptr(dctx), _ptr(ctx), _ptr(v), _ptr(probs), _ptr(rowscale), _ptr(ds), _ptr(dbd), B, H, T,
-                                     d // H, d, 3 * d, bsb, bsh, scale, drop[0], drop[1], 1 if signed_probs else 0, _stream()), "attn_bwd_ds")
+                                     d // H, d, 3 * d, bsb, bsh, scale, drop[0], drop[1], 1 if signed_probs else 0, ds_bs, _stream()), "attn_bwd_ds")
 
 
 def mask_fill(speech, masked, mask_feature, out):

@@ -62,7 +62,7 @@ extern "C" {
  * Batching: z in [0,batch): z0 = z / batch_inner, z1 = z % batch_inner; X += z0*x_bs0 + z1*x_bs1.
  * splitk>1 splits K over extra workgroups; requires accumulate == A3T_ACC_ATOMIC or A3T_ACC_SOLE.
  * ZERO-INITIALISE the descriptor (`a3t_gemm_desc d = {0};`): optional fields are appended as the library grows (round 6: a_signmask,
- * keep_layout, A2 .. colsum2) and zero / NULL always means "off".
+ * keep_layout, A2 .. a_unaligned) and zero / NULL always means "off".
  */
 typedef struct a3t_gemm_desc {
     const void* A;
@@ -125,6 +125,12 @@ typedef struct a3t_gemm_desc {
     int64_t b2_cs, b2_bs0, b2_bs1;
     float* colsum2;                    /* with colsum: column sums of the second product's share (colsum takes the first's); same
                                             slots / strides as colsum */
+    int64_t a2_rs;                     /* row stride of A2 (0: A's) */
+    int32_t a_unaligned;               /* bit 0: A, bit 1: A2 is a strided VIEW whose base is only 2-byte aligned and whose leading
+                                            stride is any number of elements (the 16-byte LDS-DMA of gfx950 takes such sources):
+                                            the compact dBD matrix of the attention backward read off the dS tensor it is a shifted
+                                            copy of (dbd[r][c] = ds_flat[r (T + 1) + c - (T - 1)]; a3t_attn_bwd_ds with dbd = NULL).
+                                            Bit 0: the 128-row kernel, plain (taps == 1) bf16 products only; bit 1: with A2. */
 } a3t_gemm_desc;
 
 int a3t_gemm(const a3t_gemm_desc* d, void* stream);
@@ -271,12 +277,15 @@ int a3t_attn_scale_rows(const void* x, const float* rowscale, void* y, int B, in
  * a3t_relpos_softmax_bwd (block (b, h) at b*dbd_bsb + h*dbd_bsh elements, both 0 = [B][H][T][T]; every entry is written).
  * Replaces the dprobs GEMM + a3t_relpos_softmax_bwd of the materialised backward.  dctx row stride ldo, v row stride ldkv
  * (head h at column h*dk), dk % 32 == 0 (<= 192, not 160), T % 8 == 0.
+ * dbd == NULL: the compact matrix is not written -- it is the flat dS sequence shifted by T - 1 elements, and a consumer reads it as
+ * a view of ds (a3t_gemm_desc::a_unaligned: base ds - (T - 1), row stride T + 1); ds_bs = elements between the (b, h) blocks of ds
+ * (0: T * T; for the view T zeros in front of every block, i.e. ds_bs >= T * T + T with ds pointing behind the first block's zeros).
  * signed_probs != 0 (drop_p > 0): probs is the sign-tagged single tensor of a3t_attn_fwd_train -- the probability is |x|, keep_ij
  * is read off the sign bit instead of being regenerated (drop_key unused); signed_probs == 0 also accepts such a tensor (|x| is
  * taken either way) as long as drop_key is the forward's. */
 int a3t_attn_bwd_ds(const void* dctx, const void* ctx, const void* v, const void* probs, const float* rowscale, void* ds,
                     void* dbd, int B, int H, int T, int dk, int64_t ldo, int64_t ldkv, int64_t dbd_bsb, int64_t dbd_bsh,
-                    float scale, float drop_p, uint32_t drop_key, int signed_probs, void* stream);
+                    float scale, float drop_p, uint32_t drop_key, int signed_probs, int64_t ds_bs, void* stream);
 
 /* Encoder prologue (conformer/encoder.py:522-553, mlm_encoder.py:57-70). */
 int a3t_mask_fill(const float* speech, const uint8_t* masked, const float* mask_feature, void* out,

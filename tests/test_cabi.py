@@ -48,7 +48,8 @@ def test_gemm_desc_layout_matches_header():
     # (round 6: + a_signmask, the sign-tagged probabilities of the attention backward's dV product)
     assert GemmDesc.a_signmask.offset == 280 and GemmDesc.keep_layout.offset == 284 and GemmDesc.A2.offset == 288
     # (... and the second product of one streaming launch: A2, B2, b2_cs, b2_bs0, b2_bs1, colsum2)
-    assert GemmDesc.colsum2.offset == 328 and ctypes.sizeof(GemmDesc) == 336
+    assert GemmDesc.colsum2.offset == 328 and GemmDesc.a2_rs.offset == 336 and GemmDesc.a_unaligned.offset == 344
+    assert ctypes.sizeof(GemmDesc) == 352
 
 
 def test_gemm_desc_layout_as_the_c_compiler_sees_the_header(tmp_path):

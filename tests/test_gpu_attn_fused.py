@@ -722,3 +722,119 @@ def test_engine_step_with_one_saved_probability_tensor_matches_the_two_tensor_st
             continue
         cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
         assert cos > 0.999 and 0.98 < float(a.norm()) / nb < 1.02, (k, cos, float(a.norm()) / nb)
+
+
+@pytest.mark.parametrize("B,H,T,dk,lengths", [(2, 2, 136, 32, None), (3, 2, 200, 64, [200, 131, 0]), (2, 2, 328, 192, [328, 211]),
+                                              (3, 2, 1120, 96, [1120, 900, 1000]), (32, 2, 1120, 192, None)])
+def test_compact_dbd_matrix_read_as_a_view_of_ds(B, H, T, dk, lengths):
+    """Round 6: the compact dBD matrix is the flat dS sequence shifted by T - 1 elements (the inverse of the legacy rel_shift,
+    attention.py:145-165): dbd[r][c] = ds_flat[r (T + 1) + c - (T - 1)].  a3t_attn_bwd_ds with dbd = NULL writes dS only, into (b, h)
+    blocks with T zeros in front of each; torch.as_strided over that buffer (row stride T + 1, base one element into the zeros) IS
+    the matrix the kernel used to store -- bit for bit -- and its two consumers read it that way through the 16-byte LDS-DMA from
+    2-byte aligned rows: the dq launch (a3t_gemm_desc::A2 with a2_rs = T + 1; same bits as over the stored matrix) and the
+    gradient of linear_pos (A as a view on the 128-row kernel, fp32 atomics: same sums)."""
+    from a3t_amd import _lib, ops
+    from a3t_amd._lib import ACC_ATOMIC, BF16
+    lib = _lib.load()
+    qkv, qu, qv, P, keymask = _inputs(B, H, T, dk, seed=5 * T + dk, lengths=lengths)
+    d, M = H * dk, B * T
+    scale, drop = 1.0 / math.sqrt(dk), (0.2, 0xD0D0)
+    ctx = torch.zeros(M, d, device=DEV, dtype=torch.bfloat16)
+    lse, rs = torch.zeros(B, H, T, device=DEV), torch.zeros(B, H, T, device=DEV)
+    sp = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    ops.attn_fwd_train(qu, qv, qkv, P, keymask, ctx, lse, sp, None, rs, B, H, T, scale, drop=drop)
+    g = torch.Generator(device=DEV).manual_seed(T)
+    dctx = torch.randn(M, d, device=DEV, generator=g).bfloat16()
+    ds0 = torch.zeros(B, H, T, T, device=DEV, dtype=torch.bfloat16)
+    dbd0 = torch.full((B, H, T, T), 3.0, device=DEV, dtype=torch.bfloat16)
+    ops.attn_bwd_ds(dctx, ctx, qkv, sp, rs, ds0, dbd0, B, H, T, scale, drop=drop, signed_probs=True)
+    bs = T + T * T
+    flat = torch.zeros(B * H * bs, device=DEV, dtype=torch.bfloat16)
+    ops.attn_bwd_ds(dctx, ctx, qkv, sp, rs, flat[T:], None, B, H, T, scale, drop=drop, signed_probs=True, ds_bs=bs)
+    torch.cuda.synchronize()
+    blocks = flat.view(B * H, bs)
+    assert torch.equal(blocks[:, T:].reshape(B, H, T, T), ds0)
+    assert not bool(blocks[:, :T].any()), "the zeros in front of the blocks are nobody's output"
+    view = torch.as_strided(flat, (B * H, T, T), (bs, T + 1, 1), storage_offset=1)
+    assert torch.equal(view.reshape(B, H, T, T), dbd0), "the stored dBD matrix is this view of dS"
+    # ---- dq = dS K + dBD P: A2 as the view against A2 as the stored matrix
+    zb, zv = (H * T * T, T * T), (H * bs, bs)
+    NS = 4
+    csk = dict(colsum_bs1=dk, colsum_slots=NS, colsum_ss=4 * d)
+    old = lib.a3t_gemm_tt_mode(1)
+    try:
+        outs = []
+        for A, A2, zz, extra in ((ds0, dbd0, zb, ()), (flat[T:], flat[1:], zv, (T + 1,))):
+            o = torch.full((M, 3 * d), 0.25, device=DEV).bfloat16()
+            s = torch.zeros(NS * 4 * d, device=DEV)
+            ops.gemm(A, qkv.view(-1)[d:], o, T, dk, T, T, 1, 1, 3 * d, 3 * d, batch=B * H, batch_inner=H, a_bs=zz, b_bs=(T * 3 * d, dk),
+                     c_bs=(T * 3 * d, dk), compute=BF16, colsum=s, second=(A2, P, d, (0, dk), s[d:]) + extra, **csk)
+            torch.cuda.synchronize()
+            assert lib.a3t_gemm_last_kernel().decode().endswith("true>")
+            outs.append((o, s))
+    finally:
+        lib.a3t_gemm_tt_mode(old)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-4 * float(outs[0][1].abs().max()) + 1e-7)
+    assert float(outs[0][0].float().view(B, T, 3, H, dk)[:, :, 0].abs().max()) > 0
+    # ---- d linear_pos: dP_h += sum_b dbd^T (q + v), the view as the [k][m] operand of the 128-row kernel
+    res = []
+    for A, acs, zz, vw in ((dbd0, T, zb, False), (flat[1:], T + 1, zv, True)):
+        dP = torch.zeros(T, d, device=DEV)
+        ops.gemm(A, qv, dP, T, dk, T, 1, acs, 1, d, d, batch=B * H, batch_inner=H, a_bs=zz, b_bs=(T * d, dk), c_bs=(0, dk),
+                 acc=ACC_ATOMIC, compute=BF16, a_view=vw)
+        torch.cuda.synchronize()
+        res.append(dP)
+    assert torch.allclose(res[0], res[1], rtol=1e-4, atol=1e-4 * float(res[0].abs().max()) + 1e-7)
+    assert float(res[0].abs().max()) > 0
+    # an odd leading stride without the flag is refused
+    with pytest.raises(Exception):
+        ops.gemm(flat[1:], qv, torch.zeros(T, d, device=DEV), T, dk, T, 1, T + 1, 1, d, d, batch=B * H, batch_inner=H, a_bs=zv,
+                 b_bs=(T * d, dk), c_bs=(0, dk), acc=ACC_ATOMIC, compute=BF16)
+
+
+@pytest.mark.parametrize("knob", ["A3T_ATTN_DBD_VIEW", "A3T_ATTN_DQ_DUAL"])
+def test_engine_step_without_a_stored_dbd_matrix_matches_the_step_with_one(knob, monkeypatch):
+    """The default training step (dq in one launch, dBD read as a view of dS) against its twins (the stored matrix; dq as two
+    launches): same masks, same loss bits (nothing in the forward changes), every parameter gradient equal to bf16 accuracy -- with
+    the view the dq launch sums the same values in the same order (bit-equal products), only the atomics of d linear_pos reorder."""
+    from a3t_amd.config import A3TConfig
+    from a3t_amd.engine import MLMEngine
+    from a3t_amd.params import ParamStore
+    from a3t_amd import _lib
+    lib = _lib.load()
+    monkeypatch.delenv("A3T_FUSED_ATTN", raising=False)
+    monkeypatch.setenv("A3T_FUSED_ATTN_TRAIN", "2")
+    oc = O.A3TConfig(adim=192, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
+    c = A3TConfig(adim=192, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab,
+                  dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
+    state = O.procedural_state(O.param_shapes(oc), 5)
+    batch = {k: v.to(DEV) for k, v in O.synthetic_batch(oc, B=8, T_mel=560, T_phn=56, seed=9, lengths=[560] * 5 + [341, 177, 8],
+                                                        text_lengths=[56] * 5 + [37, 19, 3]).items()}
+    old = lib.a3t_gemm_tt_mode(1)        # (the streaming kernel whenever legal: these shapes are below its cost model's sizes)
+    try:
+        res = {}
+        for val in ("0", "1"):
+            monkeypatch.setenv(knob, val)
+            store = ParamStore(c, DEV)
+            store.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+            eng = MLMEngine(c, store, compute="bf16", training=True, dropout=True)
+            loss = float(eng.forward(batch)["loss"])
+            store.zero_grad()
+            eng.backward()
+            torch.cuda.synchronize()
+            has_view = any(k[0].endswith("tmp.dsv") or "tmp.dsv" in k[0] for k in eng.ws.bufs)
+            has_dbd = any("tmp.dbd16" in k[0] for k in eng.ws.bufs)
+            res[val] = (loss, store.state_dict(grads=True), has_view, has_dbd)
+    finally:
+        lib.a3t_gemm_tt_mode(old)
+    (l0, g0, v0, d0), (l1, g1, v1, d1) = res["0"], res["1"]
+    assert v1 and not d1 and (not v0) and d0, (v0, d0, v1, d1)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    for k in g0:
+        a, b_ = g1[k].double().flatten(), g0[k].double().flatten()
+        nb = float(b_.norm())
+        if nb < 1e-6 or k.endswith("linear_k.bias"):
+            continue
+        cos = float((a * b_).sum() / (a.norm() * b_.norm() + 1e-30))
+        assert cos > 0.9995 and 0.99 < float(a.norm()) / nb < 1.01, (k, cos, float(a.norm()) / nb)

@@ -57,6 +57,14 @@ def ds_signed():      # the engine's default since round 6: the mask is the sign
     ops.attn_bwd_ds(dctx, ctx, qkv, sprobs, rs, ds, dbd, B, H, T, scale, drop=drop, dbd_head_major=True, signed_probs=True)
 
 
+bs_ = T + T * T
+flat_ = torch.zeros(B * H * bs_, device="cuda", dtype=torch.bfloat16)
+
+
+def ds_signed_no_dbd():      # dBD not stored: read by its consumers as a view of dS (engine default)
+    ops.attn_bwd_ds(dctx, ctx, qkv, sprobs, rs, flat_[T:], None, B, H, T, scale, drop=drop, signed_probs=True, ds_bs=bs_)
+
+
 def ds_nodrop():
     ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, scale, drop=(0.0, 0), dbd_head_major=True)
 
@@ -66,7 +74,7 @@ def gemm_only():
              c_bs=zb, compute=BF16)
 
 
-for name, fn in (("new", new), ("old", old), ("ds", ds_only), ("ds_signed", ds_signed), ("ds_nodrop", ds_nodrop), ("dprobs_gemm", gemm_only)):
+for name, fn in (("new", new), ("old", old), ("ds", ds_only), ("ds_signed", ds_signed), ("ds_signed_no_dbd", ds_signed_no_dbd), ("ds_nodrop", ds_nodrop), ("dprobs_gemm", gemm_only)):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
