@@ -759,12 +759,12 @@ class MLMEngine:
                 ops.add_pos_bias(qkv, p[pre + ".u"], p[pre + ".v"], qu, qv)
         qv_ready = self._side(dv_gemm, want_event=make_q, urgent=True)
         zbd = zb
-        # dq = ds K + dbd P as one launch of the streaming kernel (below) -- and then the compact dBD matrix is not stored at all: it
+        # dq = ds K + dbd P as one launch of the streaming kernel where it runs (below); and the compact dBD matrix is not stored at all: it
         # is the flat dS sequence shifted by T - 1 elements, read by its two consumers as a strided VIEW of dS (row stride T + 1,
         # 2-byte aligned rows: the LDS-DMA takes them) with T zeros in front of every (b, h) block for the entries of its first row
         # that never reach the scores (attention.py:157-165).  A3T_ATTN_DBD_VIEW=0: the stored matrix.
         dual = ds_fused and fz and self.attn_dq_dual and ops.gemm_tt_supported(T, dk, T, B * H)
-        dview = dual and self.attn_dbd_view
+        dview = ds_fused and fz and self.attn_dbd_view
         if dview:
             bsv = T + T * T
             flat = self.ws.get(self._t("tmp.dsv"), (B * H * bsv,), torch.bfloat16, zero_once=True)
@@ -816,8 +816,8 @@ class MLMEngine:
                                               colsum=sl[2 * d:] if fz else None, **csk), want_event=True, urgent=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         if not dual:
-            ops.gemm(dbd, P, dqv, T, dk, T, T, 1, 1, d, ldq, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
-                     c_bs=cbq, acc=ACC_ADD if dq_acc else ACC_STORE, compute=cmp, colsum=sl[d:] if fz else None, **csk)
+            ops.gemm(dbd, P, dqv, T, dk, T, T + 1 if dview else T, 1, 1, d, ldq, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),
+                     c_bs=cbq, acc=ACC_ADD if dq_acc else ACC_STORE, compute=cmp, colsum=sl[d:] if fz else None, a_view=dview, **csk)
         if not dq_acc:
             ops.add_pos_bias_bwd(dqu, dqv, dqkv)      # (the dq slice only)
         if dk_done is not None:      # the dV / dK slices of dqkv and their column sums come from the side stream

@@ -829,7 +829,11 @@ def test_engine_step_without_a_stored_dbd_matrix_matches_the_step_with_one(knob,
     finally:
         lib.a3t_gemm_tt_mode(old)
     (l0, g0, v0, d0), (l1, g1, v1, d1) = res["0"], res["1"]
-    assert v1 and not d1 and (not v0) and d0, (v0, d0, v1, d1)
+    assert v1 and not d1, (v1, d1)
+    if knob == "A3T_ATTN_DBD_VIEW":
+        assert (not v0) and d0, (v0, d0)          # (dq as two launches reads the view too: no stored matrix on either side)
+    else:
+        assert v0 and not d0, (v0, d0)
     assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
     for k in g0:
         a, b_ = g1[k].double().flatten(), g0[k].double().flatten()
