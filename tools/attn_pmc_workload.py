@@ -32,6 +32,10 @@ ds = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
 dbd = torch.empty(B, H, T, T, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
     ops.attn_bwd_ds(dctx, ctx, qkv, probs, rs, ds, dbd, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345))
-for _ in range(3):      # mask off the sign bits (attn_bwd_ds_kernel<6, 2, 5>)
+for _ in range(3):      # mask off the sign bits (attn_bwd_ds_kernel<6, 2, 5, true>)
     ops.attn_bwd_ds(dctx, ctx, qkv, sprobs, rs, ds, dbd, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345), signed_probs=True)
+bs = T + T * T
+flat = torch.zeros(B * H * bs, device="cuda", dtype=torch.bfloat16)
+for _ in range(3):      # the engine's default: dS only, dBD is a view of it (attn_bwd_ds_kernel<6, 2, 5, false>)
+    ops.attn_bwd_ds(dctx, ctx, qkv, sprobs, rs, flat[T:], None, B, H, T, 1.0 / math.sqrt(dk), drop=(0.2, 12345), signed_probs=True, ds_bs=bs)
 torch.cuda.synchronize()
