@@ -805,6 +805,8 @@ def test_engine_step_without_a_stored_dbd_matrix_matches_the_step_with_one(knob,
     lib = _lib.load()
     monkeypatch.delenv("A3T_FUSED_ATTN", raising=False)
     monkeypatch.setenv("A3T_FUSED_ATTN_TRAIN", "2")
+    for k_ in ("A3T_ATTN_DBD_VIEW", "A3T_ATTN_DQ_DUAL", "A3T_ATTN_SIGNED", "A3T_ATTN_BWD_DS"):      # (the switch under test alone differs)
+        monkeypatch.setenv(k_, "1")
     oc = O.A3TConfig(adim=192, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32)
     c = A3TConfig(adim=192, heads=2, ff=256, enc_blocks=2, dec_blocks=1, postnet_layers=2, postnet_chans=32, vocab=oc.vocab,
                   dropout_rate=0.2, positional_dropout_rate=0.2, attention_dropout_rate=0.2, postnet_dropout_rate=0.5)
