@@ -332,3 +332,21 @@ def test_token_reduction_kernels_keep_their_register_footprint_and_their_dma_pip
         counted = [l.strip() for l in loop if re.search(r"s_waitcnt\s+vmcnt\((\d+)\)", l)]
         assert not drains, (name, drains)
         assert len(counted) >= 2, (name, counted)
+
+
+def test_backward_of_the_legacy_rel_shift_is_a_strided_view_of_the_score_gradient():
+    """What the engine's dBD view rests on (a3t_attn_bwd_ds with dbd = NULL, a3t_gemm_desc::a_unaligned), pinned on the CPU against
+    autograd through the oracle's restatement of LegacyRelPositionMultiHeadedAttention.rel_shift (attention.py:145-165):
+    grad(matrix_bd)[r][c] = grad(scores)_flat[r (T + 1) + c - (T - 1)], i.e. torch.as_strided over the flat score gradient with T zeros
+    in front of it (row stride T + 1, one element into the zeros) -- including the T - 1 entries of row 0 that never reach the scores."""
+    from oracle import a3t_oracle as O
+    g = torch.Generator().manual_seed(0)
+    for (B, H, T) in [(1, 1, 8), (2, 3, 40), (1, 2, 137)]:
+        bd = torch.randn(B, H, T, T, generator=g, dtype=torch.float64, requires_grad=True)
+        ds = torch.randn(B, H, T, T, generator=g, dtype=torch.float64)
+        (O.rel_shift_legacy(bd) * ds).sum().backward()
+        flat = torch.zeros(B * H, T + T * T, dtype=torch.float64)
+        flat[:, T:] = ds.reshape(B * H, T * T)
+        view = torch.as_strided(flat, (B * H, T, T), (T + T * T, T + 1, 1), storage_offset=1)
+        assert torch.equal(view.reshape(B, H, T, T), bd.grad), (B, H, T)
+        assert not bool(bd.grad[:, :, 0, :T - 1].any())
