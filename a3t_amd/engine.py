@@ -212,6 +212,7 @@ class MLMEngine:
         self.attn_signed = os.environ.get("A3T_ATTN_SIGNED", "1") != "0"
         self.attn_dq_dual = os.environ.get("A3T_ATTN_DQ_DUAL", "1") != "0"
         self.attn_dbd_view = os.environ.get("A3T_ATTN_DBD_VIEW", "1") != "0"
+        self.attn_dk_main = os.environ.get("A3T_ATTN_DK_MAIN", "1") != "0"
         # Fused legacy rel-pos attention forward (csrc/attn_fused.hip: scores, shifted position term, softmax, dropout and PV in one
         # launch, no logits in HBM).  A3T_FUSED_ATTN = auto (default) | fwd | 0:
         #   forward-only passes (need_grad=False) use a3t_attn_fwd when it launches >= 64 workgroups (fwd: always; below that its
@@ -811,9 +812,20 @@ class MLMEngine:
         else:
             ops.gemm(ds, kk, dqu, T, dk, T, T, 1, 1, 3 * d, ldq, batch=B * H, batch_inner=H, a_bs=zbd,
                      b_bs=(T * 3 * d, dk), c_bs=cbq, compute=cmp, colsum=sl if fz else None, **csk)
-        dk_done = self._side(lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
-                                              a_bs=zbd, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
-                                              colsum=sl[2 * d:] if fz else None, **csk), want_event=True, urgent=True)
+        dk_fn = lambda: ops.gemm(ds, qu, dkk, T, dk, T, 1, T, 1, d, 3 * d, batch=B * H, batch_inner=H,
+                                 a_bs=zbd, b_bs=(T * d, dk), c_bs=(T * 3 * d, dk), compute=cmp,
+                                 colsum=sl[2 * d:] if fz else None, **csk)
+        if self.attn_dk_main and dual and self.side is not None and make_q and qv_ready is not None:
+            # dK on the MAIN queue behind dq where the products run on the streaming kernel (second session): they take turns on the
+            # CUs whatever queue they sit on (128 KiB of LDS each), and a hand-over event behind the last of them cost the main queue
+            # ~25 us of bubble per layer (profiles/r06_trace_attn_layer.txt): 39.52 / 39.56 -> 39.41 / 39.39 ms.  On the 128-row kernel
+            # (configs[3]) dK and dq do run side by side: 58.2 -> 58.6 ms with dK on the main queue, so it stays on the side queue
+            # there.  (q + u) and dV come from the second side queue: its event is long past here.
+            qv_ready.wait_on(torch.cuda.current_stream())
+            dk_fn()
+            dk_done = None
+        else:
+            dk_done = self._side(dk_fn, want_event=True, urgent=True)
         # dqv[b,h] = dbd P_h ; dP_h += sum_b dbd^T (q+v)
         if not dual:
             ops.gemm(dbd, P, dqv, T, dk, T, T + 1 if dview else T, 1, 1, d, ldq, batch=B * H, batch_inner=H, a_bs=zbd, b_bs=(0, dk),

@@ -77,7 +77,7 @@ TRAIN=2 python tools/attn_fwd_time.py >> gpurun_out/r06_attn_bench.txt 2>&1
 python tools/ffn_dgrad2_time.py >> gpurun_out/r06_attn_bench.txt 2>&1
 python tools/attn_ds_time.py >> gpurun_out/r06_attn_bench.txt 2>&1
 python tools/collate_time.py > gpurun_out/r06_collate_time.txt 2>&1
-bash tools/step_ab.sh "default:A3T_X=0" "weight_gradients_on_the_128x128_kernel:A3T_GEMM_8P_TN3=0" "no_grouped_linear_weight_gradients:A3T_WGRAD_GROUP=0" "attention_products_on_the_128_row_kernel:A3T_GEMM_TT=0" "two_saved_probability_tensors:A3T_ATTN_SIGNED=0" "stored_dbd_matrix:A3T_ATTN_DBD_VIEW=0" "dq_as_two_launches:A3T_ATTN_DQ_DUAL=0" "ffn_mask_from_the_saved_activation:A3T_FFN_KEEP4=0" "both:A3T_ATTN_SIGNED=0 A3T_FFN_KEEP4=0" "materialised_score_gradients:A3T_ATTN_BWD_DS=0" "materialised_attention_forward:A3T_FUSED_ATTN_TRAIN=0" "one_stream:A3T_SIDE_STREAM=0" "default_again:A3T_X=0" > gpurun_out/r06_step_ab.txt 2>&1
+bash tools/step_ab.sh "default:A3T_X=0" "weight_gradients_on_the_128x128_kernel:A3T_GEMM_8P_TN3=0" "no_grouped_linear_weight_gradients:A3T_WGRAD_GROUP=0" "attention_products_on_the_128_row_kernel:A3T_GEMM_TT=0" "two_saved_probability_tensors:A3T_ATTN_SIGNED=0" "stored_dbd_matrix:A3T_ATTN_DBD_VIEW=0" "dk_on_the_second_side_queue:A3T_ATTN_DK_MAIN=0" "dq_as_two_launches:A3T_ATTN_DQ_DUAL=0" "ffn_mask_from_the_saved_activation:A3T_FFN_KEEP4=0" "both:A3T_ATTN_SIGNED=0 A3T_FFN_KEEP4=0" "materialised_score_gradients:A3T_ATTN_BWD_DS=0" "materialised_attention_forward:A3T_FUSED_ATTN_TRAIN=0" "one_stream:A3T_SIDE_STREAM=0" "default_again:A3T_X=0" > gpurun_out/r06_step_ab.txt 2>&1
 bash tools/c4_ab.sh "default:A3T_X=0" "stored_dbd_matrix:A3T_ATTN_DBD_VIEW=0" "two_saved_probability_tensors:A3T_ATTN_SIGNED=0" "materialised_score_gradients:A3T_ATTN_BWD_DS=0" "attention_products_on_the_128_row_kernel:A3T_GEMM_TT=0" "128x384_tiles_everywhere:A3T_GEMM_8P_TN3=1" "default_again:A3T_X=0" > gpurun_out/r06_c4_ab_final.txt 2>&1
 bash tools/trace_step.sh > gpurun_out/r06_trace.log 2>&1
 python tools/trace_analyse.py gpurun_out/trace_step.csv > gpurun_out/r06_trace_analysis.txt 2>&1
